@@ -1,0 +1,86 @@
+"""ctypes binding of the C-ABI in include/crfp_hip.h (libcrfp_hip.so, built in-tree by
+``crfp_amd/csrc/Makefile``).  There is no fallback: if the library is missing every op raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrfp_hip.so")
+
+NUM_PARAMS = 118
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("total_ms", C.c_double),
+                ("bytes", C.c_double), ("flops", C.c_double)]
+
+
+# name -> (restype, argtypes); mirrors include/crfp_hip.h one to one
+SIGNATURES = {
+    "crfp_version": (C.c_int, []),
+    "crfp_last_error_string": (C.c_char_p, []),
+    "crfp_flow_warp_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "crfp_flow_warp_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_dcnv2_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
+    "crfp_dcnv2_forward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_conv3x3_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "crfp_conv3x3_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_upsample_bilinear_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_float] * 3 + [C.c_void_p]),
+    "crfp_psnr_partial_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "crfp_dsv_param_name": (C.c_char_p, [C.c_int]),
+    "crfp_dsv_param_numel": (C.c_int, [C.c_int, C.c_int]),
+    "crfp_dsv_packed_weight_bytes": (C.c_size_t, [C.c_int]),
+    "crfp_dsv_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_dsv_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "crfp_dsv_forward_clip": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 +
+                              [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_dsv_stream_frame": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 3 +
+                              [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_fnet_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_prof_enable": (C.c_int, [C.c_int]),
+    "crfp_prof_reset": (C.c_int, []),
+    "crfp_prof_report": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),
+    "crfp_dsv_debug_fetch": (C.c_int, [C.c_char_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p] +
+                             [C.POINTER(C.c_int)] * 3 + [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libcrfp_hip.so (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C crfp_amd/csrc`. "
+                "crfp_amd has no CPU or PyTorch fallback path.")
+        # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch first so
+        # that ONE HIP runtime serves both torch and this library (streams and device pointers are
+        # shared across the C-ABI); loading in the other order leaves the process with a runtime
+        # torch's bundled HSA stack cannot drive ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().crfp_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def prof_report(cap: int = 256):
+    arr = (ProfRecord * cap)()
+    n = lib().crfp_prof_report(arr, cap)
+    return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
+                 bytes=arr[i].bytes, flops=arr[i].flops) for i in range(min(n, cap))]

@@ -1,0 +1,126 @@
+// Per-operator C-ABI entry points (NCHW tensors as the reference's Python operators pass them).
+#include "crfp_common.h"
+
+#include <cstring>
+
+using namespace crfp;
+
+static size_t q4_bytes(int n, int c, int h, int w) { return align_up((size_t)n * ((c + 3) / 4) * h * w * 16, 256); }
+
+extern "C" {
+
+size_t crfp_flow_warp_workspace_bytes(int n, int c, int h, int w) { return 2 * q4_bytes(n, c, h, w); }
+
+int crfp_flow_warp_f32(const float* x, const float* flow, float* out, int n, int c, int h, int w, int padding_mode,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !flow || !out || n < 1 || c < 1 || h < 1 || w < 1) { set_error("flow_warp: bad argument"); return CRFP_E_BADARG; }
+    if (padding_mode != CRFP_PAD_ZEROS && padding_mode != CRFP_PAD_BORDER) { set_error("flow_warp: padding_mode %d unsupported", padding_mode); return CRFP_E_UNSUPPORTED; }
+    if (!workspace || workspace_bytes < crfp_flow_warp_workspace_bytes(n, c, h, w)) { set_error("flow_warp: workspace too small"); return CRFP_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    float* xin = (float*)workspace;
+    float* xo = (float*)((char*)workspace + q4_bytes(n, c, h, w));
+    const int nq = (c + 3) / 4;
+    const long long bs = (long long)nq * h * w * 4;
+    int rc = launch_nchw_to_q4(x, xin, n, c, h, w, s);
+    if (!rc) rc = launch_flow_warp_q4(xin, bs, flow, (long long)h * w * 2, xo, bs, n, nq, h, w, padding_mode == CRFP_PAD_BORDER, s);
+    if (!rc) rc = launch_q4_to_nchw(xo, out, n, c, h, w, s);
+    return rc;
+}
+
+size_t crfp_dcnv2_workspace_bytes(int n, int cin, int cout, int h, int w, int k, int dg) {
+    if (cin == 32 && cout == 32 && dg == 8 && k == 3)
+        return 2 * q4_bytes(n, 32, h, w) + q4_bytes(n, 216, h, w) + align_up(36 * 2 * 32 * 4 * sizeof(float), 256);
+    return 256;
+}
+
+int crfp_dcnv2_forward_f32(const float* x, const float* offset, const float* mask, const float* weight,
+                           const float* bias, float* out, int n, int cin, int cout, int h, int w, int k, int pad,
+                           int dil, int dg, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !offset || !mask || !weight || !bias || !out || n < 1 || h < 1 || w < 1) { set_error("dcnv2: bad argument"); return CRFP_E_BADARG; }
+    if (k != 3 || pad != 1 || dil != 1) { set_error("dcnv2: only kernel 3, padding 1, dilation 1 (got %d,%d,%d)", k, pad, dil); return CRFP_E_UNSUPPORTED; }
+    if (dg < 1 || cin % dg != 0 || cout < 1) { set_error("dcnv2: cin %d not divisible by deformable_groups %d", cin, dg); return CRFP_E_BADARG; }
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 32 && cout == 32 && dg == 8) {
+        if (!workspace || workspace_bytes < crfp_dcnv2_workspace_bytes(n, cin, cout, h, w, k, dg)) { set_error("dcnv2: workspace too small"); return CRFP_E_WORKSPACE; }
+        char* p = (char*)workspace;
+        float* xq = (float*)p; p += q4_bytes(n, 32, h, w);
+        float* oq = (float*)p; p += q4_bytes(n, 32, h, w);
+        float* om = (float*)p; p += q4_bytes(n, 216, h, w);
+        float* wpk = (float*)p;
+        int rc = launch_nchw_to_q4(x, xq, n, 32, h, w, s);
+        if (!rc) rc = launch_offmask_nchw_to_q4(offset, mask, om, n, 144, 72, h, w, s);
+        if (!rc) rc = launch_dcn_g8_pack(weight, wpk, s);
+        if (!rc) rc = launch_dcn_g8(xq, 8LL * h * w * 4, om, 54LL * h * w * 4, wpk, bias, oq, 8LL * h * w * 4, n, h, w, s);
+        if (!rc) rc = launch_q4_to_nchw(oq, out, n, 32, h, w, s);
+        return rc;
+    }
+    return launch_dcn_generic(x, offset, mask, weight, bias, out, n, cin, cout, h, w, dg, s);
+}
+
+static ConvArgs api_conv_plan(int cin, int cout, int act, float post_scale) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = 1;
+    a.src[0].kind = SRC_NCHW;
+    a.src[0].nch = cin;
+    a.src[0].nq = (cin + 3) / 4;
+    a.kq = a.src[0].nq;
+    if (a.kq & 1) {
+        a.src[1].kind = SRC_ZERO;
+        a.src[1].nch = 1;
+        a.src[1].nq = 1;
+        a.src[1].cbase = cin;
+        a.nsrc = 2;
+        a.kq += 1;
+    }
+    a.cin_total = cin;
+    a.cout = cout;
+    a.store = ST_NCHW;
+    a.act = act;
+    a.post_scale = post_scale;
+    a.ctiles = (cout + 31) / 32;
+    return a;
+}
+
+size_t crfp_conv3x3_workspace_bytes(int n, int cin, int cout, int h, int w) {
+    (void)n; (void)h; (void)w;
+    ConvArgs a = api_conv_plan(cin, cout, 0, 1.0f);
+    return align_up(conv_packed_weight_floats(a) * sizeof(float), 256) + align_up((size_t)a.ctiles * 32 * sizeof(float), 256);
+}
+
+int crfp_conv3x3_f32(const float* x, const float* weight, const float* bias, float* out, int n, int cin, int cout, int h,
+                     int w, int act, float post_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !weight || !out || n < 1 || cin < 1 || cout < 1 || h < 1 || w < 1) { set_error("conv3x3: bad argument"); return CRFP_E_BADARG; }
+    if (act < CRFP_ACT_NONE || act > CRFP_ACT_SIGMOID) { set_error("conv3x3: unknown activation %d", act); return CRFP_E_BADARG; }
+    if (!workspace || workspace_bytes < crfp_conv3x3_workspace_bytes(n, cin, cout, h, w)) { set_error("conv3x3: workspace too small"); return CRFP_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    ConvArgs a = api_conv_plan(cin, cout, act, post_scale);
+    float* wpk = (float*)workspace;
+    float* bpk = (float*)((char*)workspace + align_up(conv_packed_weight_floats(a) * sizeof(float), 256));
+    int rc = launch_conv_pack(a, weight, bias, nullptr, nullptr, cout, wpk, bpk, s);
+    if (rc) return rc;
+    a.src[0].p = x;
+    a.src[0].bstride = (long long)cin * h * w;
+    a.ndst = 1;
+    a.dst[0].p = out;
+    a.dst[0].bstride = (long long)cout * h * w;
+    a.dst[0].q0 = 0;
+    a.dst[0].q1 = (cout + 3) / 4;
+    a.N = n; a.H = h; a.W = w;
+    a.wpk = wpk;
+    a.bpk = bpk;
+    return launch_conv_mfma(a, "conv_mfma:api_nchw", s);
+}
+
+int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, int w, int oh, int ow, float scale_h,
+                               float scale_w, float mul, void* stream) {
+    if (!x || !out || n < 1 || c < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) { set_error("upsample: bad argument"); return CRFP_E_BADARG; }
+    return launch_upsample_nchw(x, out, n, c, h, w, oh, ow, scale_h, scale_w, mul, (hipStream_t)stream);
+}
+
+int crfp_psnr_partial_f32(const float* a, const float* b, double* acc, int n, int c, int h, int w, void* stream) {
+    if (!a || !b || !acc || n < 1 || c < 1 || h < 1 || w < 1) { set_error("psnr_partial: bad argument"); return CRFP_E_BADARG; }
+    return launch_psnr_partial(a, b, acc, n, c, h, w, (hipStream_t)stream);
+}
+
+}  // extern "C"

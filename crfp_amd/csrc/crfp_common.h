@@ -1,0 +1,209 @@
+// Internal declarations shared by the HIP translation units of libcrfp_hip.so (gfx950 only).
+//
+// Activation layout ("Q4", channel-quad planes): a tensor with C channels is stored as
+//   [N][ceil(C/4)][H][W][4] float32
+// i.e. 4 consecutive channels of one pixel form one aligned 16-byte element.  Everything the
+// irregular gathers (flow_warp, DCNv2) touch is then a single 16-B vector load per bilinear
+// corner -- a DCNv2 deformable group of the 32-channel layers (32/8 = 4 channels) and the whole
+// 4-channel 8x-resolution state are exactly one quad -- and the fp32 MFMA convolutions read their
+// B operand (4 K-channels of a pixel) with one ds_read_b128 and store 4 output channels of a
+// pixel with one global_store_dwordx4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/crfp_hip.h"
+
+namespace crfp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ conv plan
+enum SrcKind : int {
+    SRC_Q4 = 0,      // Q4 tensor, nch channels
+    SRC_NCHW = 1,    // NCHW planes (API tensors / LR frames), nch channels
+    SRC_UNSHUF4 = 2, // Q4 tensor at 4x resolution read through pixel_unshuffle(4): nch = 16 * C_hi
+    SRC_FLOW2 = 3,   // [H][W][2] (dx,dy) pairs -> quad (dx,dy,0,0)
+    SRC_ZERO = 4     // padding quad(s)
+};
+
+enum StoreMode : int {
+    ST_Q4 = 0,      // Q4 destination(s), optional channel-quad ranges to different tensors
+    ST_PS = 1,      // pixel_shuffle(r) fused into the store, Q4 destination at (H*r, W*r)
+    ST_NCHW = 2,    // NCHW planes
+    ST_OFFMASK = 3  // DCN offset/mask epilogue: quads < n_off_quads: 10*tanh + flow(y,x); rest: sigmoid
+};
+
+struct ConvSrc {
+    const float* p;
+    long long bstride;  // floats between batch items
+    int kind;
+    int nch;            // reference channels contributed to the concat
+    int nq;             // K-quads occupied
+    int cbase;          // first reference input channel of this source in the conv weight
+};
+
+struct ConvDst {
+    float* p;           // first destination plane for cout-quad q0
+    long long bstride;
+    int q0, q1;         // cout-quad range [q0,q1)
+};
+
+#define CRFP_MAX_SRC 5
+#define CRFP_MAX_DST 3
+
+struct ConvArgs {
+    ConvSrc src[CRFP_MAX_SRC];
+    ConvDst dst[CRFP_MAX_DST];
+    const float* wpk;   // packed weights (see pack_index)
+    const float* bpk;   // packed bias [ctiles*32]
+    const float* resid; // Q4, same cout-quad indexing, added after activation
+    const float* flow;  // [H][W][2] for ST_OFFMASK
+    long long resid_bstride, flow_bstride;
+    int nsrc, ndst;
+    int kq;             // total K quads (even)
+    int cin_total;      // Cin of the reference weight tensor
+    int cout;           // Cout of the reference weight tensor
+    int ctiles;         // ceil(packed rows / 32)
+    int N, H, W;
+    int act;
+    float post_scale;
+    int store, ps_r;
+    int n_off_quads;
+    int dstH, dstW;
+};
+
+// packed row (0..ctiles*32) -> reference output channel, or -1 (padding)
+__host__ __device__ inline int conv_row_to_cout(int row, int cout, int store, int ps_r) {
+    if (store == ST_PS) {
+        const int r2 = ps_r * ps_r, co_n = cout / r2;
+        const int cq = row >> 2, rr = row & 3;
+        const int Q = cq / r2, s = cq - Q * r2;
+        const int co = 4 * Q + rr;
+        return co < co_n ? co * r2 + s : -1;
+    }
+    return row < cout ? row : -1;
+}
+
+// number of packed rows needed
+__host__ __device__ inline int conv_packed_rows(int cout, int store, int ps_r) {
+    if (store == ST_PS) {
+        const int r2 = ps_r * ps_r, co_n = cout / r2;
+        return ((co_n + 3) / 4) * r2 * 4;
+    }
+    return cout;
+}
+
+// (source-local K-quad, component) -> source-local reference channel, or -1
+__host__ __device__ inline int conv_k_to_cin(int kind, int nch, int kql, int comp) {
+    switch (kind) {
+        case SRC_Q4:
+        case SRC_NCHW: {
+            const int c = 4 * kql + comp;
+            return c < nch ? c : -1;
+        }
+        case SRC_UNSHUF4: {  // hi-res quad Qp, sub-position ij: unshuffled channel (4*Qp+comp)*16 + ij
+            const int Qp = kql >> 4, ij = kql & 15;
+            const int c = (4 * Qp + comp) * 16 + ij;
+            return c < nch ? c : -1;
+        }
+        case SRC_FLOW2:
+            return comp < 2 ? comp : -1;
+        default:
+            return -1;
+    }
+}
+
+__host__ __device__ inline int src_quads(int kind, int nch) {
+    switch (kind) {
+        case SRC_Q4:
+        case SRC_NCHW: return (nch + 3) / 4;
+        case SRC_UNSHUF4: return ((nch / 16 + 3) / 4) * 16;
+        case SRC_FLOW2: return 1;
+        default: return nch;  // SRC_ZERO: nch carries the quad count
+    }
+}
+
+// ------------------------------------------------------------------ narrow (VALU stencil) conv plan
+enum NarrowEpi : int {
+    NE_PLAIN = 0,    // Q4 quad out (cout <= 4), act, optional residual
+    NE_BLEND = 1,    // state = lrelu(mask ? conv : centre value of source 0)  (conv_tttf + fovea blend)
+    NE_LAST = 2,     // NCHW out (3 or 1 planes) = conv + base (x8 bilinear LR from a Q4 quad)
+    NE_OFFMASK3 = 3  // (10*tanh(o0)+fy, 10*tanh(o1)+fx, sigmoid(o2), 0)  (dcn_3 shared offset/mask)
+};
+
+struct NarrowArgs {
+    ConvSrc src[3];
+    const float* wpk;  // [tap][kq][comp][4]
+    const float* bpk;  // [4]
+    float* dst;
+    const float* resid;
+    const float* flow;
+    const float* base;
+    const uint8_t* mask;
+    long long dst_bstride, resid_bstride, flow_bstride, base_bstride, mask_bstride;
+    int nsrc, kq, cin_total, cout;
+    int N, H, W;
+    int act, epi, y_only;
+    float post_scale;
+};
+
+// ------------------------------------------------------------------ profiling + errors
+void set_error(const char* fmt, ...);
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t s, double bytes, double flops);
+    ~ProfScope();
+    hipStream_t s_;
+    int slot_;
+};
+bool prof_enabled();
+
+#define CRFP_CHECK_LAUNCH()                                     \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) {                                \
+            set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return (int)e__;                                    \
+        }                                                       \
+    } while (0)
+
+// ------------------------------------------------------------------ launchers (one per kernel family)
+// conv_mfma.hip
+size_t conv_packed_weight_floats(const ConvArgs& a);
+int launch_conv_pack(const ConvArgs& a, const float* w_oihw, const float* bias, const float* w2, const float* bias2,
+                     int cout_split, float* wpk, float* bpk, hipStream_t s);
+int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s);
+// conv_narrow.hip
+size_t narrow_packed_weight_floats(const NarrowArgs& a);
+int launch_narrow_pack(const NarrowArgs& a, const float* w_oihw, const float* bias, const float* w2, const float* bias2,
+                       int cout_split, float* wpk, float* bpk, hipStream_t s);
+int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s);
+// gather.hip
+int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
+                        int N, int nq, int H, int W, int border, hipStream_t s);
+int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
+                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
+int launch_dcn_g8_pack(const float* w_oihw, float* wpk, hipStream_t s);  // [36][2][32][4]
+int launch_dcn3(const float* x, long long xb, const float* offmask3, long long omb, const float* w_oihw,
+                const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
+int launch_dcn_generic(const float* x, const float* offset, const float* mask, const float* w, const float* b,
+                       float* out, int N, int cin, int cout, int H, int W, int dg, hipStream_t s);
+// resample.hip
+int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, hipStream_t s);
+int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, hipStream_t s);
+int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
+                       int OW, float sh, float sw, float mul, hipStream_t s);
+int launch_upsample_nchw(const float* x, float* out, int N, int C, int H, int W, int OH, int OW, float sh, float sw,
+                         float mul, hipStream_t s);
+int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long ob, int N, int H, int W, int r,
+                  hipStream_t s);
+int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W,
+                       hipStream_t s);
+int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s);
+int launch_offmask_nchw_to_q4(const float* offset, const float* mask, float* out, int N, int noff, int nmask, int H,
+                              int W, hipStream_t s);
+int launch_psnr_partial(const float* a, const float* b, double* acc, int N, int C, int H, int W, hipStream_t s);
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace crfp

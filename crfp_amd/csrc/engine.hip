@@ -1,0 +1,635 @@
+// CRFP_DSV engine: host-side schedule of the recurrent per-frame inference loop
+// (reference model/CRFP.py:1387-1706, mid_channels=32, hr_dcn=True, offset_prop=True) over the
+// HIP kernels of this library.  One call = one clip (or one streamed frame): ~50 asynchronous
+// launches per frame on the caller's stream, no host synchronisation, all intermediates in the
+// caller-provided workspace, weights pre-packed once (crfp_dsv_pack_weights).
+//
+// What is fused away relative to the reference's op-by-op graph:
+//   * every torch.cat (:331,336,1547,1573,1586,1589,1629,1672) -> multi-source conv staging
+//   * torch.chunk / split_ratio plumbing (:1592-1596) -> two destination channel ranges of one conv
+//   * F.pixel_shuffle (:192) / pixel_unshuffle (:28-42) -> weight-row / K permutation + address math
+//   * dcn_offset and dcn_mask convs (:337,339) -> one 32->216 conv with the 10*tanh(+flow.flip) /
+//     sigmoid epilogue (:338,340,349)
+//   * dcn_3's 9x replication of offset and mask (:343-347) -> never materialised
+//   * the i == 0 branch's zero tensors (:1637,1666) -> K-restricted weight packs (0*w == 0 exactly)
+//   * fovea blend + LeakyReLU (:1674-1675) and conv_last + bilinear base (:1678-1683) -> epilogues
+#include "crfp_common.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace crfp {
+
+struct ConvDef { const char* stem; int cout, cin; };
+// order == reference state_dict order (weight, bias per entry); checked against the imported
+// reference by tests/golden/make_golden.py through crfp_amd/synth.py
+static const ConvDef kConvs[59] = {
+    {"spynet.encoder1.0", 32, 6}, {"spynet.encoder1.2", 32, 32}, {"spynet.encoder2.0", 64, 32},
+    {"spynet.encoder2.2", 64, 64}, {"spynet.encoder3.0", 128, 64}, {"spynet.encoder3.2", 128, 128},
+    {"spynet.decoder1.0", 256, 128}, {"spynet.decoder1.2", 256, 256}, {"spynet.decoder2.0", 128, 256},
+    {"spynet.decoder2.2", 128, 128}, {"spynet.decoder3.0", 64, 128}, {"spynet.decoder3.2", 64, 64},
+    {"spynet.flow.0", 32, 64}, {"spynet.flow.2", 2, 32},
+    {"dcn_0.dcn_block.0", 32, 66}, {"dcn_0.dcn_block.2", 32, 32}, {"dcn_0.dcn_offset", 144, 32},
+    {"dcn_0.dcn_mask", 72, 32}, {"dcn_0.dcn", 32, 32},
+    {"dcn_1.conv_fuse", 32, 64}, {"dcn_1.dcn_block.0", 32, 66}, {"dcn_1.dcn_block.2", 32, 32},
+    {"dcn_1.dcn_offset", 144, 32}, {"dcn_1.dcn_mask", 72, 32}, {"dcn_1.dcn", 32, 32},
+    {"dcn_2.conv_fuse", 32, 64}, {"dcn_2.dcn_block.0", 32, 66}, {"dcn_2.dcn_block.2", 32, 32},
+    {"dcn_2.dcn_offset", 144, 32}, {"dcn_2.dcn_mask", 72, 32}, {"dcn_2.dcn", 32, 32},
+    {"dcn_3.upsample.upsample_conv", 64, 32}, {"dcn_3.conv_fuse", 4, 8}, {"dcn_3.dcn_block.0", 4, 10},
+    {"dcn_3.dcn_block.2", 4, 4}, {"dcn_3.dcn_offset", 2, 4}, {"dcn_3.dcn_mask", 1, 4}, {"dcn_3.dcn", 4, 4},
+    {"encoder_lr.slice1.0", 32, 3}, {"encoder_lr.slice1.2", 32, 32}, {"encoder_hr.slice1.0", 4, 6},
+    {"encoder_hr.slice1.2", 4, 4}, {"conv_tttf", 4, 8},
+    {"forward_resblocks_0.main.0", 32, 64}, {"forward_resblocks_0.main.2.0.conv1", 32, 32},
+    {"forward_resblocks_0.main.2.0.conv2", 32, 32},
+    {"forward_resblocks_1.main.0", 32, 64}, {"forward_resblocks_1.main.2.0.conv1", 32, 32},
+    {"forward_resblocks_1.main.2.0.conv2", 32, 32},
+    {"forward_resblocks_2.main.0", 32, 64}, {"forward_resblocks_2.main.2.0.conv1", 32, 32},
+    {"forward_resblocks_2.main.2.0.conv2", 32, 32},
+    {"forward_resblocks_3.main.0", 4, 8}, {"forward_resblocks_3.main.2.0.conv1", 4, 4},
+    {"forward_resblocks_3.main.2.0.conv2", 4, 4},
+    {"downsample.downsample_conv", 32, 64}, {"upsample.upsample_conv", 96, 32},
+    {"upsample_post.upsample_conv", 64, 24}, {"conv_last", 3, 4}};
+
+enum { CI_D3_UPS = 31, CI_D3_FUSE = 32, CI_D3_B0 = 33, CI_D3_B2 = 34, CI_D3_OFF = 35, CI_D3_MASK = 36, CI_D3_DCN = 37,
+       CI_ENC_LR0 = 38, CI_ENC_LR1 = 39, CI_ENC_HR0 = 40, CI_ENC_HR1 = 41, CI_TTTF = 42, CI_RB3 = 52, CI_DOWN = 55,
+       CI_UPS = 56, CI_UPP = 57, CI_LAST = 58 };
+static inline int ci_dcn(int lvl, int which) {  // which: 0 fuse, 1 block.0, 2 block.2, 3 offset, 4 mask, 5 dcn
+    static const int base[3] = {13, 19, 25};     // lvl 0 has no conv_fuse: block.0 is 14
+    return base[lvl] + which;
+}
+static inline int ci_rb(int lvl, int which) { return 43 + 3 * lvl + which; }
+
+static int conv_cout(int ci, int y_only) { return (ci == CI_LAST && y_only) ? 1 : kConvs[ci].cout; }
+
+// ------------------------------------------------------------------ packed items
+enum ItemType { T_MFMA = 0, T_NARROW = 1, T_DCN8 = 2, T_RAW = 3 };
+struct Item {
+    int type = T_MFMA;
+    ConvArgs c;
+    NarrowArgs nw;
+    int w1 = -1, w2 = -1;
+    size_t off_w = 0, off_b = 0, n_w = 0, n_b = 0;  // float offsets / counts inside the packed buffer
+    const char* name = "";
+};
+
+enum ItemId {
+    IT_F0 = 0,  // .. IT_F0+13 : FNet
+    IT_ENC_LR0 = 14, IT_ENC_LR1, IT_UPS, IT_DOWN,
+    IT_LVL0,  // per level 9 items: FUSE, DB0, DB1, OM, DCNW, RB0, RB0F, RB1, RB2
+    IT_UPP = IT_LVL0 + 27, IT_POFF,
+    IT_EH0, IT_EH1, IT_D3B0, IT_D3B1, IT_D3FUSE, IT_D3OM, IT_D3W, IT_R3_0, IT_R3_0F, IT_R3_1, IT_R3_2, IT_TTTF,
+    IT_LAST, IT_COUNT
+};
+enum { L_FUSE = 0, L_DB0, L_DB1, L_OM, L_DCNW, L_RB0, L_RB0F, L_RB1, L_RB2 };
+static inline int it_lvl(int lvl, int which) { return IT_LVL0 + 9 * lvl + which; }
+
+struct SrcSpec { int kind, nch; };
+
+static ConvArgs make_mfma(int y_only, int ci, int ci2, std::vector<SrcSpec> srcs, int store, int ps_r, int act,
+                          float post_scale, int cbase_override = -1) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    int kq = 0, cbase = 0;
+    a.nsrc = 0;
+    for (auto& s : srcs) {
+        ConvSrc& d = a.src[a.nsrc++];
+        d.kind = s.kind;
+        d.nch = s.nch;
+        d.nq = src_quads(s.kind, s.nch);
+        d.cbase = cbase;
+        if (s.kind != SRC_ZERO) cbase += s.nch;
+        kq += d.nq;
+    }
+    (void)cbase_override;
+    if (kq & 1) {
+        ConvSrc& d = a.src[a.nsrc++];
+        d.kind = SRC_ZERO;
+        d.nch = 1;
+        d.nq = 1;
+        d.cbase = cbase;
+        kq += 1;
+    }
+    a.kq = kq;
+    a.cin_total = kConvs[ci].cin;
+    a.cout = conv_cout(ci, y_only) + (ci2 >= 0 ? conv_cout(ci2, y_only) : 0);
+    a.store = store;
+    a.ps_r = ps_r;
+    a.act = act;
+    a.post_scale = post_scale;
+    a.ctiles = (conv_packed_rows(a.cout, store, ps_r) + 31) / 32;
+    return a;
+}
+
+static NarrowArgs make_narrow(int y_only, int ci, int ci2, std::vector<SrcSpec> srcs, int act, int epi) {
+    NarrowArgs a;
+    memset(&a, 0, sizeof(a));
+    int kq = 0, cbase = 0;
+    for (auto& s : srcs) {
+        ConvSrc& d = a.src[a.nsrc++];
+        d.kind = s.kind;
+        d.nch = s.nch;
+        d.nq = src_quads(s.kind, s.nch);
+        d.cbase = cbase;
+        cbase += s.nch;
+        kq += d.nq;
+    }
+    a.kq = kq;
+    a.cin_total = kConvs[ci].cin;
+    a.cout = conv_cout(ci, y_only) + (ci2 >= 0 ? conv_cout(ci2, y_only) : 0);
+    a.act = act;
+    a.epi = epi;
+    a.y_only = y_only;
+    a.post_scale = 1.0f;
+    return a;
+}
+
+struct Model {
+    Item items[IT_COUNT];
+    size_t total_floats = 0;
+    int y_only = 0;
+
+    void add_mfma(int id, const char* name, int ci, int ci2, std::vector<SrcSpec> srcs, int store, int ps_r, int act,
+                  float post_scale = 1.0f) {
+        Item& it = items[id];
+        it.type = T_MFMA;
+        it.name = name;
+        it.w1 = ci;
+        it.w2 = ci2;
+        it.c = make_mfma(y_only, ci, ci2, srcs, store, ps_r, act, post_scale);
+        it.n_w = conv_packed_weight_floats(it.c);
+        it.n_b = (size_t)it.c.ctiles * 32;
+    }
+    void add_narrow(int id, const char* name, int ci, int ci2, std::vector<SrcSpec> srcs, int act, int epi) {
+        Item& it = items[id];
+        it.type = T_NARROW;
+        it.name = name;
+        it.w1 = ci;
+        it.w2 = ci2;
+        it.nw = make_narrow(y_only, ci, ci2, srcs, act, epi);
+        it.n_w = narrow_packed_weight_floats(it.nw);
+        it.n_b = 4;
+    }
+
+    explicit Model(int y_only_) : y_only(y_only_) {
+        const int Q = SRC_Q4;
+        static const char* fn[14] = {"conv_mfma:fnet.enc1a", "conv_mfma:fnet.enc1b", "conv_mfma:fnet.enc2a",
+                                     "conv_mfma:fnet.enc2b", "conv_mfma:fnet.enc3a", "conv_mfma:fnet.enc3b",
+                                     "conv_mfma:fnet.dec1a", "conv_mfma:fnet.dec1b", "conv_mfma:fnet.dec2a",
+                                     "conv_mfma:fnet.dec2b", "conv_mfma:fnet.dec3a", "conv_mfma:fnet.dec3b",
+                                     "conv_mfma:fnet.flow0", "conv_mfma:fnet.flow2"};
+        add_mfma(IT_F0, fn[0], 0, -1, {{SRC_NCHW, 3}, {SRC_NCHW, 3}}, ST_Q4, 0, CRFP_ACT_RELU);
+        for (int i = 1; i < 13; ++i) add_mfma(IT_F0 + i, fn[i], i, -1, {{Q, kConvs[i].cin}}, ST_Q4, 0, CRFP_ACT_RELU);
+        add_mfma(IT_F0 + 13, fn[13], 13, -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_TANH, 256.0f);
+        add_mfma(IT_ENC_LR0, "conv_mfma:enc_lr0", CI_ENC_LR0, -1, {{SRC_NCHW, 3}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+        add_mfma(IT_ENC_LR1, "conv_mfma:enc_lr1", CI_ENC_LR1, -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+        add_mfma(IT_UPS, "conv_mfma:upsample_ps2", CI_UPS, -1, {{Q, 32}}, ST_PS, 2, CRFP_ACT_NONE);
+        add_mfma(IT_DOWN, "conv_mfma:downsample_unshuf4", CI_DOWN, -1, {{SRC_UNSHUF4, 64}}, ST_Q4, 0, CRFP_ACT_NONE);
+        for (int l = 0; l < 3; ++l) {
+            if (l > 0)
+                add_mfma(it_lvl(l, L_FUSE), "conv_mfma:dcn.conv_fuse", ci_dcn(l, 0), -1, {{Q, 32}, {Q, 32}}, ST_Q4, 0,
+                         CRFP_ACT_LRELU01);
+            // dcn_block.0 input = [cur = prop(24) | carry(8)] | warped prev(32) | flow(2)   (:331,1586)
+            add_mfma(it_lvl(l, L_DB0), "conv_mfma:dcn.block0", ci_dcn(l, 1), -1,
+                     {{Q, 24}, {Q, 8}, {Q, 32}, {SRC_FLOW2, 2}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+            add_mfma(it_lvl(l, L_DB1), "conv_mfma:dcn.block2", ci_dcn(l, 2), -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+            add_mfma(it_lvl(l, L_OM), "conv_mfma:dcn.offset_mask", ci_dcn(l, 3), ci_dcn(l, 4), {{Q, 32}}, ST_OFFMASK, 0,
+                     CRFP_ACT_NONE);
+            items[it_lvl(l, L_OM)].c.n_off_quads = 36;
+            Item& dw = items[it_lvl(l, L_DCNW)];
+            dw.type = T_DCN8;
+            dw.name = "dcn_g8_weights";
+            dw.w1 = ci_dcn(l, 5);
+            dw.n_w = 36 * 2 * 32 * 4;
+            dw.n_b = 32;
+            // resblocks input = [prop(24) | carry(8)] | aligned(32)   (:1589); first frame: prop only (:1637)
+            add_mfma(it_lvl(l, L_RB0), "conv_mfma:res.main0", ci_rb(l, 0), -1, {{Q, 24}, {Q, 8}, {Q, 32}}, ST_Q4, 0,
+                     CRFP_ACT_LRELU01);
+            add_mfma(it_lvl(l, L_RB0F), "conv_mfma:res.main0_first", ci_rb(l, 0), -1, {{Q, 24}}, ST_Q4, 0,
+                     CRFP_ACT_LRELU01);
+            add_mfma(it_lvl(l, L_RB1), "conv_mfma:res.conv1", ci_rb(l, 1), -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_RELU);
+            add_mfma(it_lvl(l, L_RB2), "conv_mfma:res.conv2_add", ci_rb(l, 2), -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_NONE);
+        }
+        add_mfma(IT_UPP, "conv_mfma:upsample_post_ps4", CI_UPP, -1, {{Q, 24}}, ST_PS, 4, CRFP_ACT_LRELU01);
+        add_mfma(IT_POFF, "conv_mfma:dcn3.preoffset_ps4", CI_D3_UPS, -1, {{Q, 32}}, ST_PS, 4, CRFP_ACT_NONE, 2.0f);
+        add_narrow(IT_EH0, "conv_narrow:enc_hr0", CI_ENC_HR0, -1, {{Q, 3}, {Q, 3}}, CRFP_ACT_LRELU01, NE_PLAIN);
+        add_narrow(IT_EH1, "conv_narrow:enc_hr1", CI_ENC_HR1, -1, {{Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
+        add_narrow(IT_D3B0, "conv_narrow:dcn3.block0", CI_D3_B0, -1, {{Q, 4}, {Q, 4}, {SRC_FLOW2, 2}}, CRFP_ACT_LRELU01,
+                   NE_PLAIN);
+        add_narrow(IT_D3B1, "conv_narrow:dcn3.block2", CI_D3_B2, -1, {{Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
+        add_narrow(IT_D3FUSE, "conv_narrow:dcn3.conv_fuse", CI_D3_FUSE, -1, {{Q, 4}, {Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
+        add_narrow(IT_D3OM, "conv_narrow:dcn3.offset_mask", CI_D3_OFF, CI_D3_MASK, {{Q, 4}}, CRFP_ACT_NONE, NE_OFFMASK3);
+        Item& d3 = items[IT_D3W];
+        d3.type = T_RAW;
+        d3.name = "dcn3_weights";
+        d3.w1 = CI_D3_DCN;
+        d3.n_w = 4 * 4 * 9;
+        d3.n_b = 4;
+        add_narrow(IT_R3_0, "conv_narrow:res3.main0", CI_RB3, -1, {{Q, 4}, {Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
+        add_narrow(IT_R3_0F, "conv_narrow:res3.main0_first", CI_RB3, -1, {{Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
+        add_narrow(IT_R3_1, "conv_narrow:res3.conv1", CI_RB3 + 1, -1, {{Q, 4}}, CRFP_ACT_RELU, NE_PLAIN);
+        add_narrow(IT_R3_2, "conv_narrow:res3.conv2_add", CI_RB3 + 2, -1, {{Q, 4}}, CRFP_ACT_NONE, NE_PLAIN);
+        add_narrow(IT_TTTF, "conv_narrow:tttf_blend", CI_TTTF, -1, {{Q, 4}, {Q, 4}}, CRFP_ACT_NONE, NE_BLEND);
+        add_narrow(IT_LAST, "conv_narrow:last_plus_base", CI_LAST, -1, {{Q, 4}}, CRFP_ACT_NONE, NE_LAST);
+        size_t cur = 0;
+        for (int i = 0; i < IT_COUNT; ++i) {
+            Item& it = items[i];
+            if (it.w1 < 0) continue;
+            it.off_w = cur;
+            cur += (it.n_w + 63) / 64 * 64;
+            it.off_b = cur;
+            cur += (it.n_b + 63) / 64 * 64;
+        }
+        total_floats = cur;
+    }
+};
+
+static const Model& model_for(int y_only) {
+    static const Model m0(0), m1(1);
+    return y_only ? m1 : m0;
+}
+
+// ------------------------------------------------------------------ workspace arena
+struct Buf { std::string name; size_t off; int N, nq, H, W, kind; };  // kind 0 = Q4, 1 = NHW2
+struct Arena {
+    size_t cur = 0;
+    std::vector<Buf> bufs;
+    size_t take(const char* name, int N, int nq, int H, int W, int kind = 0) {
+        const size_t floats = kind == 0 ? (size_t)N * nq * H * W * 4 : (size_t)N * H * W * 2;
+        const size_t off = cur;
+        cur += align_up(floats * sizeof(float), 256);
+        bufs.push_back({name, off, N, nq, H, W, kind});
+        return off;
+    }
+};
+
+struct Q4 {
+    float* p = nullptr;
+    int nq = 0, H = 0, W = 0;
+    long long bs() const { return (long long)nq * H * W * 4; }
+    float* plane(int q) const { return p + (long long)q * H * W * 4; }
+};
+
+struct Layout {
+    Arena A;
+    int t, h, w;
+    // persistent recurrent state first (stable offsets for streaming)
+    size_t state_hr, carry;
+    // clip-level
+    size_t flow_lr, e_lr0, x_lr;
+    // FNet
+    size_t fa0, fa1, fp1, fb0, fb1, fp2, fc0, fc1, fp3, fd0, fd1, fu1, fe0, fe1, fu2, ff0, ff1, fu3, fg0, fg1;
+    // frame-level
+    size_t xin8, eh, x_hr, prop_a, prop_b, flow2, flow8, prev2, prev2w, prevhrw, carryw, fa, fb, offfeat[3], offmask,
+        aligned, y0, y1, up, poff, g0, g1, g2, om3, al3, z0, z1, feat;
+    int h1, w1, h2, w2, h3, w3;
+
+    Layout(int t_, int h_, int w_) : t(t_), h(h_), w(w_) {
+        const int nb = t > 1 ? t - 1 : 1;
+        const int H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
+        h1 = h / 2; w1 = w / 2; h2 = h1 / 2; w2 = w1 / 2; h3 = h2 / 2; w3 = w2 / 2;
+        state_hr = A.take("state_hr", 1, 1, H8, W8);
+        carry = A.take("carry", 1, 6, H2, W2);
+        flow_lr = A.take("flow_lr", nb, 1, h, w);
+        e_lr0 = A.take("enc_lr0", t, 8, h, w);
+        x_lr = A.take("x_lr", t, 8, h, w);
+        fa0 = A.take("fnet.a0", nb, 8, h, w);
+        fa1 = A.take("fnet.a1", nb, 8, h, w);
+        fp1 = A.take("fnet.p1", nb, 8, h1, w1);
+        fb0 = A.take("fnet.b0", nb, 16, h1, w1);
+        fb1 = A.take("fnet.b1", nb, 16, h1, w1);
+        fp2 = A.take("fnet.p2", nb, 16, h2, w2);
+        fc0 = A.take("fnet.c0", nb, 32, h2, w2);
+        fc1 = A.take("fnet.c1", nb, 32, h2, w2);
+        fp3 = A.take("fnet.p3", nb, 32, h3, w3);
+        fd0 = A.take("fnet.d0", nb, 64, h3, w3);
+        fd1 = A.take("fnet.d1", nb, 64, h3, w3);
+        fu1 = A.take("fnet.u1", nb, 64, 2 * h3, 2 * w3);
+        fe0 = A.take("fnet.e0", nb, 32, 2 * h3, 2 * w3);
+        fe1 = A.take("fnet.e1", nb, 32, 2 * h3, 2 * w3);
+        fu2 = A.take("fnet.u2", nb, 32, 4 * h3, 4 * w3);
+        ff0 = A.take("fnet.f0", nb, 16, 4 * h3, 4 * w3);
+        ff1 = A.take("fnet.f1", nb, 16, 4 * h3, 4 * w3);
+        fu3 = A.take("fnet.u3", nb, 16, 8 * h3, 8 * w3);
+        fg0 = A.take("fnet.g0", nb, 8, 8 * h3, 8 * w3);
+        fg1 = A.take("fnet.g1", nb, 1, 8 * h3, 8 * w3);
+        xin8 = A.take("xin8", 1, 2, H8, W8);
+        eh = A.take("enc_hr0", 1, 1, H8, W8);
+        x_hr = A.take("x_hr", 1, 1, H8, W8);
+        prop_a = A.take("prop_a", 1, 6, H2, W2);
+        prop_b = A.take("prop_b", 1, 6, H2, W2);
+        flow2 = A.take("flow2", 1, 0, H2, W2, 1);
+        flow8 = A.take("flow8", 1, 0, H8, W8, 1);
+        prev2 = A.take("prev2", 1, 8, H2, W2);
+        prev2w = A.take("prev2w", 1, 8, H2, W2);
+        prevhrw = A.take("prevhrw", 1, 1, H8, W8);
+        carryw = A.take("carryw", 1, 6, H2, W2);
+        fa = A.take("dcn.fa", 1, 8, H2, W2);
+        fb = A.take("dcn.fb", 1, 8, H2, W2);
+        for (int l = 0; l < 3; ++l) offfeat[l] = A.take(l == 0 ? "offfeat0" : (l == 1 ? "offfeat1" : "offfeat2"), 1, 8, H2, W2);
+        offmask = A.take("offmask", 1, 54, H2, W2);
+        aligned = A.take("aligned", 1, 8, H2, W2);
+        y0 = A.take("res.y0", 1, 8, H2, W2);
+        y1 = A.take("res.y1", 1, 8, H2, W2);
+        up = A.take("up", 1, 1, H8, W8);
+        poff = A.take("poff", 1, 1, H8, W8);
+        g0 = A.take("dcn3.g0", 1, 1, H8, W8);
+        g1 = A.take("dcn3.g1", 1, 1, H8, W8);
+        g2 = A.take("dcn3.g2", 1, 1, H8, W8);
+        om3 = A.take("om3", 1, 1, H8, W8);
+        al3 = A.take("aligned3", 1, 1, H8, W8);
+        z0 = A.take("res3.z0", 1, 1, H8, W8);
+        z1 = A.take("res3.z1", 1, 1, H8, W8);
+        feat = A.take("feat", 1, 1, H8, W8);
+    }
+    size_t bytes() const { return A.cur; }
+};
+
+struct Runner {
+    const Model& M;
+    const float* packed;
+    char* ws;
+    const Layout& L;
+    hipStream_t s;
+    int rc = 0;
+
+    float* F(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+    Q4 q(size_t off, int nq, int H, int W) const { Q4 r; r.p = F(off); r.nq = nq; r.H = H; r.W = W; return r; }
+
+    struct SrcBind { const float* p; long long bs; };
+    struct DstBind { float* p; long long bs; int q0, q1; };
+
+    void mfma(int id, int N, int H, int W, std::vector<SrcBind> srcs, std::vector<DstBind> dsts, int dstH = 0, int dstW = 0,
+              const float* resid = nullptr, long long resid_bs = 0, const float* flow = nullptr, long long flow_bs = 0) {
+        if (rc) return;
+        const Item& it = M.items[id];
+        ConvArgs a = it.c;
+        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i].p; a.src[i].bstride = srcs[i].bs; }
+        a.ndst = (int)dsts.size();
+        for (size_t i = 0; i < dsts.size(); ++i) { a.dst[i].p = dsts[i].p; a.dst[i].bstride = dsts[i].bs; a.dst[i].q0 = dsts[i].q0; a.dst[i].q1 = dsts[i].q1; }
+        a.N = N; a.H = H; a.W = W; a.dstH = dstH; a.dstW = dstW;
+        a.resid = resid; a.resid_bstride = resid_bs; a.flow = flow; a.flow_bstride = flow_bs;
+        a.wpk = packed + it.off_w;
+        a.bpk = packed + it.off_b;
+        rc = launch_conv_mfma(a, it.name, s);
+    }
+    // plain Q4 -> Q4 conv on whole tensors
+    void mfma_q(int id, int N, const Q4& in, const Q4& out) {
+        mfma(id, N, in.H, in.W, {{in.p, in.bs()}}, {{out.p, out.bs(), 0, out.nq}});
+    }
+    void narrow(int id, int H, int W, std::vector<const float*> srcs, float* dst, const float* resid = nullptr,
+                const float* flow = nullptr, const float* base = nullptr, const uint8_t* mask = nullptr) {
+        if (rc) return;
+        const Item& it = M.items[id];
+        NarrowArgs a = it.nw;
+        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i]; a.src[i].bstride = 0; }
+        a.N = 1; a.H = H; a.W = W;
+        a.dst = dst; a.resid = resid; a.flow = flow; a.base = base; a.mask = mask;
+        a.wpk = packed + it.off_w;
+        a.bpk = packed + it.off_b;
+        rc = launch_narrow(a, it.name, s);
+    }
+#define RUN(expr) do { if (!rc) rc = (expr); } while (0)
+
+    // FNet over nb pairs (reference model/CRFP.py:797-814); cur/prev are NCHW 3-channel frames
+    void fnet(int nb, const float* cur, long long cur_bs, const float* prev, long long prev_bs) {
+        const int h = L.h, w = L.w;
+        Q4 a0 = q(L.fa0, 8, h, w), a1 = q(L.fa1, 8, h, w), p1 = q(L.fp1, 8, L.h1, L.w1);
+        Q4 b0 = q(L.fb0, 16, L.h1, L.w1), b1 = q(L.fb1, 16, L.h1, L.w1), p2 = q(L.fp2, 16, L.h2, L.w2);
+        Q4 c0 = q(L.fc0, 32, L.h2, L.w2), c1 = q(L.fc1, 32, L.h2, L.w2), p3 = q(L.fp3, 32, L.h3, L.w3);
+        Q4 d0 = q(L.fd0, 64, L.h3, L.w3), d1 = q(L.fd1, 64, L.h3, L.w3), u1 = q(L.fu1, 64, 2 * L.h3, 2 * L.w3);
+        Q4 e0 = q(L.fe0, 32, 2 * L.h3, 2 * L.w3), e1 = q(L.fe1, 32, 2 * L.h3, 2 * L.w3), u2 = q(L.fu2, 32, 4 * L.h3, 4 * L.w3);
+        Q4 f0 = q(L.ff0, 16, 4 * L.h3, 4 * L.w3), f1 = q(L.ff1, 16, 4 * L.h3, 4 * L.w3), u3 = q(L.fu3, 16, 8 * L.h3, 8 * L.w3);
+        Q4 g0 = q(L.fg0, 8, 8 * L.h3, 8 * L.w3), g1 = q(L.fg1, 1, 8 * L.h3, 8 * L.w3), fl = q(L.flow_lr, 1, h, w);
+        mfma(IT_F0, nb, h, w, {{cur, cur_bs}, {prev, prev_bs}}, {{a0.p, a0.bs(), 0, 8}});
+        mfma_q(IT_F0 + 1, nb, a0, a1);
+        RUN(launch_avgpool2_q4(a1.p, a1.bs(), p1.p, p1.bs(), nb, 8, h, w, s));
+        mfma_q(IT_F0 + 2, nb, p1, b0);
+        mfma_q(IT_F0 + 3, nb, b0, b1);
+        RUN(launch_avgpool2_q4(b1.p, b1.bs(), p2.p, p2.bs(), nb, 16, L.h1, L.w1, s));
+        mfma_q(IT_F0 + 4, nb, p2, c0);
+        mfma_q(IT_F0 + 5, nb, c0, c1);
+        RUN(launch_avgpool2_q4(c1.p, c1.bs(), p3.p, p3.bs(), nb, 32, L.h2, L.w2, s));
+        mfma_q(IT_F0 + 6, nb, p3, d0);
+        mfma_q(IT_F0 + 7, nb, d0, d1);
+        RUN(launch_upsample_q4(d1.p, d1.bs(), u1.p, u1.bs(), nb, 64, d1.H, d1.W, u1.H, u1.W, 0.5f, 0.5f, 1.0f, s));
+        mfma_q(IT_F0 + 8, nb, u1, e0);
+        mfma_q(IT_F0 + 9, nb, e0, e1);
+        RUN(launch_upsample_q4(e1.p, e1.bs(), u2.p, u2.bs(), nb, 32, e1.H, e1.W, u2.H, u2.W, 0.5f, 0.5f, 1.0f, s));
+        mfma_q(IT_F0 + 10, nb, u2, f0);
+        mfma_q(IT_F0 + 11, nb, f0, f1);
+        RUN(launch_upsample_q4(f1.p, f1.bs(), u3.p, u3.bs(), nb, 16, f1.H, f1.W, u3.H, u3.W, 0.5f, 0.5f, 1.0f, s));
+        mfma_q(IT_F0 + 12, nb, u3, g0);
+        mfma_q(IT_F0 + 13, nb, g0, g1);
+        RUN(launch_upsample_q4(g1.p, g1.bs(), fl.p, fl.bs(), nb, 1, g1.H, g1.W, h, w, (float)g1.H / (float)h,
+                               (float)g1.W / (float)w, 1.0f, s));
+    }
+
+    void encode_lr(int n, const float* lrs, long long bs) {
+        Q4 e0 = q(L.e_lr0, 8, L.h, L.w), x = q(L.x_lr, 8, L.h, L.w);
+        mfma(IT_ENC_LR0, n, L.h, L.w, {{lrs, bs}}, {{e0.p, e0.bs(), 0, 8}});
+        mfma_q(IT_ENC_LR1, n, e0, x);
+    }
+
+    // one iteration of the recurrent loop (reference model/CRFP.py:1555-1684)
+    void frame(bool first, const float* lr, const float* fv, const uint8_t* mk, const float* flow_lr_q4,
+               const float* x_lr_i, float* out) {
+        const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
+        const long long P8q = (long long)H8 * W8 * 4, P2q = (long long)H2 * W2 * 4;
+        RUN(launch_hr_prep(lr, fv, mk, F(L.xin8), h, w, s));
+        narrow(IT_EH0, H8, W8, {F(L.xin8), F(L.xin8) + P8q}, F(L.eh));
+        narrow(IT_EH1, H8, W8, {F(L.eh)}, F(L.x_hr));
+        float* prop = F(L.prop_a);
+        float* prop_next = F(L.prop_b);
+        mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{prop, 0, 0, 6}}, H2, W2);
+        float* carry = F(L.carry);
+        if (!first) {
+            float* flow2 = F(L.flow2);
+            float* flow8 = F(L.flow8);
+            RUN(launch_upflow(flow_lr_q4, 0, flow2, 0, 1, h, w, 2, s));
+            RUN(launch_upflow(flow_lr_q4, 0, flow8, 0, 1, h, w, 8, s));
+            mfma(IT_DOWN, 1, H2, W2, {{F(L.state_hr), 0}}, {{F(L.prev2), 0, 0, 8}});
+            RUN(launch_flow_warp_q4(F(L.prev2), 0, flow2, 0, F(L.prev2w), 0, 1, 8, H2, W2, 0, s));
+            RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, s));
+            RUN(launch_flow_warp_q4(carry, 0, flow2, 0, F(L.carryw), 0, 1, 6, H2, W2, 0, s));
+            const float* offprev = nullptr;
+            for (int l = 0; l < 3; ++l) {
+                const float* cw = F(L.carryw) + 2 * l * P2q;
+                mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
+                     {{F(L.fa), 0, 0, 8}});
+                float* f = F(L.offfeat[l]);
+                if (l == 0) {
+                    mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{f, 0, 0, 8}});
+                } else {
+                    mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{F(L.fb), 0, 0, 8}});
+                    mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {{f, 0, 0, 8}});
+                }
+                mfma(it_lvl(l, L_OM), 1, H2, W2, {{f, 0}}, {{F(L.offmask), 0, 0, 54}}, 0, 0, nullptr, 0, flow2, 0);
+                const Item& dw = M.items[it_lvl(l, L_DCNW)];
+                RUN(launch_dcn_g8(F(L.prev2), 0, F(L.offmask), 0, packed + dw.off_w, packed + dw.off_b, F(L.aligned), 0,
+                                  1, H2, W2, s));
+                mfma(it_lvl(l, L_RB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.aligned), 0}}, {{F(L.y0), 0, 0, 8}});
+                mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
+                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2q, 0, 6, 8}}, 0, 0,
+                     F(L.y0), 0);
+                std::swap(prop, prop_next);
+                offprev = f;
+            }
+            mfma(IT_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up), 0, 0, 1}}, H8, W8);
+            mfma(IT_POFF, 1, H2, W2, {{offprev, 0}}, {{F(L.poff), 0, 0, 1}}, H8, W8);
+            narrow(IT_D3B0, H8, W8, {F(L.up), F(L.prevhrw), flow8}, F(L.g0));
+            narrow(IT_D3B1, H8, W8, {F(L.g0)}, F(L.g1));
+            narrow(IT_D3FUSE, H8, W8, {F(L.g1), F(L.poff)}, F(L.g2));
+            narrow(IT_D3OM, H8, W8, {F(L.g2)}, F(L.om3), nullptr, flow8);
+            const Item& d3 = M.items[IT_D3W];
+            RUN(launch_dcn3(F(L.state_hr), 0, F(L.om3), 0, packed + d3.off_w, packed + d3.off_b, F(L.al3), 0, 1, H8, W8, s));
+            narrow(IT_R3_0, H8, W8, {F(L.up), F(L.al3)}, F(L.z0));
+        } else {
+            for (int l = 0; l < 3; ++l) {
+                mfma(it_lvl(l, L_RB0F), 1, H2, W2, {{prop, 0}, {nullptr, 0}}, {{F(L.y0), 0, 0, 8}});
+                mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
+                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2q, 0, 6, 8}}, 0, 0,
+                     F(L.y0), 0);
+                std::swap(prop, prop_next);
+            }
+            mfma(IT_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up), 0, 0, 1}}, H8, W8);
+            narrow(IT_R3_0F, H8, W8, {F(L.up)}, F(L.z0));
+        }
+        narrow(IT_R3_1, H8, W8, {F(L.z0)}, F(L.z1));
+        narrow(IT_R3_2, H8, W8, {F(L.z1)}, F(L.feat), F(L.z0));
+        narrow(IT_TTTF, H8, W8, {F(L.feat), F(L.x_hr)}, F(L.state_hr), nullptr, nullptr, nullptr, mk);
+        narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, F(L.xin8) + P8q);
+    }
+};
+
+}  // namespace crfp
+
+using namespace crfp;
+
+extern "C" {
+
+const char* crfp_dsv_param_name(int index) {
+    static thread_local std::string s;
+    if (index < 0 || index >= CRFP_DSV_NUM_PARAMS) return nullptr;
+    s = std::string(kConvs[index / 2].stem) + (index % 2 ? ".bias" : ".weight");
+    return s.c_str();
+}
+
+int crfp_dsv_param_numel(int index, int y_only) {
+    if (index < 0 || index >= CRFP_DSV_NUM_PARAMS) return CRFP_E_BADARG;
+    const int ci = index / 2, co = conv_cout(ci, y_only);
+    return index % 2 ? co : co * kConvs[ci].cin * 9;
+}
+
+size_t crfp_dsv_packed_weight_bytes(int y_only) { return model_for(y_only).total_floats * sizeof(float); }
+
+int crfp_dsv_pack_weights(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
+    const Model& M = model_for(y_only);
+    if (!params || !packed) { set_error("pack_weights: null argument"); return CRFP_E_BADARG; }
+    if (packed_bytes < M.total_floats * sizeof(float)) { set_error("pack_weights: packed buffer too small"); return CRFP_E_WORKSPACE; }
+    for (int i = 0; i < CRFP_DSV_NUM_PARAMS; ++i)
+        if (!params[i]) { set_error("pack_weights: parameter %d (%s) is null", i, crfp_dsv_param_name(i)); return CRFP_E_BADARG; }
+    hipStream_t s = (hipStream_t)stream;
+    float* pk = (float*)packed;
+    for (int i = 0; i < IT_COUNT; ++i) {
+        const Item& it = M.items[i];
+        if (it.w1 < 0) continue;
+        const float* w = params[2 * it.w1];
+        const float* b = params[2 * it.w1 + 1];
+        const float* w2 = it.w2 >= 0 ? params[2 * it.w2] : nullptr;
+        const float* b2 = it.w2 >= 0 ? params[2 * it.w2 + 1] : nullptr;
+        const int split = conv_cout(it.w1, y_only);
+        int rc = 0;
+        switch (it.type) {
+            case T_MFMA: rc = launch_conv_pack(it.c, w, b, w2, b2, split, pk + it.off_w, pk + it.off_b, s); break;
+            case T_NARROW: rc = launch_narrow_pack(it.nw, w, b, w2, b2, split, pk + it.off_w, pk + it.off_b, s); break;
+            case T_DCN8:
+                rc = launch_dcn_g8_pack(w, pk + it.off_w, s);
+                if (!rc && hipMemcpyAsync(pk + it.off_b, b, 32 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
+                break;
+            default:
+                if (hipMemcpyAsync(pk + it.off_w, w, it.n_w * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                    hipMemcpyAsync(pk + it.off_b, b, it.n_b * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    rc = 1;
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+size_t crfp_dsv_workspace_bytes(int t, int h, int w) {
+    if (t < 1 || h < 8 || w < 8) return 0;
+    return Layout(t, h, w).bytes();
+}
+
+static int check_common(const void* packed, int t, int h, int w, void* ws, size_t ws_bytes, const Layout& L) {
+    if (!packed || !ws) { set_error("dsv: null packed weights or workspace"); return CRFP_E_BADARG; }
+    if (t < 1 || h < 8 || w < 8) { set_error("dsv: need t>=1, h,w>=8 (got %d,%d,%d)", t, h, w); return CRFP_E_BADARG; }
+    if (ws_bytes < L.bytes()) { set_error("dsv: workspace %zu < required %zu bytes", ws_bytes, L.bytes()); return CRFP_E_WORKSPACE; }
+    return 0;
+}
+
+int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, const float* fvs, const uint8_t* mks,
+                          float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    Layout L(t, h, w);
+    int rc = check_common(packed, t, h, w, workspace, workspace_bytes, L);
+    if (rc) return rc;
+    if (!lrs || !fvs || !mks || !out) { set_error("dsv_forward_clip: null tensor"); return CRFP_E_BADARG; }
+    Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    const long long lr_f = 3LL * h * w, hr_px = 64LL * h * w;
+    const int co = y_only ? 1 : 3;
+    if (t > 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
+    R.encode_lr(t, lrs, lr_f);
+    const long long xq = 8LL * h * w * 4, fq = 1LL * h * w * 4;
+    for (int i = 0; i < t && !R.rc; ++i)
+        R.frame(i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
+                i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq, out + (long long)i * co * hr_px);
+    return R.rc;
+}
+
+int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const float* lr_prev, const float* fv,
+                          const uint8_t* mk, float* out, int first, int h, int w, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    Layout L(1, h, w);
+    int rc = check_common(packed, 1, h, w, workspace, workspace_bytes, L);
+    if (rc) return rc;
+    if (!lr || !fv || !mk || !out || (!first && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
+    Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    if (!first) R.fnet(1, lr, 0, lr_prev, 0);
+    R.encode_lr(1, lr, 0);
+    R.frame(first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr), out);
+    return R.rc;
+}
+
+int crfp_fnet_forward(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    Layout L(n + 1, h, w);
+    int rc = check_common(packed, n + 1, h, w, workspace, workspace_bytes, L);
+    if (rc) return rc;
+    if (!cur || !prev || !flow) { set_error("fnet_forward: null tensor"); return CRFP_E_BADARG; }
+    Runner R{model_for(0), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    R.fnet(n, cur, 3LL * h * w, prev, 3LL * h * w);
+    if (!R.rc) R.rc = launch_q4_to_nchw(R.F(L.flow_lr), flow, n, 2, h, w, (hipStream_t)stream);
+    return R.rc;
+}
+
+int crfp_dsv_debug_fetch(const char* name, int t, int h, int w, const void* workspace, float* out_nchw, int* c_out,
+                         int* h_out, int* w_out, void* stream) {
+    if (!name || !workspace) return CRFP_E_BADARG;
+    Layout L(t, h, w);
+    for (auto& b : L.A.bufs)
+        if (b.name == name) {
+            const float* p = reinterpret_cast<const float*>((const char*)workspace + b.off);
+            if (c_out) *c_out = b.kind == 0 ? b.nq * 4 : 2;
+            if (h_out) *h_out = b.H;
+            if (w_out) *w_out = b.W;
+            if (!out_nchw) return b.N;
+            if (b.kind == 0) return launch_q4_to_nchw(p, out_nchw, b.N, b.nq * 4, b.H, b.W, (hipStream_t)stream);
+            return hipMemcpyAsync(out_nchw, p, (size_t)b.N * b.H * b.W * 2 * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream) == hipSuccess ? 0 : 1;
+        }
+    set_error("debug_fetch: unknown buffer '%s'", name);
+    return CRFP_E_BADARG;
+}
+
+}  // extern "C"

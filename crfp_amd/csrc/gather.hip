@@ -1,0 +1,301 @@
+// Irregular gathers of the CRFP path on gfx950: bilinear backward warp (reference flow_warp,
+// model/CRFP.py:90-130 -> ATen grid_sampler_2d) and the modulated deformable convolution the
+// reference imports from the third-party dcn_v2 package (model/CRFP.py:6,318-320,350).
+//
+// All feature maps are Q4 (4 channels of a pixel = one aligned 16-B element), so every bilinear
+// corner is ONE global_load_dwordx4 per lane and neighbouring lanes (neighbouring pixels, smooth
+// flow) hit consecutive 16-B elements: the four corner loads of a wave cover two nearly contiguous
+// 1-KiB row segments that the CU's L1 serves 3 times out of 4; HBM sees each input line once.
+#include "crfp_common.h"
+
+namespace crfp {
+
+// ---------------------------------------------------------------- flow_warp
+// Coordinate arithmetic restates the reference bit for bit in float32:
+//   g = x + flow_x;  gn = 2*g/max(W-1,1) - 1          (model/CRFP.py:118-121)
+//   ix = (gn + 1) * ((W-1)/2)                         (ATen CPU grid_sampler, align_corners=True)
+// zeros padding: each out-of-range corner contributes 0; border: ix clamped to [0, W-1].
+template <int BORDER>
+__global__ __launch_bounds__(256) void flow_warp_q4_kernel(const float* __restrict__ x, long long xb,
+                                                           const float* __restrict__ flow, long long fb,
+                                                           float* __restrict__ out, long long ob, int nq, int H,
+                                                           int W) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (px >= W || py >= H) return;
+    const long long pix = (long long)py * W + px;
+    const float2 f = *reinterpret_cast<const float2*>(flow + (long long)n * fb + pix * 2);
+    const float dw = (float)(W - 1 > 1 ? W - 1 : 1), dh = (float)(H - 1 > 1 ? H - 1 : 1);
+    const float gx = 2.0f * ((float)px + f.x) / dw - 1.0f;
+    const float gy = 2.0f * ((float)py + f.y) / dh - 1.0f;
+    float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f);
+    float iy = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+    if (BORDER) {
+        ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));
+        iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+    }
+    // keep the float->int conversion in range; anything beyond one pixel outside samples zero anyway
+    ix = fminf(fmaxf(ix, -2.0f), (float)W + 1.0f);
+    iy = fminf(fmaxf(iy, -2.0f), (float)H + 1.0f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float lx = ix - fx, ly = iy - fy, hx = 1.0f - lx, hy = 1.0f - ly;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const float w00 = (vy0 && vx0) ? hy * hx : 0.0f, w01 = (vy0 && vx1) ? hy * lx : 0.0f;
+    const float w10 = (vy1 && vx0) ? ly * hx : 0.0f, w11 = (vy1 && vx1) ? ly * lx : 0.0f;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    const long long o00 = ((long long)cy0 * W + cx0) * 4, o01 = ((long long)cy0 * W + cx1) * 4;
+    const long long o10 = ((long long)cy1 * W + cx0) * 4, o11 = ((long long)cy1 * W + cx1) * 4;
+    const float* xs = x + (long long)n * xb;
+    float* os = out + (long long)n * ob + pix * 4;
+    const long long plane = (long long)H * W * 4;
+    for (int q = 0; q < nq; ++q) {
+        const float* p = xs + q * plane;
+        const float4 a = *reinterpret_cast<const float4*>(p + o00);
+        const float4 b = *reinterpret_cast<const float4*>(p + o01);
+        const float4 c = *reinterpret_cast<const float4*>(p + o10);
+        const float4 d = *reinterpret_cast<const float4*>(p + o11);
+        float4 r;
+        r.x = a.x * w00 + b.x * w01 + c.x * w10 + d.x * w11;
+        r.y = a.y * w00 + b.y * w01 + c.y * w10 + d.y * w11;
+        r.z = a.z * w00 + b.z * w01 + c.z * w10 + d.z * w11;
+        r.w = a.w * w00 + b.w * w01 + c.w * w10 + d.w * w11;
+        *reinterpret_cast<float4*>(os + q * plane) = r;
+    }
+}
+
+int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
+                        int N, int nq, int H, int W, int border, hipStream_t s) {
+    const double px = (double)N * H * W;
+    ProfScope prof(nq == 1 ? "flow_warp_q4_c4" : (nq == 8 ? "flow_warp_q4_c32" : "flow_warp_q4_c24"), s,
+                   px * (2.0 * nq * 4 + 2) * 4.0, px * nq * 4 * 7.0);
+    dim3 grid((W + 63) / 64, (H + 3) / 4, N);
+    if (border)
+        flow_warp_q4_kernel<1><<<grid, 256, 0, s>>>(x, xb, flow, fb, out, ob, nq, H, W);
+    else
+        flow_warp_q4_kernel<0><<<grid, 256, 0, s>>>(x, xb, flow, fb, out, ob, nq, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------- DCNv2 sampling helper
+// Published DCNv2 semantics: p = (y - pad + ky*dil + dy, x - pad + kx*dil + dx); value 0 unless
+// -1 < p < size; bilinear with every out-of-range corner contributing 0.
+struct Corner4 {
+    long long o00, o01, o10, o11;
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ Corner4 dcn_corners(float py, float px, int H, int W) {
+    Corner4 c;
+    const bool inside = py > -1.0f && px > -1.0f && py < (float)H && px < (float)W;
+    py = fminf(fmaxf(py, -2.0f), (float)H + 1.0f);
+    px = fminf(fmaxf(px, -2.0f), (float)W + 1.0f);
+    const float fy = floorf(py), fx = floorf(px);
+    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+    const float ly = py - fy, lx = px - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+    const bool vy0 = inside && y0 >= 0, vy1 = inside && y1 <= H - 1, vx0 = x0 >= 0, vx1 = x1 <= W - 1;
+    c.w00 = (vy0 && vx0) ? hy * hx : 0.0f;
+    c.w01 = (vy0 && vx1) ? hy * lx : 0.0f;
+    c.w10 = (vy1 && vx0) ? ly * hx : 0.0f;
+    c.w11 = (vy1 && vx1) ? ly * lx : 0.0f;
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    c.o00 = ((long long)cy0 * W + cx0) * 4;
+    c.o01 = ((long long)cy0 * W + cx1) * 4;
+    c.o10 = ((long long)cy1 * W + cx0) * 4;
+    c.o11 = ((long long)cy1 * W + cx1) * 4;
+    return c;
+}
+
+__device__ __forceinline__ float4 sample_quad(const float* __restrict__ plane, const Corner4& c) {
+    const float4 a = *reinterpret_cast<const float4*>(plane + c.o00);
+    const float4 b = *reinterpret_cast<const float4*>(plane + c.o01);
+    const float4 d = *reinterpret_cast<const float4*>(plane + c.o10);
+    const float4 e = *reinterpret_cast<const float4*>(plane + c.o11);
+    float4 r;
+    r.x = c.w00 * a.x + c.w01 * b.x + c.w10 * d.x + c.w11 * e.x;
+    r.y = c.w00 * a.y + c.w01 * b.y + c.w10 * d.y + c.w11 * e.y;
+    r.z = c.w00 * a.z + c.w01 * b.z + c.w10 * d.z + c.w11 * e.z;
+    r.w = c.w00 * a.w + c.w01 * b.w + c.w10 * d.w + c.w11 * e.w;
+    return r;
+}
+
+// ---------------------------------------------------------------- DCNv2 32->32, 8 deformable groups
+// (dcn_0/1/2 of CRFP_DSV at 2x resolution).  x: Q4 8 quads (quad g = the 4 channels of deformable
+// group g).  offmask: Q4 54 quads = the reference's [offset(144) | mask(72)] channel order:
+// quad u<36: (dy,dx) of sampling positions 2u, 2u+1 (position p = g*9 + tap); quad 36+v: masks of
+// positions 4v..4v+3.  One wave = 32 pixels of a row; lane (pixel, half) samples the 36 positions of
+// groups 4*half..4*half+3 and feeds each sampled quad straight into 4 fp32 MFMAs as the B operand
+// (K index = (group, tap, channel)); the im2col matrix never exists in memory.
+__global__ __launch_bounds__(256) void dcn_g8_kernel(const float* __restrict__ x, long long xb,
+                                                     const float* __restrict__ offmask, long long omb,
+                                                     const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                     float* __restrict__ out, long long ob, int H, int W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int px = blockIdx.x * 32 + j, py = blockIdx.y * 4 + wave;
+    const int n = blockIdx.z;
+    const bool valid = px < W && py < H;
+    const int cx = min(px, W - 1), cy = min(py, H - 1);
+    const long long plane = (long long)H * W * 4;
+    const float* om = offmask + (long long)n * omb + ((long long)cy * W + cx) * 4;
+    const float* xs = x + (long long)n * xb;
+    const float4* __restrict__ wp = reinterpret_cast<const float4*>(wpk);
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+        const float4 m4 = *reinterpret_cast<const float4*>(om + (36 + 9 * h + v) * plane);
+        const float4 oa = *reinterpret_cast<const float4*>(om + (18 * h + 2 * v) * plane);
+        const float4 ob4 = *reinterpret_cast<const float4*>(om + (18 * h + 2 * v + 1) * plane);
+        const float dy[4] = {oa.x, oa.z, ob4.x, ob4.z};
+        const float dx[4] = {oa.y, oa.w, ob4.y, ob4.w};
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int p36 = 4 * v + pp, gi = p36 / 9, tap = p36 % 9, ky = tap / 3, kx = tap % 3;
+            const int g = 4 * h + gi;
+            const float sy = (float)(cy - 1 + ky) + dy[pp];
+            const float sx = (float)(cx - 1 + kx) + dx[pp];
+            const Corner4 c = dcn_corners(sy, sx, H, W);
+            float4 val = sample_quad(xs + g * plane, c);
+            const float m = mm[pp];
+            const float4 wa = wp[p36 * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, val.x * m, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, val.y * m, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, val.z * m, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, val.w * m, acc, 0, 0, 0);
+        }
+    }
+    if (!valid) return;
+    float* o = out + (long long)n * ob + ((long long)py * W + px) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cq = 2 * g + h;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * cq);
+        *reinterpret_cast<float4*>(o + cq * plane) =
+            make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+    }
+}
+
+// wpk[((p36*2 + half)*32 + row)*4 + i] = W[row][4*(4*half + p36/9) + i][p36 % 9]
+__global__ void dcn_g8_pack_kernel(const float* __restrict__ w, float* __restrict__ wpk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 36 * 2 * 32 * 4) return;
+    const int i = idx & 3, row = (idx >> 2) & 31, half = (idx >> 7) & 1, p36 = idx >> 8;
+    const int ci = 4 * (4 * half + p36 / 9) + i, tap = p36 % 9;
+    wpk[idx] = w[(row * 32 + ci) * 9 + tap];
+}
+
+int launch_dcn_g8_pack(const float* w, float* wpk, hipStream_t s) {
+    dcn_g8_pack_kernel<<<(36 * 2 * 32 * 4 + 255) / 256, 256, 0, s>>>(w, wpk);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
+                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s) {
+    const double px = (double)N * H * W;
+    ProfScope prof("dcnv2_g8_c32", s, px * (32 + 144 + 72 + 32) * 4.0 + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
+    dim3 grid((W + 31) / 32, (H + 3) / 4, N);
+    dcn_g8_kernel<<<grid, 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------- DCNv2 4->4, 1 group, offsets and mask
+// shared by the 9 taps (dcn_3 of CRFP_DSV at 8x resolution; the reference tiles the 2+1 channels 9x,
+// model/CRFP.py:341-347 -- here they stay compact: offmask3 quad = (dy, dx, mask, -)).
+// HBM-bound: 16 B in (gathered) + 16 B offmask + 16 B out per pixel.
+__global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, long long xb,
+                                                   const float* __restrict__ offmask3, long long omb,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ out, long long ob, int H, int W) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (px >= W || py >= H) return;
+    const long long pix = (long long)py * W + px;
+    const float4 om = *reinterpret_cast<const float4*>(offmask3 + (long long)n * omb + pix * 4);
+    const float* xs = x + (long long)n * xb;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float sy = (float)(py - 1 + tap / 3) + om.x;
+        const float sx = (float)(px - 1 + tap % 3) + om.y;
+        const Corner4 c = dcn_corners(sy, sx, H, W);
+        const float4 v = sample_quad(xs, c);
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            acc[o] = fmaf(w[(o * 4 + 3) * 9 + tap], v.w,
+                          fmaf(w[(o * 4 + 2) * 9 + tap], v.z,
+                               fmaf(w[(o * 4 + 1) * 9 + tap], v.y, fmaf(w[(o * 4 + 0) * 9 + tap], v.x, acc[o]))));
+    }
+    *reinterpret_cast<float4*>(out + (long long)n * ob + pix * 4) =
+        make_float4(acc[0] * om.z + bias[0], acc[1] * om.z + bias[1], acc[2] * om.z + bias[2], acc[3] * om.z + bias[3]);
+}
+
+int launch_dcn3(const float* x, long long xb, const float* offmask3, long long omb, const float* w,
+                const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s) {
+    const double px = (double)N * H * W;
+    // algorithmic bytes reported BOTH ways in DESIGN.md; the profiler record carries the compact
+    // figure (4 in + 2 off + 1 mask + 4 out floats per pixel) that this kernel actually needs
+    ProfScope prof("dcnv2_shared_c4", s, px * (4 + 2 + 1 + 4) * 4.0, px * (2.0 * 4 * 4 * 9 + 36 * 7));
+    dim3 grid((W + 63) / 64, (H + 3) / 4, N);
+    dcn3_kernel<<<grid, 256, 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------- generic DCNv2 (any C / groups), NCHW API tensors
+// One thread per (pixel, output channel block of 4).  Correct for every configuration the dcn_v2
+// module API accepts with k=3,pad=1,dil=1,stride=1; not a tuned path.
+__global__ void dcn_generic_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                   const float* __restrict__ mask, const float* __restrict__ w,
+                                   const float* __restrict__ b, float* __restrict__ out, int cin, int cout, int H, int W,
+                                   int dg) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (px >= W || py >= H) return;
+    const long long HW = (long long)H * W, pix = (long long)py * W + px;
+    const int cpg = cin / dg;
+    for (int o0 = 0; o0 < cout; o0 += 4) {
+        float acc[4] = {0, 0, 0, 0};
+        for (int g = 0; g < dg; ++g)
+            for (int tap = 0; tap < 9; ++tap) {
+                const float dy = offset[((long long)n * 2 * dg * 9 + 2 * (g * 9 + tap)) * HW + pix];
+                const float dx = offset[((long long)n * 2 * dg * 9 + 2 * (g * 9 + tap) + 1) * HW + pix];
+                const float m = mask[((long long)n * dg * 9 + g * 9 + tap) * HW + pix];
+                Corner4 c = dcn_corners((float)(py - 1 + tap / 3) + dy, (float)(px - 1 + tap % 3) + dx, H, W);
+                for (int cc = 0; cc < cpg; ++cc) {
+                    const int ci = g * cpg + cc;
+                    const float* p = x + ((long long)n * cin + ci) * HW;
+                    const float v = (c.w00 * p[c.o00 >> 2] + c.w01 * p[c.o01 >> 2] + c.w10 * p[c.o10 >> 2] +
+                                     c.w11 * p[c.o11 >> 2]) * m;
+                    for (int o = 0; o < 4; ++o)
+                        if (o0 + o < cout) acc[o] = fmaf(w[((long long)(o0 + o) * cin + ci) * 9 + tap], v, acc[o]);
+                }
+            }
+        for (int o = 0; o < 4; ++o)
+            if (o0 + o < cout) out[((long long)n * cout + o0 + o) * HW + pix] = acc[o] + b[o0 + o];
+    }
+}
+
+int launch_dcn_generic(const float* x, const float* offset, const float* mask, const float* w, const float* b,
+                       float* out, int N, int cin, int cout, int H, int W, int dg, hipStream_t s) {
+    const double px = (double)N * H * W;
+    ProfScope prof("dcnv2_generic_nchw", s, px * (cin + 27.0 * dg + cout) * 4.0, 2.0 * px * cin * cout * 9);
+    dim3 grid((W + 63) / 64, (H + 3) / 4, N);
+    dcn_generic_kernel<<<grid, 256, 0, s>>>(x, offset, mask, w, b, out, cin, cout, H, W, dg);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace crfp

@@ -1,0 +1,302 @@
+// Streaming helpers of the CRFP path (all HBM-bound, 16 B per lane where the layout allows):
+// layout conversion NCHW <-> Q4, bilinear resize (nn.Upsample / F.interpolate, align_corners=False:
+// reference model/CRFP.py:776,783,790,808-812,1471-1478), flow upsample + rescale (:1565-1566),
+// AvgPool2d(2,2) (:755,762,769), the x8 LR upsample + fovea blend in front of encoder_hr
+// (:1538,1542-1547) and the squared-error reduction behind PSNR (utils.py:166-185,328-330).
+#include "crfp_common.h"
+
+namespace crfp {
+
+// PyTorch's source index for align_corners=False (area_pixel_compute_source_index + guard):
+//   src = scale*(dst+0.5)-0.5, clamped at 0; i0 = min(floor(src), in-1); i1 = min(i0+1, in-1);
+//   l1 = clamp(src - i0, 0, 1); l0 = 1 - l1
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    i0 = min((int)floorf(src), in_size - 1);
+    i1 = min(i0 + 1, in_size - 1);
+    l1 = fminf(fmaxf(src - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+
+__global__ void nchw_to_q4_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W) {
+    const long long HW = (long long)H * W;
+    const int nq = (C + 3) / 4;
+    const long long total = (long long)nq * HW;
+    const int n = blockIdx.y;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx / HW);
+        const long long pix = idx - (long long)q * HW;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = 4 * q + c < C ? x[((long long)n * C + 4 * q + c) * HW + pix] : 0.0f;
+        *reinterpret_cast<float4*>(out + ((long long)n * nq * HW + idx) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ void q4_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W) {
+    const long long HW = (long long)H * W;
+    const int nq = (C + 3) / 4;
+    const long long total = (long long)nq * HW;
+    const int n = blockIdx.y;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx / HW);
+        const long long pix = idx - (long long)q * HW;
+        const float4 v = *reinterpret_cast<const float4*>(x + ((long long)n * nq * HW + idx) * 4);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (4 * q + c < C) out[((long long)n * C + 4 * q + c) * HW + pix] = vv[c];
+    }
+}
+
+static inline int grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, hipStream_t s) {
+    const long long total = (long long)((C + 3) / 4) * H * W;
+    ProfScope prof("nchw_to_q4", s, (double)N * H * W * (C + 4.0 * ((C + 3) / 4)) * 4.0, 0);
+    nchw_to_q4_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, out, C, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, hipStream_t s) {
+    const long long total = (long long)((C + 3) / 4) * H * W;
+    ProfScope prof("q4_to_nchw", s, (double)N * H * W * (C + 4.0 * ((C + 3) / 4)) * 4.0, 0);
+    q4_to_nchw_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, out, C, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// offset[N,noff,H,W] + mask[N,nmask,H,W] (dcn_v2 API tensors) -> Q4 [offset | mask]
+__global__ void offmask_to_q4_kernel(const float* __restrict__ off, const float* __restrict__ msk,
+                                     float* __restrict__ out, int noff, int nmask, int H, int W) {
+    const long long HW = (long long)H * W;
+    const int nq = (noff + nmask) / 4;
+    const long long total = (long long)nq * HW;
+    const int n = blockIdx.y;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx / HW);
+        const long long pix = idx - (long long)q * HW;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * q + c;
+            v[c] = ch < noff ? off[((long long)n * noff + ch) * HW + pix] : msk[((long long)n * nmask + ch - noff) * HW + pix];
+        }
+        *reinterpret_cast<float4*>(out + ((long long)n * nq * HW + idx) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+int launch_offmask_nchw_to_q4(const float* offset, const float* mask, float* out, int N, int noff, int nmask, int H,
+                              int W, hipStream_t s) {
+    const long long total = (long long)((noff + nmask) / 4) * H * W;
+    ProfScope prof("offmask_nchw_to_q4", s, (double)N * H * W * (noff + nmask) * 8.0, 0);
+    offmask_to_q4_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(offset, mask, out, noff, nmask, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// bilinear resize of a Q4 tensor; out = mul * (l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11))
+__global__ void upsample_q4_kernel(const float* __restrict__ x, long long xb, float* __restrict__ out, long long ob,
+                                   int nq, int H, int W, int OH, int OW, float sh, float sw, float mul) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= OW || oy >= OH) return;
+    const int q = blockIdx.z % nq, n = blockIdx.z / nq;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(oy, sh, H, y0, y1, ly0, ly1);
+    src_index(ox, sw, W, x0, x1, lx0, lx1);
+    const float* p = x + (long long)n * xb + (long long)q * H * W * 4;
+    const float4 a = *reinterpret_cast<const float4*>(p + ((long long)y0 * W + x0) * 4);
+    const float4 b = *reinterpret_cast<const float4*>(p + ((long long)y0 * W + x1) * 4);
+    const float4 c = *reinterpret_cast<const float4*>(p + ((long long)y1 * W + x0) * 4);
+    const float4 d = *reinterpret_cast<const float4*>(p + ((long long)y1 * W + x1) * 4);
+    float4 r;
+    r.x = mul * (ly0 * (lx0 * a.x + lx1 * b.x) + ly1 * (lx0 * c.x + lx1 * d.x));
+    r.y = mul * (ly0 * (lx0 * a.y + lx1 * b.y) + ly1 * (lx0 * c.y + lx1 * d.y));
+    r.z = mul * (ly0 * (lx0 * a.z + lx1 * b.z) + ly1 * (lx0 * c.z + lx1 * d.z));
+    r.w = mul * (ly0 * (lx0 * a.w + lx1 * b.w) + ly1 * (lx0 * c.w + lx1 * d.w));
+    *reinterpret_cast<float4*>(out + (long long)n * ob + (((long long)q * OH + oy) * OW + ox) * 4) = r;
+}
+
+int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
+                       int OW, float sh, float sw, float mul, hipStream_t s) {
+    ProfScope prof("upsample_bilinear_q4", s, (double)N * nq * 16.0 * ((double)H * W + (double)OH * OW), 0);
+    dim3 grid((OW + 63) / 64, (OH + 3) / 4, N * nq);
+    upsample_q4_kernel<<<grid, 256, 0, s>>>(x, xb, out, ob, nq, H, W, OH, OW, sh, sw, mul);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void upsample_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int OH,
+                                     int OW, float sh, float sw, float mul) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= OW || oy >= OH) return;
+    const long long nc = blockIdx.z;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(oy, sh, H, y0, y1, ly0, ly1);
+    src_index(ox, sw, W, x0, x1, lx0, lx1);
+    const float* p = x + nc * H * W;
+    out[(nc * OH + oy) * OW + ox] = mul * (ly0 * (lx0 * p[(long long)y0 * W + x0] + lx1 * p[(long long)y0 * W + x1]) +
+                                           ly1 * (lx0 * p[(long long)y1 * W + x0] + lx1 * p[(long long)y1 * W + x1]));
+}
+
+int launch_upsample_nchw(const float* x, float* out, int N, int C, int H, int W, int OH, int OW, float sh, float sw,
+                         float mul, hipStream_t s) {
+    ProfScope prof("upsample_bilinear_nchw", s, (double)N * C * 4.0 * ((double)H * W + (double)OH * OW), 0);
+    dim3 grid((OW + 63) / 64, (OH + 3) / 4, N * C);
+    upsample_nchw_kernel<<<grid, 256, 0, s>>>(x, out, H, W, OH, OW, sh, sw, mul);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// LR flow (Q4 quad: dx,dy,0,0) -> [rH][rW][2] = r * bilinear_xr(flow)   (img_upsample_rx(flow) * r)
+__global__ void upflow_kernel(const float* __restrict__ f, long long fb, float* __restrict__ out, long long ob, int H,
+                              int W, int r) {
+    const int OW = W * r, OH = H * r;
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (ox >= OW || oy >= OH) return;
+    const float sc = 1.0f / (float)r, mul = (float)r;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(oy, sc, H, y0, y1, ly0, ly1);
+    src_index(ox, sc, W, x0, x1, lx0, lx1);
+    const float* p = f + (long long)n * fb;
+    const float2 a = *reinterpret_cast<const float2*>(p + ((long long)y0 * W + x0) * 4);
+    const float2 b = *reinterpret_cast<const float2*>(p + ((long long)y0 * W + x1) * 4);
+    const float2 c = *reinterpret_cast<const float2*>(p + ((long long)y1 * W + x0) * 4);
+    const float2 d = *reinterpret_cast<const float2*>(p + ((long long)y1 * W + x1) * 4);
+    float2 o;
+    o.x = (ly0 * (lx0 * a.x + lx1 * b.x) + ly1 * (lx0 * c.x + lx1 * d.x)) * mul;
+    o.y = (ly0 * (lx0 * a.y + lx1 * b.y) + ly1 * (lx0 * c.y + lx1 * d.y)) * mul;
+    *reinterpret_cast<float2*>(out + (long long)n * ob + ((long long)oy * OW + ox) * 2) = o;
+}
+
+int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long ob, int N, int H, int W, int r,
+                  hipStream_t s) {
+    ProfScope prof(r == 8 ? "upflow_x8" : "upflow_x2", s, (double)N * H * W * (8.0 + 8.0 * r * r), 0);
+    dim3 grid((W * r + 63) / 64, (H * r + 3) / 4, N);
+    upflow_kernel<<<grid, 256, 0, s>>>(flow_q4, fb, out_nhw2, ob, H, W, r);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// AvgPool2d(2,2), floor mode: out = (v00 + v01 + v10 + v11) / 4 in that order
+__global__ void avgpool2_q4_kernel(const float* __restrict__ x, long long xb, float* __restrict__ out, long long ob,
+                                   int nq, int H, int W) {
+    const int OH = H / 2, OW = W / 2;
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= OW || oy >= OH) return;
+    const int q = blockIdx.z % nq, n = blockIdx.z / nq;
+    const float* p = x + (long long)n * xb + (long long)q * H * W * 4;
+    const float4 a = *reinterpret_cast<const float4*>(p + ((long long)(2 * oy) * W + 2 * ox) * 4);
+    const float4 b = *reinterpret_cast<const float4*>(p + ((long long)(2 * oy) * W + 2 * ox + 1) * 4);
+    const float4 c = *reinterpret_cast<const float4*>(p + ((long long)(2 * oy + 1) * W + 2 * ox) * 4);
+    const float4 d = *reinterpret_cast<const float4*>(p + ((long long)(2 * oy + 1) * W + 2 * ox + 1) * 4);
+    float4 r;
+    r.x = (((a.x + b.x) + c.x) + d.x) / 4.0f;
+    r.y = (((a.y + b.y) + c.y) + d.y) / 4.0f;
+    r.z = (((a.z + b.z) + c.z) + d.z) / 4.0f;
+    r.w = (((a.w + b.w) + c.w) + d.w) / 4.0f;
+    *reinterpret_cast<float4*>(out + (long long)n * ob + (((long long)q * OH + oy) * OW + ox) * 4) = r;
+}
+
+int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W,
+                       hipStream_t s) {
+    ProfScope prof("avgpool2_q4", s, (double)N * nq * 16.0 * ((double)H * W * 1.25), 0);
+    dim3 grid((W / 2 + 63) / 64, (H / 2 + 3) / 4, N * nq);
+    avgpool2_q4_kernel<<<grid, 256, 0, s>>>(x, xb, out, ob, nq, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// One frame: lr[3,h,w], fv[3,8h,8w] NCHW, mk[8h,8w] u8 -> Q4 2 quads at (8h,8w):
+//   quad 0 = (mk ? fv : up8(lr)) rgb, 0     (fvs*mk + lrs_lv3*(1-mk) with mk in {0,1} is a select)
+//   quad 1 = up8(lr) rgb, 0                 (also the base of the output head)
+__global__ void hr_prep_kernel(const float* __restrict__ lr, const float* __restrict__ fv,
+                               const uint8_t* __restrict__ mk, float* __restrict__ out, int h, int w) {
+    const int OH = 8 * h, OW = 8 * w;
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= OW || oy >= OH) return;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(oy, 0.125f, h, y0, y1, ly0, ly1);
+    src_index(ox, 0.125f, w, x0, x1, lx0, lx1);
+    float u[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = lr + (long long)c * h * w;
+        u[c] = ly0 * (lx0 * p[y0 * w + x0] + lx1 * p[y0 * w + x1]) + ly1 * (lx0 * p[y1 * w + x0] + lx1 * p[y1 * w + x1]);
+    }
+    const long long pix = (long long)oy * OW + ox, plane = (long long)OH * OW;
+    const bool m = mk[pix] != 0;
+    float4 a = make_float4(u[0], u[1], u[2], 0.0f);
+    if (m) a = make_float4(fv[pix], fv[plane + pix], fv[2 * plane + pix], 0.0f);
+    *reinterpret_cast<float4*>(out + pix * 4) = a;
+    *reinterpret_cast<float4*>(out + (plane + pix) * 4) = make_float4(u[0], u[1], u[2], 0.0f);
+}
+
+int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s) {
+    ProfScope prof("hr_prep_up8_blend", s, (double)64 * h * w * (12 + 1 + 32.0), 0);
+    dim3 grid((8 * w + 63) / 64, (8 * h + 3) / 4, 1);
+    hr_prep_kernel<<<grid, 256, 0, s>>>(lr, fv, mk, out_q4, h, w);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// acc[0] += sum (a-b)^2 ; acc[1] += sum (Y(a)-Y(b))^2 with Y = 24.966*c0 + 128.553*c1 + 65.481*c2 + 16
+__global__ void psnr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ acc,
+                                    int C, long long HW) {
+    const int n = blockIdx.y;
+    double s0 = 0.0, s1 = 0.0;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < HW;
+         pix += (long long)gridDim.x * blockDim.x) {
+        float ya = 16.0f, yb = 16.0f;
+        const float wy[3] = {24.966f, 128.553f, 65.481f};
+        for (int c = 0; c < C; ++c) {
+            const float va = a[((long long)n * C + c) * HW + pix], vb = b[((long long)n * C + c) * HW + pix];
+            const float d = va - vb;
+            s0 += (double)d * d;
+            if (C == 3) { ya += wy[c] * va; yb += wy[c] * vb; }
+        }
+        if (C == 3) { const float d = ya - yb; s1 += (double)d * d; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_down(s0, o);
+        s1 += __shfl_down(s1, o);
+    }
+    __shared__ double sh[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wv] = s0; sh[1][wv] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(&acc[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    }
+}
+
+int launch_psnr_partial(const float* a, const float* b, double* acc, int N, int C, int H, int W, hipStream_t s) {
+    const long long HW = (long long)H * W;
+    ProfScope prof("psnr_partial", s, (double)N * C * HW * 8.0, 0);
+    int blocks = (int)((HW + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    psnr_partial_kernel<<<dim3(blocks, N), 256, 0, s>>>(a, b, acc, C, HW);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace crfp

@@ -1,0 +1,136 @@
+"""Python handle on the C++ CRFP_DSV engine (crfp_amd/csrc/engine.hip): owns the packed weights
+and the workspace tensors, forwards clips / streamed frames with one C-ABI call each."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .ops import _dev, _stream
+
+
+def param_names():
+    L = _lib.lib()
+    return [L.crfp_dsv_param_name(i).decode() for i in range(_lib.NUM_PARAMS)]
+
+
+class DSVEngine:
+    def __init__(self, state_dict, device, y_only: bool = False):
+        """state_dict: mapping with the reference's CRFP_DSV keys -> tensors (any device)."""
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("crfp_amd.DSVEngine needs a CUDA/HIP device (no CPU path in the product)")
+        self.y_only = int(bool(y_only))
+        self._ws = {}
+        self._stream_ws = None
+        self._stream_prev = None
+        self._stream_hw = None
+        self.pack(state_dict)
+
+    def pack(self, state_dict):
+        L = _lib.lib()
+        names = param_names()
+        missing = [k for k in names if k not in state_dict]
+        if missing:
+            raise KeyError(f"state_dict lacks CRFP_DSV parameters: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        keep = []
+        ptrs = (C.c_void_p * _lib.NUM_PARAMS)()
+        for i, k in enumerate(names):
+            t = state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            want = L.crfp_dsv_param_numel(i, self.y_only)
+            if t.numel() != want:
+                raise ValueError(f"parameter {k}: {t.numel()} elements, expected {want}")
+            keep.append(t)
+            ptrs[i] = t.data_ptr()
+        nbytes = L.crfp_dsv_packed_weight_bytes(self.y_only)
+        self.packed = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.crfp_dsv_pack_weights(ptrs, self.y_only, self.packed.data_ptr(), nbytes, _stream()),
+                       "crfp_dsv_pack_weights")
+            torch.cuda.current_stream().synchronize()   # `keep` may be freed after this point
+
+    def _workspace(self, t, h, w):
+        key = (t, h, w)
+        if key not in self._ws:
+            nb = _lib.lib().crfp_dsv_workspace_bytes(t, h, w)
+            if nb == 0:
+                raise ValueError(f"unsupported clip shape t={t} h={h} w={w}")
+            self._ws = {key: torch.empty(nb, dtype=torch.uint8, device=self.device)}  # keep one shape alive
+        return self._ws[key]
+
+    @staticmethod
+    def _mask_u8(mks):
+        if mks.dtype == torch.bool:
+            return mks.contiguous().view(torch.uint8)
+        return (mks != 0).contiguous().view(torch.uint8)
+
+    def forward(self, lrs, fvs, mks):
+        """lrs[n,t,3,h,w], fvs[n,t,3,8h,8w], mks[n,t,1,8h,8w] (bool) -> [n,t,3|1,8h,8w]."""
+        lrs, fvs = _dev(lrs, "lrs"), _dev(fvs, "fvs")
+        if not mks.is_cuda:
+            raise RuntimeError("crfp_amd: `mks` must be a CUDA/HIP tensor")
+        mk8 = self._mask_u8(mks)
+        n, t, c, h, w = lrs.shape
+        assert c == 3 and tuple(fvs.shape) == (n, t, 3, 8 * h, 8 * w) and tuple(mk8.shape) == (n, t, 1, 8 * h, 8 * w)
+        out = torch.empty((n, t, 1 if self.y_only else 3, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
+        ws = self._workspace(t, h, w)
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            for b in range(n):
+                _lib.check(L.crfp_dsv_forward_clip(self.packed.data_ptr(), self.y_only, lrs[b].data_ptr(),
+                                                   fvs[b].data_ptr(), mk8[b].data_ptr(), out[b].data_ptr(), t, h, w,
+                                                   ws.data_ptr(), ws.numel(), _stream()), "crfp_dsv_forward_clip")
+        return out
+
+    # ---- streaming: one frame per call, state lives in a dedicated workspace
+    def clear_states(self):
+        self._stream_prev = None
+
+    def stream_frame(self, lr, fv, mk):
+        """lr[3,h,w], fv[3,8h,8w], mk[1,8h,8w] -> [3|1,8h,8w]; first call after clear_states() starts a clip."""
+        lr, fv = _dev(lr, "lr"), _dev(fv, "fv")
+        mk8 = self._mask_u8(mk)
+        _, h, w = lr.shape
+        if self._stream_ws is None or self._stream_hw != (h, w):
+            nb = _lib.lib().crfp_dsv_workspace_bytes(1, h, w)
+            self._stream_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            self._stream_hw = (h, w)
+            self._stream_prev = None
+        first = self._stream_prev is None
+        out = torch.empty((1 if self.y_only else 3, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().crfp_dsv_stream_frame(
+                self.packed.data_ptr(), self.y_only, lr.data_ptr(),
+                None if first else self._stream_prev.data_ptr(), fv.data_ptr(), mk8.data_ptr(), out.data_ptr(),
+                1 if first else 0, h, w, self._stream_ws.data_ptr(), self._stream_ws.numel(), _stream()),
+                "crfp_dsv_stream_frame")
+        self._stream_prev = lr
+        return out
+
+    def compute_flow(self, cur, prev):
+        """FNet(cur, prev): [n,3,h,w] x2 -> [n,2,h,w] (reference CRFP_DSV.compute_flow pairs)."""
+        cur, prev = _dev(cur, "cur"), _dev(prev, "prev")
+        n, _, h, w = cur.shape
+        ws = self._workspace(n + 1, h, w)
+        flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().crfp_fnet_forward(self.packed.data_ptr(), cur.data_ptr(), prev.data_ptr(),
+                                                    flow.data_ptr(), n, h, w, ws.data_ptr(), ws.numel(), _stream()),
+                       "crfp_fnet_forward")
+        return flow
+
+    def debug_fetch(self, name, t, h, w):
+        """Copy a named workspace intermediate of the last clip forward to an NCHW tensor (tests only)."""
+        L = _lib.lib()
+        ws = self._workspace(t, h, w)
+        c, hh, ww = C.c_int(), C.c_int(), C.c_int()
+        n = L.crfp_dsv_debug_fetch(name.encode(), t, h, w, ws.data_ptr(), None, C.byref(c), C.byref(hh), C.byref(ww),
+                                   _stream())
+        if n < 0:
+            raise KeyError(name)
+        shape = (n, c.value, hh.value, ww.value) if c.value != 2 or "flow" not in name else (n, hh.value, ww.value, 2)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        _lib.check(L.crfp_dsv_debug_fetch(name.encode(), t, h, w, ws.data_ptr(), out.data_ptr(), None, None, None,
+                                          _stream()), "crfp_dsv_debug_fetch")
+        return out

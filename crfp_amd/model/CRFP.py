@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's ``model/CRFP.py`` for the CRFP_DSV inference path.
+
+Same public names, constructor signatures, attribute names and ``state_dict`` keys as the reference
+(model/CRFP.py: flow_warp :90, PixelShufflePack :154, PixelUnShufflePack_v2 :239, DCN_module :281,
+ResidualBlockNoBN :433, ResidualBlocksWithInputConv :516, FNet :743, CRFP_DSV :1387) so reference
+checkpoints load with ``strict=True`` and ``main.py:34`` / ``trainer.py:318`` call it unchanged.
+The modules only *hold parameters*; all arithmetic runs in the HIP library: ``CRFP_DSV.forward`` is
+one C-ABI call per clip (crfp_amd.engine.DSVEngine), the smaller modules call per-operator entry
+points.  Inference only (no autograd), CUDA/HIP tensors only.
+"""
+import torch
+import torch.nn as nn
+
+from crfp_amd import ops
+from crfp_amd.dcn_v2 import DCNv2
+from crfp_amd.engine import DSVEngine
+from . import LTE
+
+
+def flow_warp(x, flow, interpolation='bilinear', padding_mode='zeros', align_corners=True):
+    return ops.flow_warp(x, flow, interpolation, padding_mode, align_corners)
+
+
+def pixel_unshuffle(input, downscale_factor):
+    return torch.nn.functional.pixel_unshuffle(input, downscale_factor)
+
+
+def conv3x3(in_channels, out_channels, stride=1):
+    return nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=True)
+
+
+def _run(conv: nn.Conv2d, x, act="none", post_scale=1.0):
+    return ops.conv3x3(x, conv.weight, conv.bias, act, post_scale)
+
+
+class PixelShufflePack(nn.Module):
+    def __init__(self, in_channels, out_channels, scale_factor, upsample_kernel):
+        super().__init__()
+        assert upsample_kernel == 3
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.scale_factor, self.upsample_kernel = scale_factor, upsample_kernel
+        self.upsample_conv = nn.Conv2d(in_channels, out_channels * scale_factor * scale_factor, 3, padding=1)
+
+    def forward(self, x):
+        return torch.nn.functional.pixel_shuffle(_run(self.upsample_conv, x), self.scale_factor)
+
+
+class PixelUnShufflePack_v2(nn.Module):
+    def __init__(self, in_channels, out_channels, scale_factor, downsample_kernel):
+        super().__init__()
+        assert downsample_kernel == 3 and out_channels % (scale_factor * scale_factor) == 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.scale_factor, self.downsample_kernel = scale_factor, downsample_kernel
+        self.downsample_conv = nn.Conv2d(in_channels * scale_factor * scale_factor, out_channels, 3, padding=1)
+
+    def forward(self, x):
+        return _run(self.downsample_conv, pixel_unshuffle(x, self.scale_factor))
+
+
+class DCN_module(nn.Module):
+    def __init__(self, mid_channels=64, dg=16, dk=3, max_mag=10, repeat=False, pre_offset=False,
+                 interpolate='none', offset_only=False):
+        super().__init__()
+        if offset_only:
+            raise NotImplementedError("offset_only is never enabled by the reference's CRFP_DSV")
+        self.mid_channels, self.dg_num, self.dk = mid_channels, dg, dk
+        self.max_residue_magnitude = max_mag
+        self.pre_offset, self.repeat, self.interpolate, self.offset_only = pre_offset, repeat, interpolate, offset_only
+        if pre_offset:
+            if interpolate == 'pixelshuffle':
+                self.upsample = PixelShufflePack(mid_channels * 8, mid_channels, 4, upsample_kernel=3)
+            elif interpolate == 'bilinear':
+                self.upsample = nn.Upsample(scale_factor=4, mode='bilinear', align_corners=False)
+            self.conv_fuse = nn.Conv2d(mid_channels * 2, mid_channels, 3, 1, 1)
+        self.init_channels = mid_channels * 2 + 2
+        self.dcn_block = nn.Sequential(nn.Conv2d(self.init_channels, mid_channels, 3, 1, 1),
+                                       nn.LeakyReLU(0.1, inplace=True),
+                                       nn.Conv2d(mid_channels, mid_channels, 3, 1, 1),
+                                       nn.LeakyReLU(0.1, inplace=True))
+        n_pos = 1 if repeat else dk * dk
+        self.dcn_offset = nn.Conv2d(mid_channels, dg * 2 * n_pos, 3, 1, 1)
+        self.dcn_mask = nn.Conv2d(mid_channels, dg * n_pos, 3, 1, 1)
+        self.dcn = DCNv2(mid_channels, mid_channels, dk, stride=1, padding=(dk - 1) // 2, dilation=1,
+                         deformable_groups=dg)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+        self.init_dcn()
+
+    def init_dcn(self):
+        with torch.no_grad():
+            for m in (self.dcn_offset, self.dcn_mask):
+                m.weight.zero_()
+                m.bias.zero_()
+            self.conv_identify(self.dcn.weight, self.dcn.bias)
+
+    @staticmethod
+    def conv_identify(weight, bias):
+        with torch.no_grad():
+            weight.zero_()
+            bias.zero_()
+            o, i, kh, kw = weight.shape
+            d = torch.arange(min(o, i))
+            weight[d, d, kh // 2, kw // 2] = 1.0
+
+    def forward(self, cur_x, pre_x, pre_x_aligned, flow, pre_offset=None):
+        f = torch.cat([cur_x, pre_x_aligned, flow], dim=1)
+        f = _run(self.dcn_block[2], _run(self.dcn_block[0], f, "lrelu"), "lrelu")
+        if torch.is_tensor(pre_offset):
+            if self.interpolate == 'pixelshuffle':
+                pre_offset = self.upsample(pre_offset) * 2.
+            elif self.interpolate == 'bilinear':
+                pre_offset = ops.upsample_bilinear(pre_offset, scale_factor=4, mul=2.0)
+            f = _run(self.conv_fuse, torch.cat([f, pre_offset], dim=1), "lrelu")
+        offset = _run(self.dcn_offset, f, "tanh", float(self.max_residue_magnitude))
+        mask = _run(self.dcn_mask, f, "sigmoid")
+        flow_yx = flow.flip(1)
+        K = self.dk * self.dk
+        if self.repeat:
+            B, C2, H, W = offset.shape
+            offset = (offset.view(B, 2, C2 // 2, H, W) + flow_yx.unsqueeze(2)).repeat(1, K, 1, 1, 1).view(B, C2 * K, H, W)
+            mask = mask.repeat(1, K, 1, 1)
+        else:
+            offset = offset + flow_yx.repeat(1, offset.size(1) // 2, 1, 1)
+        return self.dcn(pre_x, offset, mask), f
+
+
+class ResidualBlockNoBN(nn.Module):
+    def __init__(self, mid_channels=64, res_scale=1.0):
+        super().__init__()
+        self.res_scale = res_scale
+        self.conv1 = nn.Conv2d(mid_channels, mid_channels, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(mid_channels, mid_channels, 3, 1, 1, bias=True)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return x + _run(self.conv2, _run(self.conv1, x, "relu")) * self.res_scale
+
+
+class ResidualBlocksWithInputConv(nn.Module):
+    def __init__(self, in_channels, out_channels=64, num_blocks=30):
+        super().__init__()
+        self.main = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, 1, 1, bias=True),
+                                  nn.LeakyReLU(negative_slope=0.1, inplace=True),
+                                  nn.Sequential(*[ResidualBlockNoBN(mid_channels=out_channels)
+                                                  for _ in range(num_blocks)]))
+
+    def forward(self, feat):
+        x = _run(self.main[0], feat, "lrelu")
+        for blk in self.main[2]:
+            x = blk(x)
+        return x
+
+
+class FNet(nn.Module):
+    """Optical-flow net (reference model/CRFP.py:743-814): same layer containers / parameter names."""
+
+    def __init__(self, in_nc):
+        super().__init__()
+
+        def two(ci, co, tail):
+            return nn.Sequential(nn.Conv2d(ci, co, 3, 1, 1, bias=True), nn.ReLU(inplace=True),
+                                 nn.Conv2d(co, co, 3, 1, 1, bias=True), nn.ReLU(inplace=True), tail)
+
+        up = lambda: nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False)  # noqa: E731
+        self.encoder1 = two(2 * in_nc, 32, nn.AvgPool2d(2, 2))
+        self.encoder2 = two(32, 64, nn.AvgPool2d(2, 2))
+        self.encoder3 = two(64, 128, nn.AvgPool2d(2, 2))
+        self.decoder1 = two(128, 256, up())
+        self.decoder2 = two(256, 128, up())
+        self.decoder3 = two(128, 64, up())
+        self.flow = nn.Sequential(nn.Conv2d(64, 32, 3, 1, 1, bias=True), nn.ReLU(inplace=True),
+                                  nn.Conv2d(32, 2, 3, 1, 1, bias=True))
+
+    def forward(self, x1, x2):
+        """Flow from x1 to x2, [n,2,h,w]; convs and resizes on the HIP kernels."""
+        _, _, h, w = x1.shape
+        o = torch.cat([x1, x2], dim=1)
+        for blk in (self.encoder1, self.encoder2, self.encoder3):
+            o = _run(blk[2], _run(blk[0], o, "relu"), "relu")
+            o = torch.nn.functional.avg_pool2d(o, 2, 2)
+        for blk in (self.decoder1, self.decoder2, self.decoder3):
+            o = _run(blk[2], _run(blk[0], o, "relu"), "relu")
+            o = ops.upsample_bilinear(o, scale_factor=2)
+        o = _run(self.flow[2], _run(self.flow[0], o, "relu"), "tanh", 256.0)
+        return ops.upsample_bilinear(o, size=(h, w))
+
+
+class CRFP_DSV(nn.Module):
+    """Drop-in for the reference's CRFP_DSV (model/CRFP.py:1387-1706).  ``spynet_pretrained`` may be
+    None (the reference would crash: it torch.load()s it unconditionally, :1407) -- weights then come
+    from ``load_state_dict`` / ``init_weights``."""
+
+    def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, spynet_pretrained=None):
+        super().__init__()
+        if mid_channels != 32 or not hr_dcn or not offset_prop:
+            raise NotImplementedError("crfp_amd implements the reference's shipped configuration: "
+                                      "mid_channels=32, hr_dcn=True, offset_prop=True (main.py:34, eval.sh)")
+        self.device = device
+        self.mid_channels, self.last_channels = mid_channels, mid_channels // 8
+        self.dg_num, self.dk, self.max_residue_magnitude = 8, 3, 10
+        self.y_only, self.hr_dcn, self.offset_prop, self.split_ratio = y_only, hr_dcn, offset_prop, 3
+        m, l = mid_channels, mid_channels // 8
+
+        self.spynet = FNet(in_nc=3)
+        if spynet_pretrained is not None:
+            self.spynet.load_state_dict(torch.load(spynet_pretrained, map_location="cpu"))
+        self.dcn_0 = DCN_module(m, 8, 3, 10)
+        self.dcn_1 = DCN_module(m, 8, 3, 10, pre_offset=True, interpolate='none')
+        self.dcn_2 = DCN_module(m, 8, 3, 10, pre_offset=True, interpolate='none')
+        self.dcn_3 = DCN_module(l, 1, 3, 10, repeat=True, pre_offset=True, interpolate='pixelshuffle')
+        self.encoder_lr = LTE.LTE_simple_lr(m)
+        self.encoder_hr = LTE.LTE_simple_hr_single(l)
+        self.conv_tttf = conv3x3(l * 2, l)
+        self.forward_resblocks_0 = ResidualBlocksWithInputConv(m * 2, m, 1)
+        self.forward_resblocks_1 = ResidualBlocksWithInputConv(m * 2, m, 1)
+        self.forward_resblocks_2 = ResidualBlocksWithInputConv(m * 2, m, 1)
+        self.forward_resblocks_3 = ResidualBlocksWithInputConv(l * 2, l, 1)
+        self.downsample = PixelUnShufflePack_v2(l, m, 4, downsample_kernel=3)
+        self.upsample = PixelShufflePack(m, (m * self.split_ratio) // 4, 2, upsample_kernel=3)
+        self.upsample_post = PixelShufflePack((m * self.split_ratio) // 4, l, 4, upsample_kernel=3)
+        self.conv_last = nn.Conv2d(l, 1 if y_only else 3, 3, 1, 1)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+        self._engine = None
+        self._engine_sig = None
+
+    # ---- engine management: repack whenever a parameter was modified or moved
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine(self) -> DSVEngine:
+        dev = next(self.parameters()).device
+        sig = self._signature()
+        if self._engine is None or self._engine_sig != sig or self._engine.device != dev:
+            self._engine = DSVEngine(self.state_dict(), dev, self.y_only)
+            self._engine_sig = sig
+        return self._engine
+
+    def compute_flow(self, lrs):
+        n, t, c, h, w = lrs.shape
+        cur = lrs[:, 1:].reshape(-1, c, h, w)
+        prev = lrs[:, :-1].reshape(-1, c, h, w)
+        return self.engine().compute_flow(cur, prev).view(n, t - 1, 2, h, w), None
+
+    @torch.no_grad()
+    def forward(self, lrs, fvs, mks):
+        return self.engine().forward(lrs, fvs, mks)
+
+    # ---- streaming interface of the reference's one-frame-per-call variant (model/CRFP_test.py:2216-2478)
+    def clear_states(self):
+        if self._engine is not None:
+            self._engine.clear_states()
+
+    @torch.no_grad()
+    def forward_stream(self, lrs, fvs, mks):
+        """lrs[1,1,3,h,w], fvs[1,1,3,8h,8w], mks[1,1,1,8h,8w] -> [1,1,3|1,8h,8w], state kept between calls."""
+        out = self.engine().stream_frame(lrs[0, 0], fvs[0, 0], mks[0, 0])
+        return out[None, None]
+
+    def init_weights(self, pretrained=None, strict=True):
+        if isinstance(pretrained, str):
+            saved = torch.load(pretrained, map_location="cpu")
+            sd = self.state_dict()
+            sd.update(saved)
+            self.load_state_dict(sd, strict=strict)
+        elif pretrained is not None:
+            raise TypeError(f'"pretrained" must be a str or None. But received {type(pretrained)}.')

@@ -1,0 +1,115 @@
+"""Operator-level wrappers over the C-ABI (device tensors in, device tensors out).
+
+Every function requires float32 CUDA(=HIP) tensors; CPU tensors raise -- the CPU restatement of
+the path lives in ``oracle/`` and is test infrastructure, never a fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"crfp_amd: `{name}` must be a CUDA/HIP tensor (this build has no CPU path)")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_corners=True):
+    """Drop-in for the reference's ``flow_warp`` (model/CRFP.py:90-130): x[n,c,h,w], flow[n,h,w,2]."""
+    if tuple(x.shape[-2:]) != tuple(flow.shape[1:3]):
+        raise ValueError(f"The spatial sizes of input ({tuple(x.shape[-2:])}) and flow "
+                         f"({tuple(flow.shape[1:3])}) are not the same.")
+    if interpolation != "bilinear" or not align_corners:
+        raise NotImplementedError("flow_warp: only bilinear / align_corners=True (all reference call sites)")
+    if padding_mode not in ("zeros", "border"):
+        raise NotImplementedError(f"flow_warp: padding_mode {padding_mode!r}")
+    x, flow = _dev(x, "x"), _dev(flow, "flow")
+    n, c, h, w = x.shape
+    L = _lib.lib()
+    out = torch.empty_like(x)
+    nb = L.crfp_flow_warp_workspace_bytes(n, c, h, w)
+    ws = _ws(nb, x.device)
+    _lib.check(L.crfp_flow_warp_f32(x.data_ptr(), flow.data_ptr(), out.data_ptr(), n, c, h, w,
+                                    1 if padding_mode == "border" else 0, ws.data_ptr(), ws.numel(), _stream()),
+               "crfp_flow_warp_f32")
+    return out
+
+
+def dcnv2(x, offset, mask, weight, bias, kernel_size=3, padding=1, dilation=1, deformable_groups=1):
+    """Drop-in for ``dcn_v2.DCNv2.forward`` (reference model/CRFP.py:350)."""
+    x, offset, mask = _dev(x, "input"), _dev(offset, "offset"), _dev(mask, "mask")
+    weight, bias = _dev(weight, "weight"), _dev(bias, "bias")
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    K = kernel_size * kernel_size
+    assert offset.shape[1] == 2 * deformable_groups * K, "offset channels != 2*deformable_groups*k*k"
+    assert mask.shape[1] == deformable_groups * K, "mask channels != deformable_groups*k*k"
+    assert weight.shape[1] == cin and tuple(offset.shape[-2:]) == (h, w) and tuple(mask.shape[-2:]) == (h, w)
+    L = _lib.lib()
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    ws = _ws(L.crfp_dcnv2_workspace_bytes(n, cin, cout, h, w, kernel_size, deformable_groups), x.device)
+    _lib.check(L.crfp_dcnv2_forward_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), weight.data_ptr(),
+                                        bias.data_ptr(), out.data_ptr(), n, cin, cout, h, w, kernel_size, padding,
+                                        dilation, deformable_groups, ws.data_ptr(), ws.numel(), _stream()),
+               "crfp_dcnv2_forward_f32")
+    return out
+
+
+def conv3x3(x, weight, bias=None, act="none", post_scale=1.0):
+    """3x3 stride-1 pad-1 convolution + bias + activation on the fp32 MFMA path."""
+    x, weight = _dev(x, "x"), _dev(weight, "weight")
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    assert tuple(weight.shape) == (cout, cin, 3, 3), "conv3x3: weight must be [cout, cin, 3, 3]"
+    if bias is None:
+        bias = torch.zeros(cout, dtype=torch.float32, device=x.device)
+    bias = _dev(bias, "bias")
+    L = _lib.lib()
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    ws = _ws(L.crfp_conv3x3_workspace_bytes(n, cin, cout, h, w), x.device)
+    _lib.check(L.crfp_conv3x3_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n, cin, cout,
+                                  h, w, ACT[act], float(post_scale), ws.data_ptr(), ws.numel(), _stream()),
+               "crfp_conv3x3_f32")
+    return out
+
+
+def upsample_bilinear(x, scale_factor=None, size=None, mul=1.0):
+    """nn.Upsample(scale_factor=.., 'bilinear', align_corners=False) or F.interpolate(size=..)."""
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    if scale_factor is not None:
+        oh, ow = int(h * scale_factor), int(w * scale_factor)
+        sh = sw = 1.0 / float(scale_factor)
+    else:
+        oh, ow = size
+        # PyTorch computes in/out in float32 when only a size is given
+        sh = float(torch.tensor(h, dtype=torch.float32) / torch.tensor(oh, dtype=torch.float32))
+        sw = float(torch.tensor(w, dtype=torch.float32) / torch.tensor(ow, dtype=torch.float32))
+    out = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().crfp_upsample_bilinear_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, oh, ow, sh, sw,
+                                                     float(mul), _stream()), "crfp_upsample_bilinear_f32")
+    return out
+
+
+def sq_err_sums(a, b):
+    """(sum (a-b)^2, sum (Y(a)-Y(b))^2) as float64 -- raw material of psnr / psnr_y."""
+    a, b = _dev(a, "a"), _dev(b, "b")
+    n, c, h, w = a.shape
+    acc = torch.zeros(2, dtype=torch.float64, device=a.device)
+    _lib.check(_lib.lib().crfp_psnr_partial_f32(a.data_ptr(), b.data_ptr(), acc.data_ptr(), n, c, h, w, _stream()),
+               "crfp_psnr_partial_f32")
+    return acc

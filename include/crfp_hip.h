@@ -1,0 +1,134 @@
+/* libcrfp_hip.so -- C ABI of the MI355X-native (gfx950) CRFP recurrent x8 foveated-VSR path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every pointer is a
+ * DEVICE pointer owned by the caller (e.g. PyTorch's caching allocator) unless the argument is
+ * documented as host memory; the library never allocates, frees or retains device memory --
+ * scratch arrives through `workspace` (size from the matching *_workspace_bytes query).  Kernels
+ * are enqueued asynchronously on `stream` (a hipStream_t passed as void*); no entry point
+ * synchronises the device.  Return value: 0 = success, negative = CRFP_E_* argument error,
+ * positive = hipError_t of a failed launch.  crfp_last_error_string() describes the last failure
+ * on the calling thread.  No exceptions cross the boundary.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo eugenelet/CRFP):
+ *   crfp_flow_warp_f32        model/CRFP.py:90-130   flow_warp()  (ATen grid_sampler_2d underneath)
+ *   crfp_dcnv2_forward_f32    model/CRFP.py:6,318-320,350  third-party dcn_v2.DCNv2.forward
+ *   crfp_conv3x3_f32          every nn.Conv2d(k=3,s=1,p=1) on the path (e.g. model/CRFP.py:48-50,303-317)
+ *   crfp_upsample_bilinear_f32  nn.Upsample / F.interpolate(align_corners=False) (model/CRFP.py:808-812,1471-1478)
+ *   crfp_fnet_*               model/CRFP.py:743-814  FNet.forward, :1483-1508 compute_flow
+ *   crfp_dsv_*                model/CRFP.py:1387-1706 CRFP_DSV (ctor weights, forward) and the
+ *                             one-frame-per-call variant model/CRFP_test.py:2114-2478
+ *   crfp_psnr_partial_f32     utils.py:166-185,242-254,328-330 (psnr_cuda / bgr2ycbcr(y_only))
+ */
+#ifndef CRFP_HIP_H
+#define CRFP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRFP_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* error codes (negative) */
+#define CRFP_E_BADARG (-1)      /* null pointer / non-positive size / unsupported combination */
+#define CRFP_E_WORKSPACE (-2)   /* workspace missing or too small */
+#define CRFP_E_UNSUPPORTED (-3) /* shape or mode outside what the kernels implement */
+#define CRFP_E_STATE (-4)       /* engine used before weights were packed */
+
+/* activations for crfp_conv3x3_f32: out = post_scale * act(conv + bias) */
+#define CRFP_ACT_NONE 0
+#define CRFP_ACT_RELU 1
+#define CRFP_ACT_LRELU01 2 /* LeakyReLU(0.1) */
+#define CRFP_ACT_TANH 3
+#define CRFP_ACT_SIGMOID 4
+
+#define CRFP_PAD_ZEROS 0
+#define CRFP_PAD_BORDER 1
+
+int crfp_version(void);
+const char* crfp_last_error_string(void);
+
+/* ---- flow_warp: x[n,c,h,w] (NCHW f32), flow[n,h,w,2] = (dx,dy) pixels, out[n,c,h,w].
+ * Bilinear backward warp, align_corners=True semantics of the reference (sample position =
+ * pixel index + flow, routed through the [-1,1] normalisation in the same float32 order). */
+size_t crfp_flow_warp_workspace_bytes(int n, int c, int h, int w);
+int crfp_flow_warp_f32(const float* x, const float* flow, float* out, int n, int c, int h, int w,
+                       int padding_mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- DCNv2 forward (stride 1): x[n,cin,h,w], offset[n,2*dg*k*k,h,w] ((dy,dx) interleaved per
+ * tap per group), mask[n,dg*k*k,h,w], weight[cout,cin,k,k], bias[cout] -> out[n,cout,h,w].
+ * k=3, pad=1, dil=1 only (every call site of the reference).  Fast paths: (cin=cout=32, dg=8)
+ * on MFMA and (cin=cout=4, dg=1); other channel counts run a generic HIP kernel. */
+size_t crfp_dcnv2_workspace_bytes(int n, int cin, int cout, int h, int w, int k, int dg);
+int crfp_dcnv2_forward_f32(const float* x, const float* offset, const float* mask, const float* weight,
+                           const float* bias, float* out, int n, int cin, int cout, int h, int w, int k,
+                           int pad, int dil, int dg, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- 3x3 stride-1 pad-1 convolution, NCHW f32, fused bias + activation (fp32 MFMA). */
+size_t crfp_conv3x3_workspace_bytes(int n, int cin, int cout, int h, int w);
+int crfp_conv3x3_f32(const float* x, const float* weight, const float* bias, float* out, int n, int cin,
+                     int cout, int h, int w, int act, float post_scale, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ---- bilinear resize, align_corners=False, NCHW f32; out = mul * resize(x).  scale_h/scale_w
+ * are the source-index scales PyTorch uses (1/scale_factor for nn.Upsample, in/out for size=). */
+int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, int w, int oh, int ow,
+                               float scale_h, float scale_w, float mul, void* stream);
+
+/* ---- sum of squared differences for PSNR: acc[0] += sum((a-b)^2) over [n,c,h,w];
+ * acc[1] += the same on the luma the reference's eval computes (24.966*c0+128.553*c1+65.481*c2+16,
+ * utils.py:328-330), c==3 only.  acc is 2 doubles (device), zeroed by the caller. */
+int crfp_psnr_partial_f32(const float* a, const float* b, double* acc, int n, int c, int h, int w, void* stream);
+
+/* ---- CRFP_DSV engine (mid_channels=32, hr_dcn=True, offset_prop=True; y_only selectable).
+ * Parameters arrive as CRFP_DSV_NUM_PARAMS device pointers in the order of the reference's
+ * state_dict (weight then bias of each conv, list in crfp_dsv_param_name). */
+#define CRFP_DSV_NUM_PARAMS 118
+const char* crfp_dsv_param_name(int index);               /* state_dict key of parameter `index` */
+int crfp_dsv_param_numel(int index, int y_only);          /* element count of that parameter */
+size_t crfp_dsv_packed_weight_bytes(int y_only);
+/* repack all parameters into the MFMA / stencil layouts (device -> device, async on stream) */
+int crfp_dsv_pack_weights(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+
+size_t crfp_dsv_workspace_bytes(int t, int h, int w);
+/* One clip: lrs[t,3,h,w], fvs[t,3,8h,8w] f32, mks[t,1,8h,8w] u8 (bool), out[t,3|1,8h,8w].
+ * Zero initial state; flows from FNet(frame i, frame i-1).  Batches of clips: call once per clip. */
+int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, const float* fvs, const uint8_t* mks,
+                          float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Streaming: one frame per call, recurrent state kept inside `workspace` (same buffer every call).
+ * `first` != 0 resets the state (clear_states of the reference's streaming model). lr_prev may be
+ * NULL when first != 0. */
+int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const float* lr_prev, const float* fv,
+                          const uint8_t* mk, float* out, int first, int h, int w, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* FNet alone (compute_flow): pairs cur[n,3,h,w], prev[n,3,h,w] -> flow[n,2,h,w] (NCHW). */
+int crfp_fnet_forward(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-kernel timing for bench.py's roofline object: when enabled every kernel launch is
+ * bracketed by hipEvents on its stream; crfp_prof_report synchronises those events and fills
+ * up to `cap` records (name, launches, total ms, algorithmic bytes, algorithmic flops). */
+typedef struct crfp_prof_record {
+    char name[48];
+    int launches;
+    double total_ms;
+    double bytes;
+    double flops;
+} crfp_prof_record;
+int crfp_prof_enable(int on);
+int crfp_prof_reset(void);
+int crfp_prof_report(crfp_prof_record* out, int cap);
+
+/* debug: copy a named intermediate of the last crfp_dsv_* call out of the workspace (Q4 layout
+ * converted to NCHW).  Used by the parity tests to bisect; returns CRFP_E_BADARG for unknown names. */
+int crfp_dsv_debug_fetch(const char* name, int t, int h, int w, const void* workspace, float* out_nchw,
+                         int* c_out, int* h_out, int* w_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,245 @@
+"""GPU (-m gpu): parity of the HIP path against the oracle and the committed golden vectors.
+Every call goes through the C-ABI of libcrfp_hip.so (crfp_amd.ops / crfp_amd.engine).
+Tolerances: the north star asks |delta| < 1e-3 on the fp32 x8 SR frame; operator-level checks are
+held much tighter (fp32 re-association only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN  # noqa: E402
+
+T = torch.from_numpy
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def maxdiff(a, b):
+    a = a.detach().cpu() if isinstance(a, torch.Tensor) else T(np.asarray(a))
+    b = b.detach().cpu() if isinstance(b, torch.Tensor) else T(np.asarray(b))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max())
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import crfp_oracle
+    return crfp_oracle
+
+
+@pytest.fixture(autouse=True)
+def _nograd():
+    with torch.no_grad():
+        yield
+
+
+def test_library_loaded_and_version():
+    from crfp_amd import _lib
+    assert _lib.lib().crfp_version() == 100
+    assert os.path.exists(_lib.LIB_PATH)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act", [(3, 32, 17, 70, "lrelu"), (6, 32, 8, 64, "relu"), (32, 32, 24, 40, "none"),
+                                              (64, 32, 33, 65, "lrelu"), (66, 32, 9, 130, "relu"), (32, 216, 12, 20, "sigmoid"),
+                                              (128, 256, 5, 9, "relu"), (32, 2, 16, 16, "tanh"), (24, 64, 8, 8, "none")])
+def test_conv3x3_mfma(cin, cout, h, w, act):
+    from crfp_amd import ops
+    rs = np.random.RandomState(cin * 7 + cout)
+    x = T(rs.standard_normal((2, cin, h, w)).astype(np.float32))
+    wt = T((rs.standard_normal((cout, cin, 3, 3)) * (1.5 / np.sqrt(cin * 9))).astype(np.float32))
+    b = T(rs.standard_normal(cout).astype(np.float32))
+    ref = F.conv2d(x, wt, b, padding=1)
+    ref = {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1), "tanh": torch.tanh,
+           "sigmoid": torch.sigmoid}[act](ref)
+    got = ops.conv3x3(x.to(dev()), wt.to(dev()), b.to(dev()), act)
+    assert maxdiff(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["zeros", "border"])
+def test_flow_warp_golden(ops_golden, mode):
+    from crfp_amd import ops
+    g = ops_golden
+    got = ops.flow_warp(T(g["warp_x"]).to(dev()), T(g["warp_flow"]).to(dev()), padding_mode=mode)
+    assert maxdiff(got, g["warp_" + mode]) < 1e-5
+
+
+@pytest.mark.parametrize("c,h,w", [(32, 36, 64), (4, 144, 256), (24, 37, 61)])
+def test_flow_warp_random(orc, c, h, w):
+    from crfp_amd import ops
+    rs = np.random.RandomState(c + h)
+    x = T(rs.standard_normal((1, c, h, w)).astype(np.float32))
+    fl = T(rs.uniform(-9, 9, (1, h, w, 2)).astype(np.float32))
+    got = ops.flow_warp(x.to(dev()), fl.to(dev()))
+    assert maxdiff(got, orc.flow_warp(x, fl)) < 2e-5
+
+
+def test_flow_warp_shape_error():
+    from crfp_amd import ops
+    with pytest.raises(ValueError):
+        ops.flow_warp(torch.zeros(1, 2, 4, 5, device=dev()), torch.zeros(1, 4, 6, 2, device=dev()))
+
+
+def test_cpu_tensor_rejected():
+    from crfp_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.flow_warp(torch.zeros(1, 4, 4, 4), torch.zeros(1, 4, 4, 2))
+
+
+@pytest.mark.parametrize("C,O,dg,H,W", [(32, 32, 8, 23, 45), (32, 32, 8, 8, 32), (4, 4, 1, 40, 70), (8, 12, 2, 9, 11)])
+def test_dcnv2(orc, C, O, dg, H, W):
+    from crfp_amd import ops
+    rs = np.random.RandomState(C * 31 + H)
+    x = T(rs.standard_normal((2, C, H, W)).astype(np.float32))
+    off = rs.uniform(-6, 6, (2, 2 * dg * 9, H, W)).astype(np.float32)
+    off[0, :, 0, 0] = -40.0
+    off[1, 1, 2, 2] = float(W + 5)
+    off[1, 0, 1, 1] = -1.0
+    off = T(off)
+    msk = T(rs.uniform(0, 1, (2, dg * 9, H, W)).astype(np.float32))
+    wt = T((rs.standard_normal((O, C, 3, 3)) * 0.2).astype(np.float32))
+    b = T(rs.standard_normal(O).astype(np.float32))
+    ref = orc.dcnv2(x, off, msk, wt, b, dg)
+    got = ops.dcnv2(*[t.to(dev()) for t in (x, off, msk, wt, b)], 3, 1, 1, dg)
+    assert maxdiff(got, ref) < 3e-5
+
+
+def test_dcn_module_identity_kat(ops_golden):
+    """reference known-answer: fresh DCN_module == 0.5 * flow_warp (model/CRFP.py:354-370)."""
+    from crfp_amd.model import CRFP
+    g = ops_golden
+    for tag, m in (("n", CRFP.DCN_module(32, 8, 3, 10)), ("r", CRFP.DCN_module(4, 1, 3, 10, repeat=True))):
+        m = m.to(dev())
+        pre, flow = T(g[f"kat_{tag}_pre"]).to(dev()), T(g[f"kat_{tag}_flow"]).to(dev())
+        a, _ = m(torch.randn_like(pre), pre, torch.randn_like(pre), flow)
+        assert maxdiff(a, g[f"kat_{tag}_halfwarp"]) < 2e-5
+
+
+def test_upsample(orc):
+    from crfp_amd import ops
+    rs = np.random.RandomState(5)
+    x = T(rs.standard_normal((2, 3, 13, 21)).astype(np.float32))
+    for r in (2, 4, 8):
+        assert maxdiff(ops.upsample_bilinear(x.to(dev()), scale_factor=r), orc.up_bilinear(x, r)) < 1e-5
+    ref = F.interpolate(x, size=(20, 36), mode="bilinear", align_corners=False)
+    assert maxdiff(ops.upsample_bilinear(x.to(dev()), size=(20, 36)), ref) < 1e-5
+
+
+def _load_sub(module, sd, prefix):
+    module.load_state_dict({k[len(prefix):]: T(v.copy()) for k, v in sd.items() if k.startswith(prefix)}, strict=True)
+    return module.to(dev())
+
+
+def test_modules_vs_golden(ops_golden, weights_np):
+    from crfp_amd.model import CRFP, LTE
+    g, sd = ops_golden, weights_np
+    d = dev()
+    m = _load_sub(CRFP.PixelShufflePack(32, 24, 2, 3), sd, "upsample.")
+    assert maxdiff(m(T(g["psp_x"]).to(d)), g["psp_y"]) < 2e-5
+    m = _load_sub(CRFP.PixelUnShufflePack_v2(4, 32, 4, 3), sd, "downsample.")
+    assert maxdiff(m(T(g["pusp_x"]).to(d)), g["pusp_y"]) < 2e-5
+    m = _load_sub(CRFP.ResidualBlocksWithInputConv(64, 32, 1), sd, "forward_resblocks_1.")
+    assert maxdiff(m(T(g["res_x"]).to(d)), g["res_y"]) < 2e-5
+    m = _load_sub(LTE.LTE_simple_lr(32), sd, "encoder_lr.")
+    assert maxdiff(m(T(g["enc_lr_x"]).to(d), islr=True)[2], g["enc_lr_y"]) < 2e-5
+    m = _load_sub(LTE.LTE_simple_hr_single(4), sd, "encoder_hr.")
+    assert maxdiff(m(T(g["enc_hr_x"]).to(d), islr=True)[2], g["enc_hr_y"]) < 2e-5
+    m = _load_sub(CRFP.FNet(3), sd, "spynet.")
+    for tag in "ab":
+        assert maxdiff(m(T(g[f"fnet_{tag}_x1"]).to(d), T(g[f"fnet_{tag}_x2"]).to(d)), g[f"fnet_{tag}_y"]) < 1e-4
+    m = _load_sub(CRFP.DCN_module(32, 8, 3, 10, pre_offset=True, interpolate="none"), sd, "dcn_1.")
+    a, o = m(*[T(g[k]).to(d) for k in ("dcn1_cur", "dcn1_pre", "dcn1_prew", "dcn1_flow", "dcn1_poff")])
+    assert maxdiff(a, g["dcn1_aligned"]) < 1e-4 and maxdiff(o, g["dcn1_offfeat"]) < 2e-5
+    m = _load_sub(CRFP.DCN_module(4, 1, 3, 10, repeat=True, pre_offset=True, interpolate="pixelshuffle"), sd, "dcn_3.")
+    a, o = m(*[T(g[k]).to(d) for k in ("dcn3_cur", "dcn3_pre", "dcn3_prew", "dcn3_flow", "dcn3_poff")])
+    assert maxdiff(a, g["dcn3_aligned"]) < 1e-4 and maxdiff(o, g["dcn3_offfeat"]) < 2e-5
+
+
+def _model(sd_np, y_only=False):
+    from crfp_amd.model import CRFP
+    m = CRFP.CRFP_DSV(device=dev(), mid_channels=32, y_only=y_only, hr_dcn=True, offset_prop=True)
+    m.load_state_dict({k: T(v.copy()) for k, v in sd_np.items()}, strict=True)
+    return m.to(dev()).eval()
+
+
+@pytest.mark.parametrize("name", ["dsv_16x24_t3", "dsv_20x36_t4", "dsv_16x24_t2_yonly"])
+def test_full_forward_golden(name):
+    from crfp_amd import synth
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    y_only = bool(g["y_only"])
+    sd = synth.make_state_dict(int(g["weights_seed"]), y_only=y_only)
+    lrs, fvs, mks = synth.make_clip(int(g["clip_seed"]), 1, int(g["t"]), int(g["h"]), int(g["w"]),
+                                    fv_size=int(g["fv_size"]), sigma_t=10.0)
+    m = _model(sd, y_only)
+    d = dev()
+    flows, _ = m.compute_flow(T(lrs).to(d))
+    assert maxdiff(flows, g["flows"]) < 2e-3          # flow is in pixels (tanh*256 amplifies round-off)
+    out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    assert maxdiff(out, g["out"]) < 1e-3              # the north-star tolerance
+    assert maxdiff(out, g["out"]) < 2e-4              # what fp32 MFMA re-association actually gives
+
+
+def test_bisect_intermediates_small(orc):
+    """First frame + second frame intermediates against the oracle (localises a wiring error)."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    P = orc.load_numpy_state(sd)
+    h, w, t = 16, 24, 2
+    lrs, fvs, mks = synth.make_clip(3, 1, t, h, w, fv_size=48)
+    m = _model(sd)
+    d = dev()
+    out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    ref = orc.crfp_dsv_forward(P, T(lrs), T(fvs), T(mks))
+    eng = m.engine()
+    x_lr = eng.debug_fetch("x_lr", t, h, w)
+    ref_xlr = orc.lrelu(orc.conv(P, "encoder_lr.slice1.2", orc.lrelu(orc.conv(P, "encoder_lr.slice1.0", T(lrs)[0]))))
+    assert maxdiff(x_lr, ref_xlr) < 2e-5
+    assert maxdiff(out[:, 0], ref[:, 0]) < 1e-4, "first frame (no warp / DCN) differs"
+    assert maxdiff(out[:, 1], ref[:, 1]) < 2e-4, "second frame (warp + DCN) differs"
+
+
+def test_streaming_equals_clip():
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    h, w, t = 16, 24, 4
+    lrs, fvs, mks = synth.make_clip(5, 1, t, h, w, fv_size=48)
+    m = _model(sd)
+    d = dev()
+    L, Fv, M = T(lrs).to(d), T(fvs).to(d), T(mks).to(d)
+    clip = m(lrs=L, fvs=Fv, mks=M)
+    m.clear_states()
+    outs = [m.forward_stream(L[:, i:i + 1], Fv[:, i:i + 1], M[:, i:i + 1]) for i in range(t)]
+    assert maxdiff(torch.cat(outs, dim=1), clip) == 0.0
+
+
+def test_full_size_two_frames_vs_oracle(orc):
+    """BASELINE config A geometry (180x320 -> 1440x2560), 2 frames, against the oracle."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    P = orc.load_numpy_state(sd)
+    lrs, fvs, mks = synth.make_clip(1234, 1, 2, 180, 320, fv_size=96, sigma_t=10.0)
+    m = _model(sd)
+    d = dev()
+    out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    ref = orc.crfp_dsv_forward(P, T(lrs), T(fvs), T(mks))
+    assert maxdiff(out, ref) < 1e-3
+    p_ref = orc.psnr_rgb_and_y(ref[0, 1:2], T(np.clip(fvs[0, 1:2] * 0 + 0.5, 0, 1)))  # exercise metric code path
+    assert np.isfinite(p_ref[0])
+
+
+def test_psnr_sums(orc, ops_golden):
+    from crfp_amd import ops
+    g = ops_golden
+    sr, hr = T(g["metric_sr"]), T(g["metric_hr"])
+    acc = ops.sq_err_sums(sr.to(dev()), hr.to(dev())).cpu()
+    n = sr.numel()
+    psnr = -10.0 * np.log10(float(acc[0]) / n)
+    psnr_y = -10.0 * np.log10(float(acc[1]) / (n / 3) / 255.0 ** 2)
+    assert abs(psnr - float(g["metric_psnr"])) < 1e-3
+    assert abs(psnr_y - float(g["metric_psnr_y"])) < 1e-3
