@@ -1,0 +1,88 @@
+"""Eval harness counterpart of the reference's ``Trainer.eval_basicvsr`` (trainer.py:295-413) and the
+clip sharding used for multi-GPU runs.
+
+Quirks reproduced from the reference: per-frame metrics with an all-ones mask (:348), frame 0 of
+every 50th batch skipped (:350-351), RGB PSNR on the tensors as they are and PSNR-Y on the luma
+``24.966*c0 + 128.553*c1 + 65.481*c2 + 16`` (utils.py:328-330, BGR weights applied to RGB-ordered data,
+kept as is) after the data-dependent range rule of utils.py:244-250, arithmetic mean of per-frame
+values.  Clips are independent: clip c runs on rank c mod world; the only collective is the final
+sum of (sum_psnr, sum_psnr_y, n_frames).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Iterable, List, Optional, Sequence
+
+import torch
+
+
+def shard_clips(n_clips: int, rank: int, world: int) -> List[int]:
+    """Clip indices owned by `rank` (round-robin)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(range(rank, n_clips, world))
+
+
+def range_divisor(hr: torch.Tensor) -> float:
+    """utils.calc_psnr_and_ssim_cuda (utils.py:244-250): span > 2 -> /255; span > 1 -> (x+1)/2; else 1."""
+    span = float(hr.max() - hr.min())
+    if span > 2:
+        return 255.0
+    if span > 1:
+        return 2.0
+    return 1.0
+
+
+def psnr_from_mse(mse: float, numel: int) -> float:
+    """utils.psnr_cuda (utils.py:177-181)."""
+    if mse == 0:
+        return -20.0 * math.log10(math.sqrt((1 / 255.0) ** 2 / numel))
+    return -20.0 * math.log10(math.sqrt(mse))
+
+
+def frame_psnrs(sr: torch.Tensor, hr: torch.Tensor):
+    """(PSNR, PSNR-Y) of one frame pair [1,3,H,W] the way eval_basicvsr logs them; squared-error sums
+    come from the HIP reduction kernel."""
+    from . import ops
+    acc = ops.sq_err_sums(sr, hr).cpu()
+    n_rgb = sr.numel()
+    d_rgb = range_divisor(hr)
+    p = psnr_from_mse(float(acc[0]) / n_rgb / d_rgb ** 2, n_rgb)
+    wy = torch.tensor([24.966, 128.553, 65.481], device=hr.device).view(1, 3, 1, 1)
+    y_hr = (hr * wy).sum(1, keepdim=True) + 16.0
+    d_y = range_divisor(y_hr)
+    n_y = n_rgb // 3
+    py = psnr_from_mse(float(acc[1]) / n_y / d_y ** 2, n_y)
+    return p, py
+
+
+def evaluate(clip_fn: Callable[[int], Sequence[float]], n_clips: int, rank: int = 0, world: int = 1, dist=None,
+             device: Optional[torch.device] = None):
+    """Run `clip_fn(clip_index) -> [(psnr, psnr_y) per counted frame]` on this rank's shard and reduce.
+    Returns dict(psnr, psnr_y, frames)."""
+    sums = torch.zeros(3, dtype=torch.float64)
+    for c in shard_clips(n_clips, rank, world):
+        for p, py in clip_fn(c):
+            sums += torch.tensor([p, py, 1.0], dtype=torch.float64)
+    if dist is not None and world > 1:
+        buf = sums.to(device) if device is not None else sums
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        sums = buf.cpu()
+    n = float(sums[2])
+    return {"psnr": float(sums[0]) / n if n else float("nan"), "psnr_y": float(sums[1]) / n if n else float("nan"),
+            "frames": int(n)}
+
+
+def counted_frames(i_batch: int, n_frames: int) -> Iterable[int]:
+    """trainer.py:349-351: frame 0 is skipped when i_batch % 50 == 0."""
+    return (i for i in range(n_frames) if not (i == 0 and i_batch % 50 == 0))
+
+
+def eval_clip(model, batch: dict, i_batch: int):
+    """One eval batch through the model (trainer.py:307-369): batch has LR, HR, Ref, Ref_sp on device."""
+    with torch.no_grad():
+        sr = model(lrs=batch["LR"], fvs=batch["Ref"], mks=batch["Ref_sp"])
+    B, N, C, H, W = sr.shape
+    sr = sr.view(B * N, C, H, W)
+    hr = batch["HR"].view(B * N, -1, H, W)
+    return [frame_psnrs(sr[i:i + 1], hr[i:i + 1]) for i in counted_frames(i_batch, N)]

@@ -1,0 +1,152 @@
+"""CPU: host logic and the C-ABI surface (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+from crfp_amd import synth
+
+
+@pytest.fixture(scope="module")
+def lib():
+    so = os.path.join(ROOT, "crfp_amd", "libcrfp_hip.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "crfp_amd", "csrc"), "-j8"])
+    from crfp_amd import _lib
+    return _lib.lib()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "crfp_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(crfp_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_symbols()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(os.path.join(ROOT, "crfp_amd", "libcrfp_hip.so"))
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/crfp_hip.h but not exported"
+
+
+def test_binding_table_covers_header():
+    from crfp_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_version_and_param_table(lib):
+    from crfp_amd import engine
+    assert lib.crfp_version() == 100
+    names = engine.param_names()
+    assert names == synth.state_dict_keys()
+    sd = synth.make_state_dict(1)
+    for i, k in enumerate(names):
+        assert lib.crfp_dsv_param_numel(i, 0) == sd[k].size
+    sd1 = synth.make_state_dict(1, y_only=True)
+    for i, k in enumerate(names):
+        assert lib.crfp_dsv_param_numel(i, 1) == sd1[k].size
+    assert lib.crfp_dsv_param_name(-1) is None and lib.crfp_dsv_param_name(118) is None
+
+
+def test_sizes_are_sane(lib):
+    assert 9e6 < lib.crfp_dsv_packed_weight_bytes(0) < 12e6      # 2.28 M params + padding/packing overhead
+    a = lib.crfp_dsv_workspace_bytes(7, 180, 320)
+    b = lib.crfp_dsv_workspace_bytes(7, 270, 480)
+    assert 1e9 < a < 4e9 and 2.0 < b / a < 2.5                    # scales with pixels
+    assert lib.crfp_dsv_workspace_bytes(0, 180, 320) == 0
+    assert lib.crfp_dsv_workspace_bytes(7, 4, 4) == 0
+    assert lib.crfp_flow_warp_workspace_bytes(1, 32, 360, 640) == 2 * 32 * 360 * 640 * 4
+
+
+def test_argument_errors_do_not_touch_the_gpu(lib):
+    from crfp_amd import _lib
+    rc = lib.crfp_dsv_forward_clip(None, 0, None, None, None, None, 7, 180, 320, None, 0, None)
+    assert rc == -1 and b"null" in lib.crfp_last_error_string()
+    rc = lib.crfp_flow_warp_f32(None, None, None, 1, 4, 8, 8, 0, None, 0, None)
+    assert rc == -1
+    rc = lib.crfp_dcnv2_forward_f32(*([ctypes.c_void_p(16)] * 6), 1, 32, 32, 8, 8, 5, 2, 1, 8, None, 0, None)
+    assert rc == -3 and b"kernel 3" in lib.crfp_last_error_string()
+    rc = lib.crfp_dcnv2_forward_f32(*([ctypes.c_void_p(16)] * 6), 1, 30, 32, 8, 8, 3, 1, 1, 8, None, 0, None)
+    assert rc == -1
+    rc = lib.crfp_conv3x3_f32(*([ctypes.c_void_p(16)] * 4), 1, 3, 8, 8, 8, 9, 1.0, None, 0, None)
+    assert rc == -1
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "x")
+
+
+def test_module_mirror_keys_and_shapes():
+    from crfp_amd.model import CRFP
+    for y_only in (False, True):
+        m = CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=32, y_only=y_only)
+        sd = synth.make_state_dict(3, y_only=y_only)
+        assert list(m.state_dict().keys()) == list(sd.keys())
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        assert any("spynet" in k for k, _ in m.named_parameters())        # trainer.py:131-141 relies on it
+    with pytest.raises(NotImplementedError):
+        CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=16)
+
+
+def test_dcn_module_init_matches_reference_contract():
+    from crfp_amd.model import CRFP
+    m = CRFP.DCN_module(32, 8, 3, 10)
+    assert float(m.dcn_offset.weight.abs().max()) == 0 and float(m.dcn_mask.bias.abs().max()) == 0
+    w = m.dcn.weight.detach()
+    assert float(w.sum()) == 32 and all(float(w[i, i, 1, 1]) == 1 for i in range(32))
+    r = CRFP.DCN_module(4, 1, 3, 10, repeat=True, pre_offset=True, interpolate="pixelshuffle")
+    assert r.dcn_offset.out_channels == 2 and r.dcn_mask.out_channels == 1
+    assert r.upsample.upsample_conv.weight.shape == (64, 32, 3, 3)
+
+
+def test_product_refuses_cpu_tensors():
+    from crfp_amd import ops
+    from crfp_amd.model import CRFP
+    with pytest.raises(RuntimeError):
+        ops.conv3x3(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
+    m = CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=32)
+    with pytest.raises(RuntimeError):
+        m(lrs=torch.zeros(1, 2, 3, 8, 8), fvs=torch.zeros(1, 2, 3, 64, 64), mks=torch.zeros(1, 2, 1, 64, 64, dtype=torch.bool))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is a checker: nothing under crfp_amd/ may import, call or load it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "crfp_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "dcnv2_ref" not in txt, f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r); import crfp_amd._lib as L; L.LIB_PATH = %r\n"
+            "try:\n    L.lib()\nexcept RuntimeError as e:\n    print('RAISED', 'not built' in str(e))\n") % (ROOT, str(tmp_path / "nope.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).stdout
+    assert "RAISED True" in out
+
+
+def test_eval_quirks():
+    from crfp_amd import evalrig
+    assert list(evalrig.counted_frames(0, 4)) == [1, 2, 3]         # trainer.py:350-351
+    assert list(evalrig.counted_frames(7, 4)) == [0, 1, 2, 3]
+    assert list(evalrig.counted_frames(50, 3)) == [1, 2]
+    assert evalrig.range_divisor(torch.tensor([16.0, 235.0])) == 255.0
+    assert evalrig.range_divisor(torch.tensor([-1.0, 0.9])) == 2.0
+    assert evalrig.range_divisor(torch.tensor([0.0, 1.0])) == 1.0
+    assert abs(evalrig.psnr_from_mse(0.01, 10) - 20.0) < 1e-9
+    assert evalrig.shard_clips(32, 3, 8) == [3, 11, 19, 27]
+    assert sorted(sum((evalrig.shard_clips(10, r, 4) for r in range(4)), [])) == list(range(10))
+
+
+def test_synth_clip_properties():
+    lrs, fvs, mks = synth.make_clip(5, 1, 3, 16, 24, fv_size=48, sigma_t=10.0)
+    assert lrs.shape == (1, 3, 3, 16, 24) and fvs.shape == (1, 3, 3, 128, 192) and mks.dtype == np.bool_
+    assert int(mks[0, 0].sum()) == 48 * 48
+    assert float(np.abs(fvs[~np.broadcast_to(mks, fvs.shape)]).max()) == 0.0   # zero outside the fovea (reds.py:196-203)
+    assert 0.0 <= lrs.min() and lrs.max() <= 1.0
