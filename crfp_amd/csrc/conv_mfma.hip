@@ -19,9 +19,14 @@
 // input in chunks of 2 quads (8 channels): stage (8+2)x(64+2) halo -> LDS, 9 taps x 4 MFMAs x CT x 4.
 #include "crfp_common.h"
 
+#include <cstdlib>
+
 namespace crfp {
 
-constexpr int TW = 64, TH = 8, LW = TW + 2, LH = TH + 2;
+constexpr int TW = 64, LW = TW + 2;
+#ifndef CRFP_TAP_UNROLL
+#define CRFP_TAP_UNROLL 3
+#endif
 
 __device__ __forceinline__ float4 load_src_quad(const ConvSrc& s, int n, int kql, int gy, int gx, int H, int W) {
     const float* base = s.p + (long long)n * s.bstride;
@@ -61,9 +66,83 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
-template <int CT>
+// Stage NIN halo elements of one K-quad into registers; the switch on the source kind is hoisted out
+// of the (fully unrolled) element loop so every case is straight-line code with static register indices.
+template <int NIN>
+__device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc& s, int n, int kql,
+                                                const int (&gy)[NIN], const int (&gx)[NIN], const bool (&ok)[NIN],
+                                                int H, int W) {
+    const float* base = s.p + (long long)n * s.bstride;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    switch (s.kind) {
+        case SRC_Q4: {
+            const float* b = base + (long long)kql * H * W * 4;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                if (ok[k]) r[k] = *reinterpret_cast<const float4*>(b + ((long long)gy[k] * W + gx[k]) * 4);
+            break;
+        }
+        case SRC_NCHW: {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                if (ok[k]) {
+                    const long long o = (long long)gy[k] * W + gx[k], pl = (long long)H * W;
+                    const int c0 = 4 * kql;
+                    r[k].x = c0 + 0 < s.nch ? base[(c0 + 0) * pl + o] : 0.0f;
+                    r[k].y = c0 + 1 < s.nch ? base[(c0 + 1) * pl + o] : 0.0f;
+                    r[k].z = c0 + 2 < s.nch ? base[(c0 + 2) * pl + o] : 0.0f;
+                    r[k].w = c0 + 3 < s.nch ? base[(c0 + 3) * pl + o] : 0.0f;
+                }
+            break;
+        }
+        case SRC_UNSHUF4: {
+            const int Qp = kql >> 4, ij = kql & 15, i = ij >> 2, jj = ij & 3;
+            const int H4 = 4 * H, W4 = 4 * W;
+            const float* b = base + (long long)Qp * H4 * W4 * 4;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                if (ok[k]) r[k] = *reinterpret_cast<const float4*>(b + ((long long)(4 * gy[k] + i) * W4 + 4 * gx[k] + jj) * 4);
+            break;
+        }
+        case SRC_FLOW2: {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                if (ok[k]) {
+                    const float2 f = *reinterpret_cast<const float2*>(base + ((long long)gy[k] * W + gx[k]) * 2);
+                    r[k] = make_float4(f.x, f.y, 0.0f, 0.0f);
+                }
+            break;
+        }
+        default: break;
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct
+                                                          // copies lowered to memcpy into a private alloca)
+template <int CT, int NW>
+__device__ __forceinline__ void load_weight_batch(f32x4 (&rw)[NW], const f32x4* __restrict__ wp, int T0, int npairs,
+                                                  int pair, int tid) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int idx = min(tid + 256 * k, CT * 576 - 1);  // clamp: always a valid load
+        const int ct = idx / 576, rem = idx - ct * 576;
+        rw[k] = wp[((long long)(T0 + ct) * npairs + pair) * 576 + rem];
+    }
+}
+
+// CT = cout tiles (of 32) per workgroup, RPW = output rows per wave (tile = 4*RPW rows x 64 px).
+template <int CT, int RPW>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) {
+    constexpr int TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
+    // One K-chunk (2 quads = 8 input channels) lives in LDS at a time: the halo tile of both quads
+    // and the packed weights of the chunk for the CT cout tiles.  The NEXT chunk's global loads are
+    // issued into registers before the MFMAs of the current chunk start, so HBM/L2 latency hides
+    // behind 144*CT MFMAs per wave; LDS is rewritten between two barriers.
     __shared__ float4 tile[2][LH][LW];
+    __shared__ float4 wlds[CT][9 * 64];
+    constexpr int NIN = (LH * LW + 255) / 256;       // 3 halo elements per thread per quad
+    constexpr int NW = (CT * 9 * 64 + 255) / 256;    // 3 (CT=1) or 5 (CT=2) weight float4 per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
@@ -72,47 +151,77 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
 
-    f32x16 acc[CT][4];
+    // per-thread staging coordinates (constant over the K loop)
+    int sgy[NIN], sgx[NIN];
+    bool sval[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const int idx = tid + 256 * k;
+        const int r = idx / LW, c = idx - r * LW;
+        sgy[k] = ty0 + r - 1;
+        sgx[k] = tx0 + c - 1;
+        sval[k] = idx < LH * LW && sgy[k] >= 0 && sgy[k] < H && sgx[k] >= 0 && sgx[k] < W;
+    }
+
+    f32x16 acc[CT][PT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+        for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
 
     const int npairs = a.kq >> 1;
-    const float4* __restrict__ wp = reinterpret_cast<const float4*>(a.wpk);
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wpk);
+    float4 rin0[NIN], rin1[NIN];
+    f32x4 rw[NW];
 
+#define CRFP_ISSUE_LOADS(PAIR)                                                                          \
+    {                                                                                                   \
+        {                                                                                               \
+            int kql = 2 * (PAIR), s = 0;                                                                \
+            while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }                  \
+            load_quad_batch<NIN>(rin0, a.src[s], n, kql, sgy, sgx, sval, H, W);                         \
+        }                                                                                               \
+        {                                                                                               \
+            int kql = 2 * (PAIR) + 1, s = 0;                                                            \
+            while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }                  \
+            load_quad_batch<NIN>(rin1, a.src[s], n, kql, sgy, sgx, sval, H, W);                         \
+        }                                                                                               \
+        load_weight_batch<CT, NW>(rw, wp, T0, npairs, (PAIR), tid);                                     \
+    }
+
+    CRFP_ISSUE_LOADS(0)
     for (int pair = 0; pair < npairs; ++pair) {
-        __syncthreads();
+        __syncthreads();  // every wave finished reading the previous chunk
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            int kql = 2 * pair + q, s = 0;
-            while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
-            const ConvSrc src = a.src[s];
-            for (int idx = tid; idx < LH * LW; idx += 256) {
-                const int r = idx / LW, c = idx - r * LW;
-                const int gy = ty0 + r - 1, gx = tx0 + c - 1;
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = load_src_quad(src, n, kql, gy, gx, H, W);
-                tile[q][r][c] = v;
+        for (int k = 0; k < NIN; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < LH * LW) {
+                (&tile[0][0][0])[idx] = rin0[k];
+                (&tile[1][0][0])[idx] = rin1[k];
             }
         }
-        __syncthreads();
 #pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < CT * 576) reinterpret_cast<f32x4*>(&wlds[0][0])[idx] = rw[k];
+        }
+        __syncthreads();
+        if (pair + 1 < npairs) CRFP_ISSUE_LOADS(pair + 1)
+#pragma unroll CRFP_TAP_UNROLL
         for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
+            const int ky = tap / 3, kx = tap - 3 * ky;
             float4 wa[CT];
 #pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wa[ct] = wlds[ct][tap * 64 + lane];
+            float4 b[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) b[pt] = tile[h][wave * RPW + (pt >> 1) + ky][(pt & 1) * 32 + j + kx];
+#pragma unroll
             for (int ct = 0; ct < CT; ++ct)
-                wa[ct] = wp[(((long long)(T0 + ct) * npairs + pair) * 9 + tap) * 64 + lane];
-            float4 b[4];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) b[pt] = tile[h][wave * 2 + (pt >> 1) + ky][(pt & 1) * 32 + j + kx];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt) {
+                for (int pt = 0; pt < PT; ++pt) {
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct].x, b[pt].x, acc[ct][pt], 0, 0, 0);
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct].y, b[pt].y, acc[ct][pt], 0, 0, 0);
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct].z, b[pt].z, acc[ct][pt], 0, 0, 0);
@@ -120,14 +229,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
                 }
         }
     }
+#undef CRFP_ISSUE_LOADS
 
     // ---------------- epilogue: bias, activation, scale, residual, layout-aware store
     const int nrows = conv_packed_rows(a.cout, a.store, a.ps_r);
     const int ncq = (nrows + 3) >> 2;
     const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        const int y = ty0 + wave * 2 + (pt >> 1), x = tx0 + (pt & 1) * 32 + j;
+    for (int pt = 0; pt < PT; ++pt) {
+        const int y = ty0 + wave * RPW + (pt >> 1), x = tx0 + (pt & 1) * 32 + j;
         if (y >= H || x >= W) continue;
         float2 fl = make_float2(0.0f, 0.0f);
         if (a.store == ST_OFFMASK)
@@ -242,15 +352,21 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         set_error("conv_mfma %s: bad plan (kq=%d ctiles=%d nsrc=%d)", name, a.kq, a.ctiles, a.nsrc);
         return CRFP_E_BADARG;
     }
+    static const int max_ct = getenv("CRFP_CONV_CT") ? atoi(getenv("CRFP_CONV_CT")) : 2;  // tuning knob
+    const bool ct2 = a.ctiles % 2 == 0 && max_ct >= 2;
+    const int TH = ct2 ? 4 : 8;
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const double px = (double)a.N * a.H * a.W;
     double in_ch = 0;
     for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].kind == SRC_ZERO ? 0 : a.src[i].nch;
     ProfScope prof(name, s, px * (in_ch + a.cout) * 4.0 + (double)a.cout * in_ch * 9 * 4.0,
                    2.0 * px * a.cout * in_ch * 9.0);
-    {
+    if (ct2) {
+        dim3 grid(tiles, a.ctiles / 2, a.N);
+        conv3x3_mfma_kernel<2, 1><<<grid, 256, 0, s>>>(a);
+    } else {
         dim3 grid(tiles, a.ctiles, a.N);
-        conv3x3_mfma_kernel<1><<<grid, 256, 0, s>>>(a);
+        conv3x3_mfma_kernel<1, 2><<<grid, 256, 0, s>>>(a);
     }
     CRFP_CHECK_LAUNCH();
     return 0;

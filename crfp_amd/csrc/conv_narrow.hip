@@ -11,6 +11,8 @@
 
 namespace crfp {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float4 narrow_load(const ConvSrc& s, int n, int kql, int gy, int gx, int H, int W) {
     const float* base = s.p + (long long)n * s.bstride;
     if (s.kind == SRC_FLOW2) {
@@ -30,74 +32,122 @@ __device__ __forceinline__ float n_act(float v, int act) {
     }
 }
 
-template <int KQ>
-__global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const NarrowArgs a) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+// Workgroup = 256 threads = one 64 x 16 output tile; the (16+2) x (64+2) halo of every input quad
+// is staged in LDS once (coalesced 16-B loads), then thread (tx, ty) produces the 4 vertically
+// adjacent pixels (tx, 4*ty .. 4*ty+3): 18 ds_read_b128 per input quad feed 4 x 9 x 16 FMAs, and
+// the 144*KQ weights (wave-uniform scalar loads) are amortised over 4 pixels.
+constexpr int NTW = 64, NTH = 16, NLW = NTW + 2, NLH = NTH + 2;
+
+template <int KQ, int EPI>
+__global__ __launch_bounds__(256, 4) void conv3x3_narrow_kernel(const NarrowArgs a) {
+    __shared__ float4 tile[KQ][NLH][NLW];
+    __shared__ float4 wl[9 * KQ * 4];  // weights as [tap][kq][cin comp] -> float4 over cout (broadcast reads)
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    if (tid < 9 * KQ * 4) wl[tid] = reinterpret_cast<const float4*>(a.wpk)[tid];
+    const int x0 = blockIdx.x * NTW, y0 = blockIdx.y * NTH;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
-    if (x >= W || y >= H) return;
 
-    // resolve K-quad -> (source, local quad) once (uniform)
-    int ksrc[KQ], klocal[KQ];
+    constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per quad
 #pragma unroll
     for (int k = 0; k < KQ; ++k) {
         int kql = k, s = 0;
         while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
-        ksrc[k] = s;
-        klocal[k] = kql;
-    }
-
-    float acc[4] = {a.bpk[0], a.bpk[1], a.bpk[2], a.bpk[3]};
-    float4 centre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float* __restrict__ w = a.wpk;
+        const ConvSrc src = a.src[s];
+        const float* base = src.p + (long long)n * src.bstride + (src.kind == SRC_FLOW2 ? 0 : (long long)kql * H * W * 4);
+        f32x4 r[NST];
+        // issue every load of this quad before the first LDS write (independent loads in flight together)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int gy = y + tap / 3 - 1, gx = x + tap % 3 - 1;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        for (int t = 0; t < NST; ++t) {
+            const int idx = tid + 256 * t;
+            const int rr = idx / NLW, c = idx - rr * NLW;
+            const int gy = y0 + rr - 1, gx = x0 + c - 1;
+            r[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (idx < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                if (src.kind == SRC_FLOW2) {
+                    const float2 f = *reinterpret_cast<const float2*>(base + ((long long)gy * W + gx) * 2);
+                    r[t] = f32x4{f.x, f.y, 0.0f, 0.0f};
+                } else {
+                    r[t] = *reinterpret_cast<const f32x4*>(base + ((long long)gy * W + gx) * 4);
+                }
+            }
+        }
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) {
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (in) v = narrow_load(a.src[ksrc[k]], n, klocal[k], gy, gx, H, W);
-            if (tap == 4 && k == 0) centre = v;
-            const float* wk = w + (tap * KQ + k) * 16;
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-                acc[o] = fmaf(wk[12 + o], v.w, fmaf(wk[8 + o], v.z, fmaf(wk[4 + o], v.y, fmaf(wk[o], v.x, acc[o]))));
+        for (int t = 0; t < NST; ++t) {
+            const int idx = tid + 256 * t;
+            if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = r[t];
         }
     }
+    __syncthreads();
 
-    const long long pix = (long long)y * W + x;
-    if (a.epi == NE_PLAIN) {
-        float v[4];
+    float acc[4][4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) v[o] = o < a.cout ? n_act(acc[o], a.act) * a.post_scale : 0.0f;
-        if (a.resid) {
-            const float4 r = *reinterpret_cast<const float4*>(a.resid + (long long)n * a.resid_bstride + pix * 4);
-            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-        }
-        *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if (a.epi == NE_BLEND) {
-        const bool m = a.mask[(long long)n * a.mask_bstride + pix] != 0;
-        float v[4] = {m ? acc[0] : centre.x, m ? acc[1] : centre.y, m ? acc[2] : centre.z, m ? acc[3] : centre.w};
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int o = 0; o < 4; ++o) v[o] = v[o] > 0.0f ? v[o] : 0.1f * v[o];
-        *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if (a.epi == NE_LAST) {
-        const float4 b = *reinterpret_cast<const float4*>(a.base + (long long)n * a.base_bstride + pix * 4);
-        float* o = a.dst + (long long)n * a.dst_bstride;
-        if (a.y_only) {
-            o[pix] = acc[0] + (0.299f * b.x + 0.587f * b.y + 0.114f * b.z);
-        } else {
-            const long long plane = (long long)H * W;
-            o[pix] = acc[0] + b.x;
-            o[plane + pix] = acc[1] + b.y;
-            o[2 * plane + pix] = acc[2] + b.z;
+        for (int o = 0; o < 4; ++o) acc[i][o] = a.bpk[o];
+    // (k, ky) loops are deliberately NOT unrolled: hipcc otherwise hoists all 36 weight reads and
+    // 18 halo reads of a quad and blows past 200 VGPRs (or spills at a lower cap).
+#pragma unroll 1
+    for (int k = 0; k < KQ; ++k) {
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4* wq = &wl[((ky * 3 + kx) * KQ + k) * 4];
+                const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 u = tile[k][4 * ty + ky + i][tx + kx];
+                    acc[i][0] = fmaf(w3.x, u.w, fmaf(w2.x, u.z, fmaf(w1.x, u.y, fmaf(w0.x, u.x, acc[i][0]))));
+                    acc[i][1] = fmaf(w3.y, u.w, fmaf(w2.y, u.z, fmaf(w1.y, u.y, fmaf(w0.y, u.x, acc[i][1]))));
+                    acc[i][2] = fmaf(w3.z, u.w, fmaf(w2.z, u.z, fmaf(w1.z, u.y, fmaf(w0.z, u.x, acc[i][2]))));
+                    acc[i][3] = fmaf(w3.w, u.w, fmaf(w2.w, u.z, fmaf(w1.w, u.y, fmaf(w0.w, u.x, acc[i][3]))));
+                }
+            }
         }
-    } else {  // NE_OFFMASK3
-        const float2 f = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + pix * 2);
-        *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) =
-            make_float4(10.0f * tanhf(acc[0]) + f.y, 10.0f * tanhf(acc[1]) + f.x, 1.0f / (1.0f + expf(-acc[2])), 0.0f);
+    }
+
+    const int x = x0 + tx;
+    if (x >= W) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = y0 + 4 * ty + i;
+        if (y >= H) break;
+        const long long pix = (long long)y * W + x;
+        if (EPI == NE_PLAIN) {
+            float v[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[o] = o < a.cout ? n_act(acc[i][o], a.act) * a.post_scale : 0.0f;
+            if (a.resid) {
+                const float4 r = *reinterpret_cast<const float4*>(a.resid + (long long)n * a.resid_bstride + pix * 4);
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            }
+            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (EPI == NE_BLEND) {
+            const float4 centre = tile[0][4 * ty + i + 1][tx + 1];
+            const bool m = a.mask[(long long)n * a.mask_bstride + pix] != 0;
+            float v[4] = {m ? acc[i][0] : centre.x, m ? acc[i][1] : centre.y, m ? acc[i][2] : centre.z,
+                          m ? acc[i][3] : centre.w};
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[o] = v[o] > 0.0f ? v[o] : 0.1f * v[o];
+            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (EPI == NE_LAST) {
+            const float4 b = *reinterpret_cast<const float4*>(a.base + (long long)n * a.base_bstride + pix * 4);
+            float* o = a.dst + (long long)n * a.dst_bstride;
+            if (a.y_only) {
+                o[pix] = acc[i][0] + (0.299f * b.x + 0.587f * b.y + 0.114f * b.z);
+            } else {
+                const long long plane = (long long)H * W;
+                o[pix] = acc[i][0] + b.x;
+                o[plane + pix] = acc[i][1] + b.y;
+                o[2 * plane + pix] = acc[i][2] + b.z;
+            }
+        } else {  // NE_OFFMASK3
+            const float2 f = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + pix * 2);
+            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) =
+                make_float4(10.0f * tanhf(acc[i][0]) + f.y, 10.0f * tanhf(acc[i][1]) + f.x,
+                            1.0f / (1.0f + expf(-acc[i][2])), 0.0f);
+        }
     }
 }
 
@@ -149,12 +199,20 @@ int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s) {
     if (a.resid) extra += 4;
     ProfScope prof(name, s, px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * 4.0,
                    2.0 * px * in_ch * a.cout * 9.0);
-    dim3 grid((a.W + 63) / 64, (a.H + 3) / 4, a.N);
-    switch (a.kq) {
-        case 1: conv3x3_narrow_kernel<1><<<grid, 256, 0, s>>>(a); break;
-        case 2: conv3x3_narrow_kernel<2><<<grid, 256, 0, s>>>(a); break;
-        default: conv3x3_narrow_kernel<3><<<grid, 256, 0, s>>>(a); break;
+    dim3 grid((a.W + NTW - 1) / NTW, (a.H + NTH - 1) / NTH, a.N);
+#define CRFP_NARROW_LAUNCH(KQ_)                                                                    \
+    switch (a.epi) {                                                                               \
+        case NE_PLAIN: conv3x3_narrow_kernel<KQ_, NE_PLAIN><<<grid, 256, 0, s>>>(a); break;        \
+        case NE_BLEND: conv3x3_narrow_kernel<KQ_, NE_BLEND><<<grid, 256, 0, s>>>(a); break;        \
+        case NE_LAST: conv3x3_narrow_kernel<KQ_, NE_LAST><<<grid, 256, 0, s>>>(a); break;          \
+        default: conv3x3_narrow_kernel<KQ_, NE_OFFMASK3><<<grid, 256, 0, s>>>(a); break;           \
     }
+    switch (a.kq) {
+        case 1: CRFP_NARROW_LAUNCH(1) break;
+        case 2: CRFP_NARROW_LAUNCH(2) break;
+        default: CRFP_NARROW_LAUNCH(3) break;
+    }
+#undef CRFP_NARROW_LAUNCH
     CRFP_CHECK_LAUNCH();
     return 0;
 }
