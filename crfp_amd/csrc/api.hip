@@ -6,6 +6,10 @@
 using namespace crfp;
 
 static size_t q4_bytes(int n, int c, int h, int w) { return align_up((size_t)n * ((c + 3) / 4) * h * w * 16, 256); }
+static size_t p4_guard(int w) { return align_up((size_t)(w + 2) * 16, 256); }  // zeroed guard in front of plane 0
+static size_t p4_bytes(int n, int c, int h, int w) {
+    return p4_guard(w) + align_up((size_t)n * ((c + 3) / 4) * (h + 1) * (w + 1) * 16, 256);
+}
 
 extern "C" {
 
@@ -21,15 +25,15 @@ int crfp_flow_warp_f32(const float* x, const float* flow, float* out, int n, int
     float* xo = (float*)((char*)workspace + q4_bytes(n, c, h, w));
     const int nq = (c + 3) / 4;
     const long long bs = (long long)nq * h * w * 4;
-    int rc = launch_nchw_to_q4(x, xin, n, c, h, w, s);
-    if (!rc) rc = launch_flow_warp_q4(xin, bs, flow, (long long)h * w * 2, xo, bs, n, nq, h, w, padding_mode == CRFP_PAD_BORDER, s);
-    if (!rc) rc = launch_q4_to_nchw(xo, out, n, c, h, w, s);
+    int rc = launch_nchw_to_q4(x, xin, n, c, h, w, 0, s);
+    if (!rc) rc = launch_flow_warp_q4(xin, bs, flow, (long long)h * w * 2, xo, bs, n, nq, h, w, padding_mode == CRFP_PAD_BORDER, 0, s);
+    if (!rc) rc = launch_q4_to_nchw(xo, out, n, c, h, w, 0, s);
     return rc;
 }
 
 size_t crfp_dcnv2_workspace_bytes(int n, int cin, int cout, int h, int w, int k, int dg) {
     if (cin == 32 && cout == 32 && dg == 8 && k == 3)
-        return 2 * q4_bytes(n, 32, h, w) + q4_bytes(n, 216, h, w) + align_up(36 * 2 * 32 * 4 * sizeof(float), 256);
+        return p4_bytes(n, 32, h, w) + q4_bytes(n, 32, h, w) + q4_bytes(n, 216, h, w) + align_up(36 * 2 * 32 * 4 * sizeof(float), 256);
     return 256;
 }
 
@@ -43,15 +47,16 @@ int crfp_dcnv2_forward_f32(const float* x, const float* offset, const float* mas
     if (cin == 32 && cout == 32 && dg == 8) {
         if (!workspace || workspace_bytes < crfp_dcnv2_workspace_bytes(n, cin, cout, h, w, k, dg)) { set_error("dcnv2: workspace too small"); return CRFP_E_WORKSPACE; }
         char* p = (char*)workspace;
-        float* xq = (float*)p; p += q4_bytes(n, 32, h, w);
+        float* xq = (float*)(p + p4_guard(w)); p += p4_bytes(n, 32, h, w);   // P4: padded planes, guard + pads zeroed below
         float* oq = (float*)p; p += q4_bytes(n, 32, h, w);
         float* om = (float*)p; p += q4_bytes(n, 216, h, w);
         float* wpk = (float*)p;
-        int rc = launch_nchw_to_q4(x, xq, n, 32, h, w, s);
+        if (hipMemsetAsync((char*)xq - p4_guard(w), 0, p4_bytes(n, 32, h, w), s) != hipSuccess) { set_error("dcnv2: memset failed"); return 1; }
+        int rc = launch_nchw_to_q4(x, xq, n, 32, h, w, 1, s);
         if (!rc) rc = launch_offmask_nchw_to_q4(offset, mask, om, n, 144, 72, h, w, s);
         if (!rc) rc = launch_dcn_g8_pack(weight, wpk, s);
-        if (!rc) rc = launch_dcn_g8(xq, 8LL * h * w * 4, om, 54LL * h * w * 4, wpk, bias, oq, 8LL * h * w * 4, n, h, w, s);
-        if (!rc) rc = launch_q4_to_nchw(oq, out, n, 32, h, w, s);
+        if (!rc) rc = launch_dcn_g8(xq, 8LL * (h + 1) * (w + 1) * 4, om, 54LL * h * w * 4, wpk, bias, oq, 8LL * h * w * 4, n, h, w, s);
+        if (!rc) rc = launch_q4_to_nchw(oq, out, n, 32, h, w, 0, s);
         return rc;
     }
     return launch_dcn_generic(x, offset, mask, weight, bias, out, n, cin, cout, h, w, dg, s);

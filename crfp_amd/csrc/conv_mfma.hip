@@ -20,6 +20,7 @@
 #include "crfp_common.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace crfp {
 
@@ -32,7 +33,7 @@ __device__ __forceinline__ float4 load_src_quad(const ConvSrc& s, int n, int kql
     const float* base = s.p + (long long)n * s.bstride;
     switch (s.kind) {
         case SRC_Q4:
-            return *reinterpret_cast<const float4*>(base + (((long long)kql * H + gy) * W + gx) * 4);
+            return *reinterpret_cast<const float4*>(base + (((long long)kql * (H + s.pad) + gy) * (W + s.pad) + gx) * 4);
         case SRC_NCHW: {
             float v[4];
 #pragma unroll
@@ -44,7 +45,7 @@ __device__ __forceinline__ float4 load_src_quad(const ConvSrc& s, int n, int kql
         }
         case SRC_UNSHUF4: {
             const int Qp = kql >> 4, ij = kql & 15, i = ij >> 2, jj = ij & 3;
-            const int H4 = 4 * H, W4 = 4 * W;
+            const int H4 = 4 * H + s.pad, W4 = 4 * W + s.pad;
             return *reinterpret_cast<const float4*>(base + (((long long)Qp * H4 + 4 * gy + i) * W4 + 4 * gx + jj) * 4);
         }
         case SRC_FLOW2: {
@@ -77,10 +78,11 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
     for (int k = 0; k < NIN; ++k) r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     switch (s.kind) {
         case SRC_Q4: {
-            const float* b = base + (long long)kql * H * W * 4;
+            const int PW = W + s.pad;
+            const float* b = base + (long long)kql * (H + s.pad) * PW * 4;
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
-                if (ok[k]) r[k] = *reinterpret_cast<const float4*>(b + ((long long)gy[k] * W + gx[k]) * 4);
+                if (ok[k]) r[k] = *reinterpret_cast<const float4*>(b + ((long long)gy[k] * PW + gx[k]) * 4);
             break;
         }
         case SRC_NCHW: {
@@ -98,7 +100,7 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
         }
         case SRC_UNSHUF4: {
             const int Qp = kql >> 4, ij = kql & 15, i = ij >> 2, jj = ij & 3;
-            const int H4 = 4 * H, W4 = 4 * W;
+            const int H4 = 4 * H + s.pad, W4 = 4 * W + s.pad;
             const float* b = base + (long long)Qp * H4 * W4 * 4;
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
@@ -115,6 +117,81 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
             break;
         }
         default: break;
+    }
+}
+
+// Epilogue shared by the fp32-MFMA and the split-bf16-MFMA main loops (identical C/D lane map):
+// bias, activation, scale, residual, layout-aware store.
+template <int CT, int PT, int RPW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[CT][PT], int n, int T0, int tx0, int ty0,
+                                              int wave, int j, int h) {
+    const int H = a.H, W = a.W;
+    const int nrows = conv_packed_rows(a.cout, a.store, a.ps_r);
+    const int ncq = (nrows + 3) >> 2;
+    const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int y = ty0 + wave * RPW + (pt >> 1), x = tx0 + (pt & 1) * 32 + j;
+        if (y >= H || x >= W) continue;
+        float2 fl = make_float2(0.0f, 0.0f);
+        if (a.store == ST_OFFMASK)
+            fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + ((long long)y * W + x) * 2);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cq = (T0 + ct) * 8 + 2 * g + h;
+                if (cq >= ncq) continue;
+                const float4 bb = bp[cq];
+                float v[4] = {acc[ct][pt][4 * g + 0] + bb.x, acc[ct][pt][4 * g + 1] + bb.y,
+                              acc[ct][pt][4 * g + 2] + bb.z, acc[ct][pt][4 * g + 3] + bb.w};
+                if (a.store == ST_OFFMASK) {
+                    if (cq < a.n_off_quads) {  // (dy,dx) pairs: 10*tanh(.) + flow flipped to (y,x)
+                        v[0] = 10.0f * tanhf(v[0]) + fl.y;
+                        v[1] = 10.0f * tanhf(v[1]) + fl.x;
+                        v[2] = 10.0f * tanhf(v[2]) + fl.y;
+                        v[3] = 10.0f * tanhf(v[3]) + fl.x;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = 1.0f / (1.0f + expf(-v[c]));
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], a.act) * a.post_scale;
+                }
+                if (a.store != ST_PS) {  // zero the padding components of a ragged last quad
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (4 * cq + c >= a.cout) v[c] = 0.0f;
+                }
+                if (a.resid) {
+                    const float4 r = *reinterpret_cast<const float4*>(
+                        a.resid + (long long)n * a.resid_bstride + (((long long)cq * H + y) * W + x) * 4);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                if (a.store == ST_Q4 || a.store == ST_OFFMASK) {
+#pragma unroll
+                    for (int d = 0; d < CRFP_MAX_DST; ++d)
+                        if (d < a.ndst && cq >= a.dst[d].q0 && cq < a.dst[d].q1)
+                            *reinterpret_cast<float4*>(a.dst[d].p + (long long)n * a.dst[d].bstride +
+                                                       (((long long)(cq - a.dst[d].q0) * (H + a.dst[d].pad) + y) *
+                                                            (W + a.dst[d].pad) + x) * 4) =
+                                make_float4(v[0], v[1], v[2], v[3]);
+                } else if (a.store == ST_PS) {
+                    const int r = a.ps_r, r2 = r * r;
+                    const int Q = cq / r2, s = cq - Q * r2, i = s / r, jj = s - i * r;
+                    *reinterpret_cast<float4*>(a.dst[0].p + (long long)n * a.dst[0].bstride +
+                                               (((long long)Q * a.dstH + y * r + i) * a.dstW + x * r + jj) * 4) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else {  // ST_NCHW
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int ch = 4 * cq + c;
+                        if (ch < a.cout)
+                            a.dst[0].p[(long long)n * a.dst[0].bstride + ((long long)ch * H + y) * W + x] = v[c];
+                    }
+                }
+            }
     }
 }
 
@@ -231,73 +308,274 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     }
 #undef CRFP_ISSUE_LOADS
 
-    // ---------------- epilogue: bias, activation, scale, residual, layout-aware store
-    const int nrows = conv_packed_rows(a.cout, a.store, a.ps_r);
-    const int ncq = (nrows + 3) >> 2;
-    const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+    conv_epilogue<CT, PT, RPW>(a, acc, n, T0, tx0, ty0, wave, j, h);
+}
+
+// ================================================================ split-bf16 ("bf16x6") main loop
+// fp32-grade convolution on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA rate):
+// every fp32 operand x is split exactly into three bf16 terms x = x0 + x1 + x2 (x0 = bf16(x),
+// x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); the subtractions are exact in fp32) and the product is
+// accumulated in fp32 as  x0w0 + x0w1 + x1w0 + x0w2 + x2w0 + x1w1 ; the dropped terms are <= 2^-24
+// relative, i.e. below fp32 rounding (measured: max rel. error 1.9e-6 vs 3.1e-6 for a plain fp32
+// matmul at K = 576).  6 bf16 MFMAs replace 8 fp32 MFMAs of 1/16 the rate: 2.67x the throughput of
+// the fp32-MFMA path at the same accuracy.  Weights are split once at pack time; activations are
+// split while the halo tile is staged (global fp32 -> registers -> 3 bf16 images in LDS).
+// K-chunk = 16 channels = 4 quads (lane-half h supplies k = 8h..8h+7 = quads 2h, 2h+1 of the chunk).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16x8(const f32x4& lo, const f32x4& hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const int y = ty0 + wave * RPW + (pt >> 1), x = tx0 + (pt & 1) * 32 + j;
-        if (y >= H || x >= W) continue;
-        float2 fl = make_float2(0.0f, 0.0f);
-        if (a.store == ST_OFFMASK)
-            fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + ((long long)y * W + x) * 2);
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 a = (__bf16)x[i];
+        const float r = x[i] - (float)a;
+        const __bf16 b = (__bf16)r;
+        const float r2 = r - (float)b;
+        p0[i] = a;
+        p1[i] = b;
+        p2[i] = (__bf16)r2;
+    }
+}
+
+__device__ __forceinline__ f32x4 mask_quad(const f32x4& v, int m) {
+    return f32x4{(m & 1) ? v.x : 0.0f, (m & 2) ? v.y : 0.0f, (m & 4) ? v.z : 0.0f, (m & 8) ? v.w : 0.0f};
+}
+
+// one K-quad of NIN halo elements into registers (native vectors, switch hoisted out of the loop)
+template <int NIN>
+__device__ __forceinline__ void load_quad_batch_v(f32x4 (&r)[NIN], const ConvSrc& s, int n, int kql,
+                                                  const int (&gy)[NIN], const int (&gx)[NIN], const bool (&ok)[NIN],
+                                                  int H, int W) {
+    const float* base = s.p + (long long)n * s.bstride;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+    for (int k = 0; k < NIN; ++k) r[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    switch (s.kind) {
+        case SRC_Q4: {
+            const int PW = W + s.pad;
+            const float* b = base + (long long)kql * (H + s.pad) * PW * 4;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cq = (T0 + ct) * 8 + 2 * g + h;
-                if (cq >= ncq) continue;
-                const float4 bb = bp[cq];
-                float v[4] = {acc[ct][pt][4 * g + 0] + bb.x, acc[ct][pt][4 * g + 1] + bb.y,
-                              acc[ct][pt][4 * g + 2] + bb.z, acc[ct][pt][4 * g + 3] + bb.w};
-                if (a.store == ST_OFFMASK) {
-                    if (cq < a.n_off_quads) {  // (dy,dx) pairs: 10*tanh(.) + flow flipped to (y,x)
-                        v[0] = 10.0f * tanhf(v[0]) + fl.y;
-                        v[1] = 10.0f * tanhf(v[1]) + fl.x;
-                        v[2] = 10.0f * tanhf(v[2]) + fl.y;
-                        v[3] = 10.0f * tanhf(v[3]) + fl.x;
-                    } else {
+            for (int k = 0; k < NIN; ++k)
+                if (ok[k]) r[k] = *reinterpret_cast<const f32x4*>(b + ((long long)gy[k] * PW + gx[k]) * 4);
+            break;
+        }
+        case SRC_NCHW: {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = 1.0f / (1.0f + expf(-v[c]));
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], a.act) * a.post_scale;
+            for (int k = 0; k < NIN; ++k)
+                if (ok[k]) {
+                    const long long o = (long long)gy[k] * W + gx[k], pl = (long long)H * W;
+                    const int c0 = 4 * kql;
+                    r[k].x = c0 + 0 < s.nch ? base[(c0 + 0) * pl + o] : 0.0f;
+                    r[k].y = c0 + 1 < s.nch ? base[(c0 + 1) * pl + o] : 0.0f;
+                    r[k].z = c0 + 2 < s.nch ? base[(c0 + 2) * pl + o] : 0.0f;
+                    r[k].w = c0 + 3 < s.nch ? base[(c0 + 3) * pl + o] : 0.0f;
                 }
-                if (a.store != ST_PS) {  // zero the padding components of a ragged last quad
+            break;
+        }
+        case SRC_UNSHUF4: {
+            const int Qp = kql >> 4, ij = kql & 15, i = ij >> 2, jj = ij & 3;
+            const int H4 = 4 * H + s.pad, W4 = 4 * W + s.pad;
+            const float* b = base + (long long)Qp * H4 * W4 * 4;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (4 * cq + c >= a.cout) v[c] = 0.0f;
+            for (int k = 0; k < NIN; ++k)
+                if (ok[k]) r[k] = *reinterpret_cast<const f32x4*>(b + ((long long)(4 * gy[k] + i) * W4 + 4 * gx[k] + jj) * 4);
+            break;
+        }
+        case SRC_FLOW2: {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                if (ok[k]) {
+                    const float2 f = *reinterpret_cast<const float2*>(base + ((long long)gy[k] * W + gx[k]) * 2);
+                    r[k] = f32x4{f.x, f.y, 0.0f, 0.0f};
                 }
-                if (a.resid) {
-                    const float4 r = *reinterpret_cast<const float4*>(
-                        a.resid + (long long)n * a.resid_bstride + (((long long)cq * H + y) * W + x) * 4);
-                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-                }
-                if (a.store == ST_Q4 || a.store == ST_OFFMASK) {
+            break;
+        }
+        default: break;
+    }
+}
+
+template <int CT, int RPW>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a) {
+    constexpr int TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
+    constexpr int NEL = LH * LW;                 // halo pixels
+    constexpr int NIN = (NEL + 255) / 256;       // halo pixels per thread; each carries the chunk's 4 quads
+    __shared__ bf16x8 tile[3][2][NEL];           // [split part][quad pair][halo pixel], 16 B each
+    __shared__ bf16x8 wlds[CT][27 * 64];         // [cout tile][(tap, part)][lane]: this chunk's A fragments
+    constexpr int NWS = (CT * 27 * 64 + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int T0 = blockIdx.y * CT;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+
+    // halo pixels of this thread: clamped coordinates (every load is unconditional and in range; pixels
+    // outside the image are zeroed when the registers are converted, not when they are loaded)
+    int cgy[NIN], cgx[NIN];
+    bool sval[NIN];
 #pragma unroll
-                    for (int d = 0; d < CRFP_MAX_DST; ++d)
-                        if (d < a.ndst && cq >= a.dst[d].q0 && cq < a.dst[d].q1)
-                            *reinterpret_cast<float4*>(a.dst[d].p + (long long)n * a.dst[d].bstride +
-                                                       (((long long)(cq - a.dst[d].q0) * H + y) * W + x) * 4) =
-                                make_float4(v[0], v[1], v[2], v[3]);
-                } else if (a.store == ST_PS) {
-                    const int r = a.ps_r, r2 = r * r;
-                    const int Q = cq / r2, s = cq - Q * r2, i = s / r, jj = s - i * r;
-                    *reinterpret_cast<float4*>(a.dst[0].p + (long long)n * a.dst[0].bstride +
-                                               (((long long)Q * a.dstH + y * r + i) * a.dstW + x * r + jj) * 4) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-                } else {  // ST_NCHW
+    for (int t = 0; t < NIN; ++t) {
+        const int idx = min(tid + 256 * t, NEL - 1);
+        const int r = idx / LW, c = idx - r * LW;
+        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+        sval[t] = tid + 256 * t < NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        cgy[t] = min(max(gy, 0), H - 1);
+        cgx[t] = min(max(gx, 0), W - 1);
+    }
+
+    f32x16 acc[CT][PT];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int ch = 4 * cq + c;
-                        if (ch < a.cout)
-                            a.dst[0].p[(long long)n * a.dst[0].bstride + ((long long)ch * H + y) * W + x] = v[c];
-                    }
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
+
+    const int nchunks = a.kq >> 2;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit);
+    f32x4 rq0[NIN], rq1[NIN], rq2[NIN], rq3[NIN];   // the chunk's 4 quads of each of this thread's halo pixels
+    bf16x8 rws[NWS];   // weights ride in the same prefetch batch: no global load (vmcnt is in-order!) may sit
+                       // inside the MFMA loop, or every tap would wait for the whole input prefetch to land
+
+    // Branch-free issue: each K-quad of the chunk is described by wave-uniform (base, row stride, column
+    // stride, component mask); all source kinds share one load form.  Nothing between issue and the LDS
+    // write touches a loaded register (a use, a zero-init or a copy forces s_waitcnt and serialises the
+    // prefetch behind memory latency -- measured: 5.7k cycles per issue with conditional loads).
+    const float* qb0; const float* qb1; const float* qb2; const float* qb3;
+    int qrs0, qrs1, qrs2, qrs3, qcs0, qcs1, qcs2, qcs3, qm0 = 0, qm1 = 0, qm2 = 0, qm3 = 0;
+#define CRFP_QDESC(QB, QRS, QCS, QM, QI, CH)                                                              \
+    {                                                                                                     \
+        const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
+        QB = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                 \
+    }
+#define CRFP_SPLIT_ISSUE(CH)                                                                              \
+    {                                                                                                     \
+        CRFP_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) CRFP_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                   \
+        CRFP_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) CRFP_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                   \
+        _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                                 \
+            rq0[t] = *reinterpret_cast<const f32x4*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
+            rq1[t] = *reinterpret_cast<const f32x4*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
+            rq2[t] = *reinterpret_cast<const f32x4*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
+            rq3[t] = *reinterpret_cast<const f32x4*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
+        }                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < NWS; ++k) {                                                 \
+            const int idx = min(tid + 256 * k, CT * 1728 - 1);                                            \
+            const int ct = idx / 1728, rem = idx - ct * 1728;                                             \
+            rws[k] = wp[(((long long)(T0 + ct) * nchunks + (CH)) * 27) * 64 + rem];                       \
+        }                                                                                                 \
+    }
+
+    long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
+    CRFP_SPLIT_ISSUE(0)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;  // component masks of the chunk now in registers
+        __syncthreads();  // every wave finished reading the previous chunk
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tA += t - t0; t0 = t; }
+#pragma unroll
+        for (int t = 0; t < NIN; ++t) {
+            const int idx = tid + 256 * t;
+            if (idx < NEL) {
+                bf16x8 p0, p1, p2;
+                split_bf16x8(mask_quad(rq0[t], sval[t] ? m0 : 0), mask_quad(rq1[t], sval[t] ? m1 : 0), p0, p1, p2);
+                tile[0][0][idx] = p0; tile[1][0][idx] = p1; tile[2][0][idx] = p2;
+                split_bf16x8(mask_quad(rq2[t], sval[t] ? m2 : 0), mask_quad(rq3[t], sval[t] ? m3 : 0), p0, p1, p2);
+                tile[0][1][idx] = p0; tile[1][1][idx] = p1; tile[2][1][idx] = p2;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NWS; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < CT * 1728) (&wlds[0][0])[idx] = rws[k];
+        }
+        __syncthreads();
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
+        if (ch + 1 < nchunks) CRFP_SPLIT_ISSUE(ch + 1)
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
+#pragma unroll CRFP_TAP_UNROLL
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            bf16x8 wa[CT][3];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wa[ct][p] = wlds[ct][(tap * 3 + p) * 64 + lane];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int pix = (wave * RPW + (pt >> 1) + ky) * LW + (pt & 1) * 32 + j + kx;
+                const bf16x8 b0 = tile[0][h][pix], b1 = tile[1][h][pix], b2 = tile[2][h][pix];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    f32x16 c = acc[ct][pt];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][1], b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][0], b2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][2], b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][0], b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][1], b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][0], b0, c, 0, 0, 0);
+                    acc[ct][pt] = c;
                 }
             }
+        }
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
     }
+#undef CRFP_SPLIT_ISSUE
+#undef CRFP_QDESC
+    if (a.stamps) {
+        const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t;
+        if (tid == 0) {
+            long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+            o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD;
+        }
+    }
+    conv_epilogue<CT, PT, RPW>(a, acc, n, T0, tx0, ty0, wave, j, h);
+}
+
+// split weight pack: wsplit bf16 index =
+//   (((((T*nchunks + ch)*9 + tap)*3 + part)*64 + lane)*8 + jj),  lane = half*32 + row,
+//   K-quad = 4*ch + 2*half + (jj>>2), component = jj&3
+__global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict__ w, const float* __restrict__ w2,
+                                       int cout_split, __bf16* __restrict__ wsplit) {
+    const int nchunks = a.kq >> 2;
+    const long long total = (long long)a.ctiles * nchunks * 9 * 64 * 8;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int jj = t & 7; t >>= 3;
+        const int lane = t & 63; t >>= 6;
+        const int tap = t % 9; t /= 9;
+        const int ch = t % nchunks;
+        const int T = (int)(t / nchunks);
+        const int row = lane & 31, half = lane >> 5;
+        const int co = conv_row_to_cout(T * 32 + row, a.cout, a.store, a.ps_r);
+        int kql = 4 * ch + 2 * half + (jj >> 2), s = 0;
+        while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
+        int ci = kql < a.src[s].nq ? conv_k_to_cin(a.src[s].kind, a.src[s].nch, kql, jj & 3) : -1;
+        if (ci >= 0) ci += a.src[s].cbase;
+        float val = 0.0f;
+        if (co >= 0 && ci >= 0 && ci < a.cin_total)
+            val = co < cout_split ? w[((long long)co * a.cin_total + ci) * 9 + tap]
+                                  : w2[((long long)(co - cout_split) * a.cin_total + ci) * 9 + tap];
+        const __bf16 p0 = (__bf16)val;
+        const float r = val - (float)p0;
+        const __bf16 p1 = (__bf16)r;
+        const __bf16 p2 = (__bf16)(r - (float)p1);
+        const long long base = (((((long long)T * nchunks + ch) * 9 + tap) * 3) * 64 + lane) * 8 + jj;
+        wsplit[base] = p0;
+        wsplit[base + 64 * 8] = p1;
+        wsplit[base + 2 * 64 * 8] = p2;
+    }
+}
+
+size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 3 * 64 * 16; }
+
+int launch_conv_pack_split(const ConvArgs& a, const float* w, const float* w2, int cout_split, void* wsplit,
+                           hipStream_t s) {
+    if (a.kq & 3) { set_error("conv_pack_split: kq %d not a multiple of 4", a.kq); return CRFP_E_BADARG; }
+    const long long total = (long long)a.ctiles * (a.kq >> 2) * 9 * 64 * 8;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout, (__bf16*)wsplit);
+    CRFP_CHECK_LAUNCH();
+    return 0;
 }
 
 // ---------------------------------------------------------------- weight packing (device side)
@@ -353,15 +631,59 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         return CRFP_E_BADARG;
     }
     static const int max_ct = getenv("CRFP_CONV_CT") ? atoi(getenv("CRFP_CONV_CT")) : 2;  // tuning knob
-    const bool ct2 = a.ctiles % 2 == 0 && max_ct >= 2;
-    const int TH = ct2 ? 4 : 8;
+    bool ct2 = a.ctiles % 2 == 0 && max_ct >= 2;
+    static const bool use_split = !(getenv("CRFP_CONV_MODE") && !strcmp(getenv("CRFP_CONV_MODE"), "f32"));
+    static const int split_rpw = getenv("CRFP_SPLIT_RPW") ? atoi(getenv("CRFP_SPLIT_RPW")) : 1;  // tuning knob
+    bool nchw_src = false;
+    for (int i = 0; i < a.nsrc; ++i) nchw_src |= a.src[i].kind == SRC_NCHW;
+    const bool split = a.wsplit && use_split && (a.kq & 3) == 0 && !nchw_src && a.kq <= CRFP_MAX_KQ;
+    static const int split_ct = getenv("CRFP_SPLIT_CT") ? atoi(getenv("CRFP_SPLIT_CT")) : 1;  // tuning knob
+    if (split && split_ct < 2) ct2 = false;  // <2,1> needs 93 KB of LDS (1 workgroup per CU): slower than 2 x <1,1>
+    const int TH = (ct2 || (split && split_rpw == 1)) ? 4 : 8;
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const double px = (double)a.N * a.H * a.W;
     double in_ch = 0;
     for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].kind == SRC_ZERO ? 0 : a.src[i].nch;
     ProfScope prof(name, s, px * (in_ch + a.cout) * 4.0 + (double)a.cout * in_ch * 9 * 4.0,
                    2.0 * px * a.cout * in_ch * 9.0);
-    if (ct2) {
+    // diagnostic: CRFP_STAMP_PTR=<device address> CRFP_STAMP_NAME=<launch site> records phase cycles per block
+    static const char* stamp_name = getenv("CRFP_STAMP_NAME");
+    static long long* stamp_ptr = getenv("CRFP_STAMP_PTR") ? (long long*)strtoull(getenv("CRFP_STAMP_PTR"), nullptr, 0) : nullptr;
+    ConvArgs& am = const_cast<ConvArgs&>(a);  // callers pass a private, mutable plan copy
+    am.stamps = (stamp_ptr && stamp_name && !strcmp(stamp_name, name)) ? stamp_ptr : nullptr;
+    if (a.kq <= CRFP_MAX_KQ) {  // per-quad load descriptors (wave-uniform in the kernel: one s_load per quad)
+        int q = 0;
+        for (int i = 0; i < a.nsrc; ++i)
+            for (int k = 0; k < a.src[i].nq; ++k, ++q) {
+                const ConvSrc& sr = a.src[i];
+                QuadDesc& d = am.qd[q];
+                d.bstride = sr.bstride; d.rsv = 0;
+                if (sr.kind == SRC_Q4) {
+                    d.rs = (a.W + sr.pad) * 4; d.cs = 4; d.mask = 15;
+                    d.base = sr.p + (long long)k * (a.H + sr.pad) * d.rs;
+                } else if (sr.kind == SRC_UNSHUF4) {
+                    const int W4 = 4 * a.W + sr.pad, ij = k & 15;
+                    d.rs = 16 * W4; d.cs = 16; d.mask = 15;
+                    d.base = sr.p + ((long long)(k >> 4) * (4 * a.H + sr.pad) * W4 + (ij >> 2) * W4 + (ij & 3)) * 4;
+                } else if (sr.kind == SRC_FLOW2) {
+                    d.rs = 2 * a.W; d.cs = 2; d.mask = 3; d.base = sr.p;
+                } else {
+                    d.rs = 0; d.cs = 0; d.mask = 0; d.base = a.wpk; d.bstride = 0;
+                }
+            }
+    }
+    if (split) {
+        if (ct2) {
+            dim3 grid(tiles, a.ctiles / 2, a.N);
+            conv3x3_split_kernel<2, 1><<<grid, 256, 0, s>>>(a);
+        } else if (split_rpw == 1) {
+            dim3 grid(tiles, a.ctiles, a.N);
+            conv3x3_split_kernel<1, 1><<<grid, 256, 0, s>>>(a);
+        } else {
+            dim3 grid(tiles, a.ctiles, a.N);
+            conv3x3_split_kernel<1, 2><<<grid, 256, 0, s>>>(a);
+        }
+    } else if (ct2) {
         dim3 grid(tiles, a.ctiles / 2, a.N);
         conv3x3_mfma_kernel<2, 1><<<grid, 256, 0, s>>>(a);
     } else {

@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256, 4) void conv3x3_narrow_kernel(const NarrowArgs
         int kql = k, s = 0;
         while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
         const ConvSrc src = a.src[s];
-        const float* base = src.p + (long long)n * src.bstride + (src.kind == SRC_FLOW2 ? 0 : (long long)kql * H * W * 4);
+        const int SPW = W + src.pad;
+        const float* base = src.p + (long long)n * src.bstride +
+                            (src.kind == SRC_FLOW2 ? 0 : (long long)kql * (H + src.pad) * SPW * 4);
         f32x4 r[NST];
         // issue every load of this quad before the first LDS write (independent loads in flight together)
 #pragma unroll
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_narrow_kernel(const NarrowArgs
                     const float2 f = *reinterpret_cast<const float2*>(base + ((long long)gy * W + gx) * 2);
                     r[t] = f32x4{f.x, f.y, 0.0f, 0.0f};
                 } else {
-                    r[t] = *reinterpret_cast<const f32x4*>(base + ((long long)gy * W + gx) * 4);
+                    r[t] = *reinterpret_cast<const f32x4*>(base + ((long long)gy * SPW + gx) * 4);
                 }
             }
         }
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_narrow_kernel(const NarrowArgs
         const int y = y0 + 4 * ty + i;
         if (y >= H) break;
         const long long pix = (long long)y * W + x;
+        const long long dpix = (long long)y * (W + a.dst_pad) + x;  // Q4 destination may be padded (P4)
         if (EPI == NE_PLAIN) {
             float v[4];
 #pragma unroll
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_narrow_kernel(const NarrowArgs
                 const float4 r = *reinterpret_cast<const float4*>(a.resid + (long long)n * a.resid_bstride + pix * 4);
                 v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
             }
-            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
         } else if (EPI == NE_BLEND) {
             const float4 centre = tile[0][4 * ty + i + 1][tx + 1];
             const bool m = a.mask[(long long)n * a.mask_bstride + pix] != 0;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_narrow_kernel(const NarrowArgs
                           m ? acc[i][3] : centre.w};
 #pragma unroll
             for (int o = 0; o < 4; ++o) v[o] = v[o] > 0.0f ? v[o] : 0.1f * v[o];
-            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
         } else if (EPI == NE_LAST) {
             const float4 b = *reinterpret_cast<const float4*>(a.base + (long long)n * a.base_bstride + pix * 4);
             float* o = a.dst + (long long)n * a.dst_bstride;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_narrow_kernel(const NarrowArgs
             }
         } else {  // NE_OFFMASK3
             const float2 f = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + pix * 2);
-            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + pix * 4) =
+            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + dpix * 4) =
                 make_float4(10.0f * tanhf(acc[i][0]) + f.y, 10.0f * tanhf(acc[i][1]) + f.x,
                             1.0f / (1.0f + expf(-acc[i][2])), 0.0f);
         }

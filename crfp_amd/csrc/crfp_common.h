@@ -41,21 +41,36 @@ struct ConvSrc {
     int nch;            // reference channels contributed to the concat
     int nq;             // K-quads occupied
     int cbase;          // first reference input channel of this source in the conv weight
+    int pad;            // 1: planes are (H+1) x (W+1) with a zero pad row / column ("P4", gather sources)
+    int rsv;
 };
 
 struct ConvDst {
     float* p;           // first destination plane for cout-quad q0
     long long bstride;
     int q0, q1;         // cout-quad range [q0,q1)
+    int pad, rsv;       // 1: destination planes are (H+1) x (W+1) (pad row/column never written)
 };
 
 #define CRFP_MAX_SRC 5
 #define CRFP_MAX_DST 3
+#define CRFP_MAX_KQ 80   // K-quads per conv the per-quad descriptor table can hold (Cin <= 320)
+
+// per-K-quad load descriptor (filled on the host at launch): element (gy,gx) of the quad is the 16 bytes
+// at base + n*bstride + gy*rs + gx*cs (floats); mask selects the components that really exist
+struct QuadDesc {
+    const float* base;
+    long long bstride;
+    int rs, cs, mask, rsv;
+};
 
 struct ConvArgs {
     ConvSrc src[CRFP_MAX_SRC];
     ConvDst dst[CRFP_MAX_DST];
     const float* wpk;   // packed weights (see pack_index)
+    const void* wsplit; // split-bf16 packed weights (3 bf16 images) or null -> fp32 MFMA path
+    long long* stamps;  // diagnostic builds only: per-block phase cycle sums (null in production)
+    QuadDesc qd[CRFP_MAX_KQ];
     const float* bpk;   // packed bias [ctiles*32]
     const float* resid; // Q4, same cout-quad indexing, added after activation
     const float* flow;  // [H][W][2] for ST_OFFMASK
@@ -146,6 +161,7 @@ struct NarrowArgs {
     int N, H, W;
     int act, epi, y_only;
     float post_scale;
+    int dst_pad, rsv;
 };
 
 // ------------------------------------------------------------------ profiling + errors
@@ -173,14 +189,18 @@ size_t conv_packed_weight_floats(const ConvArgs& a);
 int launch_conv_pack(const ConvArgs& a, const float* w_oihw, const float* bias, const float* w2, const float* bias2,
                      int cout_split, float* wpk, float* bpk, hipStream_t s);
 int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s);
+size_t conv_split_weight_bytes(const ConvArgs& a);
+int launch_conv_pack_split(const ConvArgs& a, const float* w_oihw, const float* w2, int cout_split, void* wsplit,
+                           hipStream_t s);
 // conv_narrow.hip
 size_t narrow_packed_weight_floats(const NarrowArgs& a);
 int launch_narrow_pack(const NarrowArgs& a, const float* w_oihw, const float* bias, const float* w2, const float* bias2,
                        int cout_split, float* wpk, float* bpk, hipStream_t s);
 int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s);
 // gather.hip
+// src_pad = 1: x is P4 (padded planes, zero pads): validity logic replaced by clamping + hardware range check
 int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
-                        int N, int nq, int H, int W, int border, hipStream_t s);
+                        int N, int nq, int H, int W, int border, int src_pad, hipStream_t s);
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
                   const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
 int launch_dcn_g8_pack(const float* w_oihw, float* wpk, hipStream_t s);  // [36][2][32][4]
@@ -189,8 +209,8 @@ int launch_dcn3(const float* x, long long xb, const float* offmask3, long long o
 int launch_dcn_generic(const float* x, const float* offset, const float* mask, const float* w, const float* b,
                        float* out, int N, int cin, int cout, int H, int W, int dg, hipStream_t s);
 // resample.hip
-int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, hipStream_t s);
-int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, hipStream_t s);
+int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s);
+int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s);
 int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
                        int OW, float sh, float sw, float mul, hipStream_t s);
 int launch_upsample_nchw(const float* x, float* out, int N, int C, int H, int W, int OH, int OW, float sh, float sw,

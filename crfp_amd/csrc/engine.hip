@@ -70,6 +70,7 @@ struct Item {
     NarrowArgs nw;
     int w1 = -1, w2 = -1;
     size_t off_w = 0, off_b = 0, n_w = 0, n_b = 0;  // float offsets / counts inside the packed buffer
+    size_t off_s = 0, n_s = 0;                       // split-bf16 weight image (T_MFMA only), in floats
     const char* name = "";
 };
 
@@ -102,13 +103,13 @@ static ConvArgs make_mfma(int y_only, int ci, int ci2, std::vector<SrcSpec> srcs
         kq += d.nq;
     }
     (void)cbase_override;
-    if (kq & 1) {
+    if (kq & 3) {  // K is consumed in chunks of 4 quads (16 channels) by the split-bf16 main loop
         ConvSrc& d = a.src[a.nsrc++];
         d.kind = SRC_ZERO;
-        d.nch = 1;
-        d.nq = 1;
+        d.nq = 4 - (kq & 3);
+        d.nch = d.nq;
         d.cbase = cbase;
-        kq += 1;
+        kq += d.nq;
     }
     a.kq = kq;
     a.cin_total = kConvs[ci].cin;
@@ -159,6 +160,7 @@ struct Model {
         it.c = make_mfma(y_only, ci, ci2, srcs, store, ps_r, act, post_scale);
         it.n_w = conv_packed_weight_floats(it.c);
         it.n_b = (size_t)it.c.ctiles * 32;
+        it.n_s = conv_split_weight_bytes(it.c) / sizeof(float);
     }
     void add_narrow(int id, const char* name, int ci, int ci2, std::vector<SrcSpec> srcs, int act, int epi) {
         Item& it = items[id];
@@ -239,6 +241,8 @@ struct Model {
             cur += (it.n_w + 63) / 64 * 64;
             it.off_b = cur;
             cur += (it.n_b + 63) / 64 * 64;
+            it.off_s = cur;
+            cur += (it.n_s + 63) / 64 * 64;
         }
         total_floats = cur;
     }
@@ -250,16 +254,23 @@ static const Model& model_for(int y_only) {
 }
 
 // ------------------------------------------------------------------ workspace arena
-struct Buf { std::string name; size_t off; int N, nq, H, W, kind; };  // kind 0 = Q4, 1 = NHW2
+struct Buf { std::string name; size_t off; int N, nq, H, W, kind, pad; size_t bytes, guard; };  // kind 0 = Q4, 1 = NHW2
 struct Arena {
     size_t cur = 0;
     std::vector<Buf> bufs;
-    size_t take(const char* name, int N, int nq, int H, int W, int kind = 0) {
-        const size_t floats = kind == 0 ? (size_t)N * nq * H * W * 4 : (size_t)N * H * W * 2;
-        const size_t off = cur;
-        cur += align_up(floats * sizeof(float), 256);
-        bufs.push_back({name, off, N, nq, H, W, kind});
+    // pad = 1: "P4" planes of (H+1) x (W+1) with zero pad row / column (sources of the gather kernels)
+    size_t take(const char* name, int N, int nq, int H, int W, int kind = 0, int pad = 0) {
+        const size_t floats = kind == 0 ? (size_t)N * nq * (H + pad) * (W + pad) * 4 : (size_t)N * H * W * 2;
+        // P4 tensors carry a zeroed guard (>= one pad row + one element) in front of plane 0
+        const size_t guard = pad ? align_up((size_t)(W + 2) * 16, 256) : 0;
+        const size_t off = cur + guard;
+        cur += guard + align_up(floats * sizeof(float), 256);
+        bufs.push_back({name, off, N, nq, H, W, kind, pad, floats * sizeof(float), guard});
         return off;
+    }
+    const Buf* find(size_t off) const {
+        for (auto& b : bufs) if (b.off == off) return &b;
+        return nullptr;
     }
 };
 
@@ -288,8 +299,8 @@ struct Layout {
         const int nb = t > 1 ? t - 1 : 1;
         const int H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         h1 = h / 2; w1 = w / 2; h2 = h1 / 2; w2 = w1 / 2; h3 = h2 / 2; w3 = w2 / 2;
-        state_hr = A.take("state_hr", 1, 1, H8, W8);
-        carry = A.take("carry", 1, 6, H2, W2);
+        state_hr = A.take("state_hr", 1, 1, H8, W8, 0, 1);
+        carry = A.take("carry", 1, 6, H2, W2, 0, 1);
         flow_lr = A.take("flow_lr", nb, 1, h, w);
         e_lr0 = A.take("enc_lr0", t, 8, h, w);
         x_lr = A.take("x_lr", t, 8, h, w);
@@ -320,7 +331,7 @@ struct Layout {
         prop_b = A.take("prop_b", 1, 6, H2, W2);
         flow2 = A.take("flow2", 1, 0, H2, W2, 1);
         flow8 = A.take("flow8", 1, 0, H8, W8, 1);
-        prev2 = A.take("prev2", 1, 8, H2, W2);
+        prev2 = A.take("prev2", 1, 8, H2, W2, 0, 1);
         prev2w = A.take("prev2w", 1, 8, H2, W2);
         prevhrw = A.take("prevhrw", 1, 1, H8, W8);
         carryw = A.take("carryw", 1, 6, H2, W2);
@@ -356,21 +367,25 @@ struct Runner {
     float* F(size_t off) const { return reinterpret_cast<float*>(ws + off); }
     Q4 q(size_t off, int nq, int H, int W) const { Q4 r; r.p = F(off); r.nq = nq; r.H = H; r.W = W; return r; }
 
-    struct SrcBind { const float* p; long long bs; };
-    struct DstBind { float* p; long long bs; int q0, q1; };
+    struct SrcBind { const float* p; long long bs; int pad = 0; };
+    struct DstBind { float* p; long long bs; int q0, q1; int pad = 0; };
 
     void mfma(int id, int N, int H, int W, std::vector<SrcBind> srcs, std::vector<DstBind> dsts, int dstH = 0, int dstW = 0,
               const float* resid = nullptr, long long resid_bs = 0, const float* flow = nullptr, long long flow_bs = 0) {
         if (rc) return;
         const Item& it = M.items[id];
         ConvArgs a = it.c;
-        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i].p; a.src[i].bstride = srcs[i].bs; }
+        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i].p; a.src[i].bstride = srcs[i].bs; a.src[i].pad = srcs[i].pad; }
         a.ndst = (int)dsts.size();
-        for (size_t i = 0; i < dsts.size(); ++i) { a.dst[i].p = dsts[i].p; a.dst[i].bstride = dsts[i].bs; a.dst[i].q0 = dsts[i].q0; a.dst[i].q1 = dsts[i].q1; }
+        for (size_t i = 0; i < dsts.size(); ++i) {
+            a.dst[i].p = dsts[i].p; a.dst[i].bstride = dsts[i].bs; a.dst[i].q0 = dsts[i].q0; a.dst[i].q1 = dsts[i].q1;
+            a.dst[i].pad = dsts[i].pad;
+        }
         a.N = N; a.H = H; a.W = W; a.dstH = dstH; a.dstW = dstW;
         a.resid = resid; a.resid_bstride = resid_bs; a.flow = flow; a.flow_bstride = flow_bs;
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
+        a.wsplit = packed + it.off_s;
         rc = launch_conv_mfma(a, it.name, s);
     }
     // plain Q4 -> Q4 conv on whole tensors
@@ -378,11 +393,14 @@ struct Runner {
         mfma(id, N, in.H, in.W, {{in.p, in.bs()}}, {{out.p, out.bs(), 0, out.nq}});
     }
     void narrow(int id, int H, int W, std::vector<const float*> srcs, float* dst, const float* resid = nullptr,
-                const float* flow = nullptr, const float* base = nullptr, const uint8_t* mask = nullptr) {
+                const float* flow = nullptr, const float* base = nullptr, const uint8_t* mask = nullptr,
+                int src0_pad = 0, int dst_pad = 0) {
         if (rc) return;
         const Item& it = M.items[id];
         NarrowArgs a = it.nw;
-        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i]; a.src[i].bstride = 0; }
+        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i]; a.src[i].bstride = 0; a.src[i].pad = 0; }
+        a.src[0].pad = src0_pad;
+        a.dst_pad = dst_pad;
         a.N = 1; a.H = H; a.W = W;
         a.dst = dst; a.resid = resid; a.flow = flow; a.base = base; a.mask = mask;
         a.wpk = packed + it.off_w;
@@ -425,6 +443,17 @@ struct Runner {
                                (float)g1.W / (float)w, 1.0f, s));
     }
 
+    // zero the P4 buffers (pads must read as 0; also gives the zero initial state)
+    void reset_state() {
+        for (size_t off : {L.state_hr, L.carry, L.prev2}) {
+            const Buf* b = L.A.find(off);
+            if (!rc && hipMemsetAsync(ws + off - b->guard, 0, b->bytes + b->guard, s) != hipSuccess) {
+                set_error("dsv: hipMemsetAsync of recurrent state failed");
+                rc = 1;
+            }
+        }
+    }
+
     void encode_lr(int n, const float* lrs, long long bs) {
         Q4 e0 = q(L.e_lr0, 8, L.h, L.w), x = q(L.x_lr, 8, L.h, L.w);
         mfma(IT_ENC_LR0, n, L.h, L.w, {{lrs, bs}}, {{e0.p, e0.bs(), 0, 8}});
@@ -436,6 +465,7 @@ struct Runner {
                const float* x_lr_i, float* out) {
         const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         const long long P8q = (long long)H8 * W8 * 4, P2q = (long long)H2 * W2 * 4;
+        const long long P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;   // padded (P4) plane at 2x resolution
         RUN(launch_hr_prep(lr, fv, mk, F(L.xin8), h, w, s));
         narrow(IT_EH0, H8, W8, {F(L.xin8), F(L.xin8) + P8q}, F(L.eh));
         narrow(IT_EH1, H8, W8, {F(L.eh)}, F(L.x_hr));
@@ -448,10 +478,10 @@ struct Runner {
             float* flow8 = F(L.flow8);
             RUN(launch_upflow(flow_lr_q4, 0, flow2, 0, 1, h, w, 2, s));
             RUN(launch_upflow(flow_lr_q4, 0, flow8, 0, 1, h, w, 8, s));
-            mfma(IT_DOWN, 1, H2, W2, {{F(L.state_hr), 0}}, {{F(L.prev2), 0, 0, 8}});
-            RUN(launch_flow_warp_q4(F(L.prev2), 0, flow2, 0, F(L.prev2w), 0, 1, 8, H2, W2, 0, s));
-            RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, s));
-            RUN(launch_flow_warp_q4(carry, 0, flow2, 0, F(L.carryw), 0, 1, 6, H2, W2, 0, s));
+            mfma(IT_DOWN, 1, H2, W2, {{F(L.state_hr), 0, 1}}, {{F(L.prev2), 0, 0, 8, 1}});
+            RUN(launch_flow_warp_q4(F(L.prev2), 0, flow2, 0, F(L.prev2w), 0, 1, 8, H2, W2, 0, 1, s));
+            RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, 1, s));
+            RUN(launch_flow_warp_q4(carry, 0, flow2, 0, F(L.carryw), 0, 1, 6, H2, W2, 0, 1, s));
             const float* offprev = nullptr;
             for (int l = 0; l < 3; ++l) {
                 const float* cw = F(L.carryw) + 2 * l * P2q;
@@ -470,7 +500,7 @@ struct Runner {
                                   1, H2, W2, s));
                 mfma(it_lvl(l, L_RB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.aligned), 0}}, {{F(L.y0), 0, 0, 8}});
                 mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
-                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2q, 0, 6, 8}}, 0, 0,
+                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2qp, 0, 6, 8, 1}}, 0, 0,
                      F(L.y0), 0);
                 std::swap(prop, prop_next);
                 offprev = f;
@@ -488,7 +518,7 @@ struct Runner {
             for (int l = 0; l < 3; ++l) {
                 mfma(it_lvl(l, L_RB0F), 1, H2, W2, {{prop, 0}, {nullptr, 0}}, {{F(L.y0), 0, 0, 8}});
                 mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
-                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2q, 0, 6, 8}}, 0, 0,
+                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2qp, 0, 6, 8, 1}}, 0, 0,
                      F(L.y0), 0);
                 std::swap(prop, prop_next);
             }
@@ -497,8 +527,8 @@ struct Runner {
         }
         narrow(IT_R3_1, H8, W8, {F(L.z0)}, F(L.z1));
         narrow(IT_R3_2, H8, W8, {F(L.z1)}, F(L.feat), F(L.z0));
-        narrow(IT_TTTF, H8, W8, {F(L.feat), F(L.x_hr)}, F(L.state_hr), nullptr, nullptr, nullptr, mk);
-        narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, F(L.xin8) + P8q);
+        narrow(IT_TTTF, H8, W8, {F(L.feat), F(L.x_hr)}, F(L.state_hr), nullptr, nullptr, nullptr, mk, 0, 1);
+        narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, F(L.xin8) + P8q, nullptr, 1, 0);
     }
 };
 
@@ -541,7 +571,10 @@ int crfp_dsv_pack_weights(const float* const* params, int y_only, void* packed, 
         const int split = conv_cout(it.w1, y_only);
         int rc = 0;
         switch (it.type) {
-            case T_MFMA: rc = launch_conv_pack(it.c, w, b, w2, b2, split, pk + it.off_w, pk + it.off_b, s); break;
+            case T_MFMA:
+                rc = launch_conv_pack(it.c, w, b, w2, b2, split, pk + it.off_w, pk + it.off_b, s);
+                if (!rc) rc = launch_conv_pack_split(it.c, w, w2, split, pk + it.off_s, s);
+                break;
             case T_NARROW: rc = launch_narrow_pack(it.nw, w, b, w2, b2, split, pk + it.off_w, pk + it.off_b, s); break;
             case T_DCN8:
                 rc = launch_dcn_g8_pack(w, pk + it.off_w, s);
@@ -578,6 +611,7 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
     Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     const long long lr_f = 3LL * h * w, hr_px = 64LL * h * w;
     const int co = y_only ? 1 : 3;
+    R.reset_state();
     if (t > 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
     R.encode_lr(t, lrs, lr_f);
     const long long xq = 8LL * h * w * 4, fq = 1LL * h * w * 4;
@@ -595,6 +629,7 @@ int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const
     if (rc) return rc;
     if (!lr || !fv || !mk || !out || (!first && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    if (first) R.reset_state();
     if (!first) R.fnet(1, lr, 0, lr_prev, 0);
     R.encode_lr(1, lr, 0);
     R.frame(first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr), out);
@@ -609,7 +644,7 @@ int crfp_fnet_forward(const void* packed, const float* cur, const float* prev, f
     if (!cur || !prev || !flow) { set_error("fnet_forward: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(0), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.fnet(n, cur, 3LL * h * w, prev, 3LL * h * w);
-    if (!R.rc) R.rc = launch_q4_to_nchw(R.F(L.flow_lr), flow, n, 2, h, w, (hipStream_t)stream);
+    if (!R.rc) R.rc = launch_q4_to_nchw(R.F(L.flow_lr), flow, n, 2, h, w, 0, (hipStream_t)stream);
     return R.rc;
 }
 
@@ -624,7 +659,7 @@ int crfp_dsv_debug_fetch(const char* name, int t, int h, int w, const void* work
             if (h_out) *h_out = b.H;
             if (w_out) *w_out = b.W;
             if (!out_nchw) return b.N;
-            if (b.kind == 0) return launch_q4_to_nchw(p, out_nchw, b.N, b.nq * 4, b.H, b.W, (hipStream_t)stream);
+            if (b.kind == 0) return launch_q4_to_nchw(p, out_nchw, b.N, b.nq * 4, b.H, b.W, b.pad, (hipStream_t)stream);
             return hipMemcpyAsync(out_nchw, p, (size_t)b.N * b.H * b.W * 2 * sizeof(float), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream) == hipSuccess ? 0 : 1;
         }

@@ -8,6 +8,8 @@
 // 1-KiB row segments that the CU's L1 serves 3 times out of 4; HBM sees each input line once.
 #include "crfp_common.h"
 
+#include <cstdlib>
+
 namespace crfp {
 
 // ---------------------------------------------------------------- flow_warp
@@ -66,13 +68,68 @@ __global__ __launch_bounds__(256) void flow_warp_q4_kernel(const float* __restri
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- P4 sources ("padded Q4"): planes are (H+1) x (W+1) with a zero pad row (y == H) and a zero pad
+// column (x == W).  With the sample position clamped to [-1, size] every one of the 4 bilinear
+// corners either hits real data, a zero pad element (x == -1 is the pad column of the previous row,
+// y == -1 the pad row of the previous plane) or falls outside the buffer, where the hardware range
+// check of a raw buffer load returns 0.  No per-corner validity logic and no 64-bit address math is
+// left on the VALU: one 32-bit byte offset per sample, the other three corners ride on the scalar
+// offset operand (+16, +pitch, +pitch+16).
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restrict__ x, long long xb,
+                                                           const float* __restrict__ flow, long long fb,
+                                                           float* __restrict__ out, long long ob, int nq, int H,
+                                                           int W) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (px >= W || py >= H) return;
+    const long long pix = (long long)py * W + px;
+    const float2 f = *reinterpret_cast<const float2*>(flow + (long long)n * fb + pix * 2);
+    const float dw = (float)(W - 1 > 1 ? W - 1 : 1), dh = (float)(H - 1 > 1 ? H - 1 : 1);
+    const float gx = 2.0f * ((float)px + f.x) / dw - 1.0f;
+    const float gy = 2.0f * ((float)py + f.y) / dh - 1.0f;
+    float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f);
+    float iy = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+    ix = fminf(fmaxf(ix, -1.0f), (float)W);
+    iy = fminf(fmaxf(iy, -1.0f), (float)H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float lx = ix - fx, ly = iy - fy, hx = 1.0f - lx, hy = 1.0f - ly;
+    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
+    // the descriptor starts one pad row + one element BEFORE plane 0 (zeroed guard that every P4
+    // allocation carries) so that (y0,x0) = (-1,-1) is still a non-negative offset
+    const int guard = pitch + 16;
+    const int voff = ((int)fy * PW + (int)fx) * 16 + guard;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + (long long)n * xb) - (guard >> 2), 0, nq * plane_b + guard, 0x00020000);
+    float* os = out + (long long)n * ob + pix * 4;
+    const long long oplane = (long long)H * W * 4;
+    for (int q = 0; q < nq; ++q) {
+        const int vo = voff + q * plane_b;
+        const f32x4 a = bload(r, vo, 0), b = bload(r, vo, 16), c = bload(r, vo, pitch), d = bload(r, vo, pitch + 16);
+        *reinterpret_cast<f32x4*>(os + q * oplane) = a * w00 + b * w01 + c * w10 + d * w11;
+    }
+}
+
 int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
-                        int N, int nq, int H, int W, int border, hipStream_t s) {
+                        int N, int nq, int H, int W, int border, int src_pad, hipStream_t s) {
     const double px = (double)N * H * W;
     ProfScope prof(nq == 1 ? "flow_warp_q4_c4" : (nq == 8 ? "flow_warp_q4_c32" : "flow_warp_q4_c24"), s,
                    px * (2.0 * nq * 4 + 2) * 4.0, px * nq * 4 * 7.0);
     dim3 grid((W + 63) / 64, (H + 3) / 4, N);
-    if (border)
+    if (src_pad && !border)
+        flow_warp_p4_kernel<<<grid, 256, 0, s>>>(x, xb, flow, fb, out, ob, nq, H, W);
+    else if (src_pad) {
+        set_error("flow_warp: border padding on a P4 source is not implemented");
+        return CRFP_E_UNSUPPORTED;
+    } else if (border)
         flow_warp_q4_kernel<1><<<grid, 256, 0, s>>>(x, xb, flow, fb, out, ob, nq, H, W);
     else
         flow_warp_q4_kernel<0><<<grid, 256, 0, s>>>(x, xb, flow, fb, out, ob, nq, H, W);
@@ -130,11 +187,19 @@ __device__ __forceinline__ float4 sample_quad(const float* __restrict__ plane, c
 // positions 4v..4v+3.  One wave = 32 pixels of a row; lane (pixel, half) samples the 36 positions of
 // groups 4*half..4*half+3 and feeds each sampled quad straight into 4 fp32 MFMAs as the B operand
 // (K index = (group, tap, channel)); the im2col matrix never exists in memory.
-__global__ __launch_bounds__(256) void dcn_g8_kernel(const float* __restrict__ x, long long xb,
-                                                     const float* __restrict__ offmask, long long omb,
-                                                     const float* __restrict__ wpk, const float* __restrict__ bias,
-                                                     float* __restrict__ out, long long ob, int H, int W) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// x is P4 (see above).  VALU budget per sampling position: position (2), clamp (4), floor/frac (6),
+// modulated bilinear weights (6), byte offset (4), 16 FMAs for the 4-channel sample.
+__global__ __launch_bounds__(256, 3) void dcn_g8_kernel(const float* __restrict__ x, long long xb,
+                                                        const float* __restrict__ offmask, long long omb,
+                                                        const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                        float* __restrict__ out, long long ob, int H, int W, int dbg) {
+    // packed DCN weights (36 KB) are shared by the 4 waves of the workgroup through LDS
+    __shared__ f32x4 wl[36 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!(dbg & 32))
+        for (int i = tid; i < 36 * 64; i += 256) wl[i] = reinterpret_cast<const f32x4*>(wpk)[i];
     const int j = lane & 31, h = lane >> 5;
     const int px = blockIdx.x * 32 + j, py = blockIdx.y * 4 + wave;
     const int n = blockIdx.z;
@@ -142,35 +207,72 @@ __global__ __launch_bounds__(256) void dcn_g8_kernel(const float* __restrict__ x
     const int cx = min(px, W - 1), cy = min(py, H - 1);
     const long long plane = (long long)H * W * 4;
     const float* om = offmask + (long long)n * omb + ((long long)cy * W + cx) * 4;
-    const float* xs = x + (long long)n * xb;
-    const float4* __restrict__ wp = reinterpret_cast<const float4*>(wpk);
+    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
+    const int guard = pitch + 16;  // zeroed guard in front of plane 0 (see flow_warp_p4_kernel)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + (long long)n * xb) - (guard >> 2), 0, 8 * plane_b + guard, 0x00020000);
+    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
+    const int hbase = 4 * h * plane_b + guard;
 
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 
-#pragma unroll
-    for (int v = 0; v < 9; ++v) {
-        const float4 m4 = *reinterpret_cast<const float4*>(om + (36 + 9 * h + v) * plane);
-        const float4 oa = *reinterpret_cast<const float4*>(om + (18 * h + 2 * v) * plane);
-        const float4 ob4 = *reinterpret_cast<const float4*>(om + (18 * h + 2 * v + 1) * plane);
+    // software pipeline: the (dy,dx) pairs and masks of iteration v+1 are in flight while the 16 corner
+    // loads of iteration v (4 sampling positions x 4 corners, issued back to back) are consumed
+    f32x4 m4 = ldg4(om + (36 + 9 * h) * plane);
+    f32x4 oa = ldg4(om + (18 * h) * plane);
+    f32x4 ob4 = ldg4(om + (18 * h + 1) * plane);
+    __syncthreads();
+#pragma unroll 1
+    for (int v = 0; v < ((dbg & 16) ? 1 : 9); ++v) {
         const float dy[4] = {oa.x, oa.z, ob4.x, ob4.z};
         const float dx[4] = {oa.y, oa.w, ob4.y, ob4.w};
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        if (v < 8 && !(dbg & 4)) {
+            m4 = ldg4(om + (36 + 9 * h + v + 1) * plane);
+            oa = ldg4(om + (18 * h + 2 * v + 2) * plane);
+            ob4 = ldg4(om + (18 * h + 2 * v + 3) * plane);
+        }
+        float w00[4], w01[4], w10[4], w11[4];
+        f32x4 q00[4], q01[4], q10[4], q11[4];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            const int p36 = 4 * v + pp, gi = p36 / 9, tap = p36 % 9, ky = tap / 3, kx = tap % 3;
-            const int g = 4 * h + gi;
-            const float sy = (float)(cy - 1 + ky) + dy[pp];
-            const float sx = (float)(cx - 1 + kx) + dx[pp];
-            const Corner4 c = dcn_corners(sy, sx, H, W);
-            float4 val = sample_quad(xs + g * plane, c);
-            const float m = mm[pp];
-            const float4 wa = wp[p36 * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, val.x * m, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, val.y * m, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, val.z * m, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, val.w * m, acc, 0, 0, 0);
+            const int p36 = 4 * v + pp, gi = p36 / 9, tap = p36 - 9 * gi, ky = tap / 3, kx = tap - 3 * ky;
+            // (float)(cy-1) + (float)ky is exact, so this equals the reference's (float)(y - pad + ky) + dy
+            float sy = (fy0 + (float)ky) + dy[pp];
+            float sx = (fx0 + (float)kx) + dx[pp];
+            sy = fminf(fmaxf(sy, -1.0f), fH);
+            sx = fminf(fmaxf(sx, -1.0f), fW);
+            const float fy = floorf(sy), fx = floorf(sx);
+            const float ly = sy - fy, lx = sx - fx;
+            const float a = (1.0f - ly) * mm[pp], b = ly * mm[pp], hx = 1.0f - lx;
+            w00[pp] = a * hx; w01[pp] = a * lx; w10[pp] = b * hx; w11[pp] = b * lx;
+            const int vo = ((int)fy * PW + (int)fx) * 16 + hbase + gi * plane_b;
+            if (dbg & 2) {
+                q00[pp] = q01[pp] = q10[pp] = q11[pp] = f32x4{sy, sx, (float)vo, 2.0f};
+            } else {
+                q00[pp] = bload(rx, vo, 0);
+                q01[pp] = bload(rx, vo, 16);
+                q10[pp] = bload(rx, vo, pitch);
+                q11[pp] = bload(rx, vo, pitch + 16);
+            }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            f32x4 val = q00[pp] * w00[pp];
+            val = __builtin_elementwise_fma(q01[pp], f32x4{w01[pp], w01[pp], w01[pp], w01[pp]}, val);
+            val = __builtin_elementwise_fma(q10[pp], f32x4{w10[pp], w10[pp], w10[pp], w10[pp]}, val);
+            val = __builtin_elementwise_fma(q11[pp], f32x4{w11[pp], w11[pp], w11[pp], w11[pp]}, val);
+            const f32x4 wa = (dbg & 8) ? f32x4{1.0f, 2.0f, 3.0f, (float)lane} : wl[(4 * v + pp) * 64 + lane];
+            if (dbg & 1) {
+                acc[pp] += wa.x * val.x + wa.y * val.y + wa.z * val.z + wa.w * val.w;
+                continue;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, val.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, val.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, val.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, val.w, acc, 0, 0, 0);
         }
     }
     if (!valid) return;
@@ -204,7 +306,8 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * (32 + 144 + 72 + 32) * 4.0 + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
     dim3 grid((W + 31) / 32, (H + 3) / 4, N);
-    dcn_g8_kernel<<<grid, 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
+    static const int dbg = getenv("CRFP_DCN_DBG") ? atoi(getenv("CRFP_DCN_DBG")) : 0;  // ablation switch (timing only)
+    dcn_g8_kernel<<<grid, 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, dbg);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -223,14 +326,25 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
     if (px >= W || py >= H) return;
     const long long pix = (long long)py * W + px;
     const float4 om = *reinterpret_cast<const float4*>(offmask3 + (long long)n * omb + pix * 4);
-    const float* xs = x + (long long)n * xb;
+    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
+    const int guard = pitch + 16;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + (long long)n * xb) - (guard >> 2), 0, plane_b + guard, 0x00020000);
+    const float fy0 = (float)(py - 1), fx0 = (float)(px - 1), fH = (float)H, fW = (float)W;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        const float sy = (float)(py - 1 + tap / 3) + om.x;
-        const float sx = (float)(px - 1 + tap % 3) + om.y;
-        const Corner4 c = dcn_corners(sy, sx, H, W);
-        const float4 v = sample_quad(xs, c);
+        // per-tap coordinates exactly as the reference forms them ((float)(y-1+ky) + dy), no sharing of
+        // the fractional part between taps
+        float sy = (fy0 + (float)(tap / 3)) + om.x;
+        float sx = (fx0 + (float)(tap % 3)) + om.y;
+        sy = fminf(fmaxf(sy, -1.0f), fH);
+        sx = fminf(fmaxf(sx, -1.0f), fW);
+        const float fy = floorf(sy), fx = floorf(sx);
+        const float ly = sy - fy, lx = sx - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+        const int vo = ((int)fy * PW + (int)fx) * 16 + guard;
+        const f32x4 a = bload(rx, vo, 0), b = bload(rx, vo, 16), c = bload(rx, vo, pitch), d = bload(rx, vo, pitch + 16);
+        const f32x4 v = a * (hy * hx) + b * (hy * lx) + c * (ly * hx) + d * (ly * lx);
 #pragma unroll
         for (int o = 0; o < 4; ++o)
             acc[o] = fmaf(w[(o * 4 + 3) * 9 + tap], v.w,

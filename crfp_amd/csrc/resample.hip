@@ -19,8 +19,9 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
     l0 = 1.0f - l1;
 }
 
-__global__ void nchw_to_q4_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W) {
-    const long long HW = (long long)H * W;
+// pad = 1: destination / source planes are (H+1) x (W+1) ("P4"); pads are not touched here
+__global__ void nchw_to_q4_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W, int pad) {
+    const long long HW = (long long)H * W, PHW = (long long)(H + pad) * (W + pad);
     const int nq = (C + 3) / 4;
     const long long total = (long long)nq * HW;
     const int n = blockIdx.y;
@@ -28,15 +29,17 @@ __global__ void nchw_to_q4_kernel(const float* __restrict__ x, float* __restrict
          idx += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(idx / HW);
         const long long pix = idx - (long long)q * HW;
+        const long long y = pix / W, xx = pix - y * W;
         float v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = 4 * q + c < C ? x[((long long)n * C + 4 * q + c) * HW + pix] : 0.0f;
-        *reinterpret_cast<float4*>(out + ((long long)n * nq * HW + idx) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(out + (((long long)n * nq + q) * PHW + y * (W + pad) + xx) * 4) =
+            make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
-__global__ void q4_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W) {
-    const long long HW = (long long)H * W;
+__global__ void q4_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W, int pad) {
+    const long long HW = (long long)H * W, PHW = (long long)(H + pad) * (W + pad);
     const int nq = (C + 3) / 4;
     const long long total = (long long)nq * HW;
     const int n = blockIdx.y;
@@ -44,7 +47,8 @@ __global__ void q4_to_nchw_kernel(const float* __restrict__ x, float* __restrict
          idx += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(idx / HW);
         const long long pix = idx - (long long)q * HW;
-        const float4 v = *reinterpret_cast<const float4*>(x + ((long long)n * nq * HW + idx) * 4);
+        const long long y = pix / W, xx = pix - y * W;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((long long)n * nq + q) * PHW + y * (W + pad) + xx) * 4);
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -57,18 +61,18 @@ static inline int grid_for(long long total) {
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, hipStream_t s) {
+int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s) {
     const long long total = (long long)((C + 3) / 4) * H * W;
     ProfScope prof("nchw_to_q4", s, (double)N * H * W * (C + 4.0 * ((C + 3) / 4)) * 4.0, 0);
-    nchw_to_q4_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, out, C, H, W);
+    nchw_to_q4_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, out, C, H, W, pad);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
-int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, hipStream_t s) {
+int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s) {
     const long long total = (long long)((C + 3) / 4) * H * W;
     ProfScope prof("q4_to_nchw", s, (double)N * H * W * (C + 4.0 * ((C + 3) / 4)) * 4.0, 0);
-    q4_to_nchw_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, out, C, H, W);
+    q4_to_nchw_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, out, C, H, W, pad);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
