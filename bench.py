@@ -34,14 +34,39 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+# The wide convs run as 6 bf16 MFMA products per algorithmic fp32 MAC (split-bf16, fp32-grade result),
+# so their algorithmic-flop ceiling is the bf16 peak / 6.
+SPLIT_BF16_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
 def kernel_family(name: str) -> str:
     if name.startswith("conv_mfma"):
-        return "conv3x3_mfma_f32"
+        return "conv3x3_mfma"
     if name.startswith("conv_narrow"):
         return "conv3x3_narrow"
     return name
+
+
+# hipEvent launch-site family -> rocprofv3 kernel names (for the PMC traffic lookup)
+ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_mfma_kernel"), "conv3x3_narrow": ("conv3x3_narrow_kernel",),
+                 "dcnv2_g8_c32": ("dcn_g8_kernel",), "dcnv2_shared_c4": ("dcn3_kernel",),
+                 "flow_warp_q4_c4": ("flow_warp_p4_kernel",), "flow_warp_q4_c32": ("flow_warp_p4_kernel",),
+                 "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "hr_prep_up8_blend": ("hr_prep_kernel",)}
+
+
+def pmc_traffic(family: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE, per
+    MI355X_MICROARCH.md), averaged over the family's kernels; None when no summary is present."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary_latest.json")
+    if not os.path.exists(path) or family not in ROCPROF_NAMES:
+        return None
+    tot = calls = 0.0
+    for r in json.load(open(path)):
+        if any(r["kernel"].startswith(n) for n in ROCPROF_NAMES[family]) and r.get("hbm_MB_per_launch_corrected") is not None:
+            tot += r["hbm_MB_per_launch_corrected"] * 1e6 * r["calls"]
+            calls += r["calls"]
+    return tot / calls if calls else None
 
 
 def main():
@@ -152,14 +177,19 @@ def main():
         result["kernel_ms_per_clip"] = total_ms / psteps
         dom = table[0]
         domf = fam[dom["kernel"]]
-        if dom["kernel"] == "conv3x3_mfma_f32":
+        if dom["kernel"] == "conv3x3_mfma":
+            f32_mode = os.environ.get("CRFP_CONV_MODE") == "f32"
+            peak = F32_MFMA_PEAK_TFLOPS if f32_mode else SPLIT_BF16_EQUIV_PEAK_TFLOPS
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["TFLOPs"],
-                                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                                  "traffic": None, "avg_launch_us": dom["avg_us"],
-                                  "algorithmic_flops_per_launch": domf["flops"] / domf["launches"]}
+                                  "peak": peak, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / peak,
+                                  "traffic": pmc_traffic(dom["kernel"]), "avg_launch_us": dom["avg_us"],
+                                  "algorithmic_flops_per_launch": domf["flops"] / domf["launches"],
+                                  "frac_of_fp32_mfma_peak": dom["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
+                                  "note": "algorithmic fp32 flops; executed as 6 bf16 MFMA products per MAC (split-bf16), "
+                                          "so peak = 2.5 PF dense bf16 / 6" if not f32_mode else "fp32 MFMA"}
         else:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                                  "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"]),
                                   "avg_launch_us": dom["avg_us"],
                                   "algorithmic_bytes_per_launch": domf["bytes"] / domf["launches"]}
         gat = [f for n, f in fam.items() if n.startswith("flow_warp") or n.startswith("dcnv2")]
@@ -167,7 +197,8 @@ def main():
             gb = sum(f["bytes"] for f in gat); gs = sum(f["ms"] for f in gat) * 1e-3
             result["warp_dcn"] = {"bound": "hbm", "achieved": gb / gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": gb / gs / 1e9 / HBM_PEAK_GBS, "frac_of_copy_ceiling": gb / gs / 1e9 / HBM_COPY_CEILING_GBS,
-                                  "ms_per_clip": 1e3 * gs / psteps, "traffic": None,
+                                  "ms_per_clip": 1e3 * gs / psteps,
+                                  "traffic": {n: pmc_traffic(n) for n in fam if n.startswith("flow_warp") or n.startswith("dcnv2")},
                                   "note": "dcn_3 priced at its compact 2+1 offset/mask channels (162.2 MB/frame), "
                                           "not the 9x-replicated API tensors (516.1 MB/frame)"}
 

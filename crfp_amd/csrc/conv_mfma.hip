@@ -470,7 +470,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
     for (int ch = 0; ch < nchunks; ++ch) {
         const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;  // component masks of the chunk now in registers
         __syncthreads();  // every wave finished reading the previous chunk
-        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tA += t - t0; t0 = t; }
+        if (a.stamps) {
+            long long t = __builtin_amdgcn_s_memtime(); tA += t - t0; t0 = t;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t;   // diagnostic: load-landing wait booked under C
+        }
 #pragma unroll
         for (int t = 0; t < NIN; ++t) {
             const int idx = tid + 256 * t;
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
         __syncthreads();
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
         if (ch + 1 < nchunks) CRFP_SPLIT_ISSUE(ch + 1)
-        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }  // diagnostic: issue booked under D
 #pragma unroll CRFP_TAP_UNROLL
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of tools/collect_profiles.sh: per-kernel calls, avg duration and HBM bytes per
+launch from the FETCH_SIZE / WRITE_SIZE passes.  MI355X_MICROARCH.md: the counters are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced stream -> x2 (both raw and corrected are
+printed); WRITE_SIZE is exact for 16-B-per-lane stores."""
+import csv, glob, json, os, sys, collections, re
+
+out = sys.argv[1]
+
+def short(n):
+    n = re.sub(r"\(.*", "", n).replace("void ", "").replace("crfp::", "")
+    return n[:60]
+
+stats = {}
+for f in glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+
+def pmc(sub, counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(out, sub, "*", "*counter_collection.csv")):
+        per = collections.defaultdict(float)
+        name = {}
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+                name[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+        for d, v in per.items():
+            agg[name[d]][0] += v
+            agg[name[d]][1] += 1
+    return {k: v[0] / v[1] for k, v in agg.items() if v[1]}
+
+fetch = pmc("fetch", "FETCH_SIZE")
+write = pmc("write", "WRITE_SIZE")
+rows = []
+for k, (calls, avg_us, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
+    fk, wk = fetch.get(k), write.get(k)
+    rows.append({"kernel": k, "calls": calls, "avg_us": avg_us, "pct": pct,
+                 "fetch_KiB_raw": fk, "write_KiB": wk,
+                 "hbm_MB_per_launch_corrected": None if fk is None or wk is None else (2 * fk + wk) * 1024 / 1e6})
+print(f"{'kernel':60s} {'calls':>6s} {'avg us':>9s} {'%':>6s} {'FETCH KiB':>11s} {'WRITE KiB':>11s} {'HBM MB/launch (2*F+W)':>22s}")
+for r in rows[:30]:
+    f = "-" if r["fetch_KiB_raw"] is None else f"{r['fetch_KiB_raw']:.0f}"
+    w = "-" if r["write_KiB"] is None else f"{r['write_KiB']:.0f}"
+    h = "-" if r["hbm_MB_per_launch_corrected"] is None else f"{r['hbm_MB_per_launch_corrected']:.1f}"
+    print(f"{r['kernel']:60s} {r['calls']:6d} {r['avg_us']:9.1f} {r['pct']:6.2f} {f:>11s} {w:>11s} {h:>22s}")
+json.dump(rows, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
