@@ -57,12 +57,22 @@ __device__ __forceinline__ float4 load_src_quad(const ConvSrc& s, int n, int kql
     }
 }
 
+// tanh / sigmoid on the hardware exp2 + rcp (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of the libm
+// versions (~30 VALU instructions each): the 216-channel offset/mask epilogue is transcendental-bound
+// otherwise.  |error| < 3e-7 absolute on both, i.e. < 3e-6 px on the +-10 px DCN offsets.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) {
+    const float e = __expf(-2.0f * fabsf(v));          // in (0, 1]: no overflow
+    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    return copysignf(t, v);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case CRFP_ACT_RELU: return fmaxf(v, 0.0f);
         case CRFP_ACT_LRELU01: return v > 0.0f ? v : 0.1f * v;
-        case CRFP_ACT_TANH: return tanhf(v);
-        case CRFP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case CRFP_ACT_TANH: return fast_tanh(v);
+        case CRFP_ACT_SIGMOID: return fast_sigmoid(v);
         default: return v;
     }
 }
@@ -122,9 +132,13 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
 
 // Epilogue shared by the fp32-MFMA and the split-bf16-MFMA main loops (identical C/D lane map):
 // bias, activation, scale, residual, layout-aware store.
+// flpre: flow vectors of this lane's PT pixels preloaded by the caller (ST_OFFMASK), or null.  Inside a
+// loop over cout tiles a vector load here would force s_waitcnt vmcnt(0), i.e. drain every store of the
+// previous tile's epilogue (vmcnt is in-order and counts stores on CDNA4): 12k cycles per tile measured.
+// For the same reason the bias comes through wave-uniform (scalar) loads, selected per lane half.
 template <int CT, int PT, int RPW>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[CT][PT], int n, int T0, int tx0, int ty0,
-                                              int wave, int j, int h) {
+                                              int wave, int j, int h, const float2* flpre = nullptr) {
     const int H = a.H, W = a.W;
     const int nrows = conv_packed_rows(a.cout, a.store, a.ps_r);
     const int ncq = (nrows + 3) >> 2;
@@ -135,25 +149,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
         if (y >= H || x >= W) continue;
         float2 fl = make_float2(0.0f, 0.0f);
         if (a.store == ST_OFFMASK)
-            fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + ((long long)y * W + x) * 2);
+            fl = flpre ? flpre[pt]
+                       : *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + ((long long)y * W + x) * 2);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cq = (T0 + ct) * 8 + 2 * g + h;
+                const int cq0 = (T0 + ct) * 8 + 2 * g;      // wave-uniform: both halves' bias rows via s_load
+                const int cq = cq0 + h;
                 if (cq >= ncq) continue;
-                const float4 bb = bp[cq];
+                const float4 bb0 = bp[cq0], bb1 = bp[cq0 + 1];
+                const float4 bb = h ? bb1 : bb0;
                 float v[4] = {acc[ct][pt][4 * g + 0] + bb.x, acc[ct][pt][4 * g + 1] + bb.y,
                               acc[ct][pt][4 * g + 2] + bb.z, acc[ct][pt][4 * g + 3] + bb.w};
                 if (a.store == ST_OFFMASK) {
                     if (cq < a.n_off_quads) {  // (dy,dx) pairs: 10*tanh(.) + flow flipped to (y,x)
-                        v[0] = 10.0f * tanhf(v[0]) + fl.y;
-                        v[1] = 10.0f * tanhf(v[1]) + fl.x;
-                        v[2] = 10.0f * tanhf(v[2]) + fl.y;
-                        v[3] = 10.0f * tanhf(v[3]) + fl.x;
+                        v[0] = 10.0f * fast_tanh(v[0]) + fl.y;
+                        v[1] = 10.0f * fast_tanh(v[1]) + fl.x;
+                        v[2] = 10.0f * fast_tanh(v[2]) + fl.y;
+                        v[3] = 10.0f * fast_tanh(v[3]) + fl.x;
                     } else {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = 1.0f / (1.0f + expf(-v[c]));
+                        for (int c = 0; c < 4; ++c) v[c] = fast_sigmoid(v[c]);
                     }
                 } else {
 #pragma unroll
@@ -534,6 +551,284 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
     conv_epilogue<CT, PT, RPW>(a, acc, n, T0, tx0, ty0, wave, j, h);
 }
 
+// ---------------------------------------------------------------- input-stationary variant (short K, many couts)
+// For convolutions whose whole K fits in LDS (Cin <= 32: the 32->216 offset/mask conv, the pixel-shuffle
+// expanders 32->96 / 24->64 / 32->64) the halo tile is staged and split ONCE per workgroup and the
+// workgroup then walks all cout tiles, streaming only the packed weights (27 KB per (cout tile, chunk),
+// prefetched into registers during the previous step's MFMAs).  The regular kernel re-stages the same
+// input once per cout tile and pays its prologue/epilogue bubble 7x for the 216-channel conv.
+template <int NCH, int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES, 1) void conv3x3_split_is_kernel(const ConvArgs a) {
+    constexpr int RPW = 1, TH = NWAVES, LH = TH + 2, PT = 2, NT = 64 * NWAVES;
+    constexpr int NEL = LH * LW;
+    constexpr int NIN = (NEL + NT - 1) / NT;
+    constexpr int NWS = (27 * 64 + NT - 1) / NT;
+    __shared__ bf16x8 tile[NCH][3][2][NEL];
+    __shared__ bf16x8 wlds[27 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit);
+    const int nsteps = a.ctiles * NCH;
+
+    bf16x8 rws[NWS];
+#define CRFP_IS_WLOAD(STEP)                                                                               \
+    _Pragma("unroll") for (int k = 0; k < NWS; ++k)                                                       \
+        rws[k] = wp[(long long)(STEP) * 1728 + min(tid + NT * k, 1727)];
+    CRFP_IS_WLOAD(0)   // (cout tile 0, chunk 0): packed index ((T*nchunks + ch)*27)*64 == step*1728
+
+    // ---- stage + split the whole input tile once
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        f32x4 rq[4][NIN];
+        int msk[4];
+        bool ok[NIN];
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const QuadDesc d = a.qd[4 * ch + qi];
+            const float* qb = d.base + (long long)n * d.bstride;
+            msk[qi] = d.mask;
+#pragma unroll
+            for (int t = 0; t < NIN; ++t) {
+                const int idx = min(tid + NT * t, NEL - 1);
+                const int r = idx / LW, c = idx - r * LW;
+                const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+                ok[t] = tid + NT * t < NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                rq[qi][t] = *reinterpret_cast<const f32x4*>(qb + min(max(gy, 0), H - 1) * d.rs + min(max(gx, 0), W - 1) * d.cs);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NIN; ++t) {
+            const int idx = tid + NT * t;
+            if (idx < NEL) {
+                bf16x8 p0, p1, p2;
+                split_bf16x8(mask_quad(rq[0][t], ok[t] ? msk[0] : 0), mask_quad(rq[1][t], ok[t] ? msk[1] : 0), p0, p1, p2);
+                tile[ch][0][0][idx] = p0; tile[ch][1][0][idx] = p1; tile[ch][2][0][idx] = p2;
+                split_bf16x8(mask_quad(rq[2][t], ok[t] ? msk[2] : 0), mask_quad(rq[3][t], ok[t] ? msk[3] : 0), p0, p1, p2);
+                tile[ch][0][1][idx] = p0; tile[ch][1][1][idx] = p1; tile[ch][2][1][idx] = p2;
+            }
+        }
+    }
+
+    long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
+    if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tA += t - t0; t0 = t; }
+    f32x16 acc[1][PT];
+    for (int step = 0; step < nsteps; ++step) {
+        const int ch = step % NCH, ct = step / NCH;
+        if (ch == 0) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[0][pt][e] = 0.0f;
+        }
+        __syncthreads();  // all waves done with the previous step's weights (and, first time, tile staged)
+#pragma unroll
+        for (int k = 0; k < NWS; ++k) {
+            const int idx = tid + NT * k;
+            if (idx < 1728) wlds[idx] = rws[k];
+        }
+        __syncthreads();
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
+        if (step + 1 < nsteps) { CRFP_IS_WLOAD(step + 1) }
+#pragma unroll CRFP_TAP_UNROLL
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const bf16x8 w0 = wlds[(tap * 3 + 0) * 64 + lane], w1 = wlds[(tap * 3 + 1) * 64 + lane],
+                         w2 = wlds[(tap * 3 + 2) * 64 + lane];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int pix = (wave * RPW + (pt >> 1) + ky) * LW + (pt & 1) * 32 + j + kx;
+                const bf16x8 b0 = tile[ch][0][h][pix], b1 = tile[ch][1][h][pix], b2 = tile[ch][2][h][pix];
+                f32x16 c = acc[0][pt];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b2, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, c, 0, 0, 0);
+                acc[0][pt] = c;
+            }
+        }
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
+        if (ch == NCH - 1) conv_epilogue<1, PT, RPW>(a, acc, n, ct, tx0, ty0, wave, j, h);
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
+    }
+    if (a.stamps && tid == 0) {
+        long long* o = a.stamps + (long long)blockIdx.x * 4;
+        o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD;
+    }
+#undef CRFP_IS_WLOAD
+}
+
+// ================================================================ warp-specialised split-bf16 convolution
+// Measured on the single-role kernels above (s_memtime stamps): the MFMA phase is only 40-50 % of a
+// block's life; the rest is (a) the fp32->3xbf16 split + LDS write of the next chunk, which cannot
+// overlap the MFMAs of the same waves, and (b) vmcnt being in-order on CDNA: a wave that has epilogue
+// stores in flight must drain them before it can consume a prefetched load (12k cycles per cout tile
+// in the 216-channel conv).  Here the roles are split:
+//   * 8 compute waves (one output row of 64 px each, 2 per SIMD) only ever read LDS, issue MFMAs and
+//     fire their epilogue stores -- they never wait on vmcnt inside the main loop;
+//   * 4 loader waves (one per SIMD) own every global load: they fetch the next chunk's halo tile (fp32)
+//     and packed weights, split the activations into 3 bf16 images and write them into the OTHER half
+//     of a double-buffered LDS tile while the compute waves run the current chunk.
+// Two workgroup barriers per chunk: X = compute done with the weight image / loaders done with the next
+// tile, Y = weight image of this chunk visible.  Weights (27 KB per chunk) are single-buffered: the
+// loaders hold them in registers and copy them in between X and Y (~400 idle compute cycles).
+// IS = input-stationary form for Cin <= 32 and many couts: both LDS tile halves hold the (at most two)
+// K-chunks for the whole block and the loop runs over (cout tile, chunk) steps streaming only weights.
+constexpr int WS_NC = 8, WS_NL = 8, WS_NT = 64 * (WS_NC + WS_NL), WS_TH = 8, WS_LH = WS_TH + 2, WS_NEL = WS_LH * LW;
+
+template <bool IS>
+__global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvArgs a) {
+    constexpr int NLT = 64 * WS_NL;                       // loader threads
+    constexpr int NIN = (WS_NEL + NLT - 1) / NLT;         // halo pixels per loader thread (3)
+    constexpr int NWS = (27 * 64 + NLT - 1) / NLT;        // weight vectors per loader thread (7)
+    __shared__ bf16x8 tile[2][3][2][WS_NEL];
+    __shared__ bf16x8 wlds[27 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * WS_TH;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int nchunks = a.kq >> 2;
+    const int T0 = IS ? 0 : blockIdx.y;
+    const int nsteps = IS ? a.ctiles * nchunks : nchunks;   // IS: step = ct*nchunks + ch
+
+    if (wave >= WS_NC) {
+        // ------------------------------------------------------------ loader role
+        const int lt = tid - 64 * WS_NC;
+        const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit);
+        int cgy[NIN], cgx[NIN];
+        bool sval[NIN];
+#pragma unroll
+        for (int t = 0; t < NIN; ++t) {
+            const int idx = min(lt + NLT * t, WS_NEL - 1);
+            const int r = idx / LW, c = idx - r * LW;
+            const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+            sval[t] = lt + NLT * t < WS_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            cgy[t] = min(max(gy, 0), H - 1);
+            cgx[t] = min(max(gx, 0), W - 1);
+        }
+        f32x4 rq0[NIN], rq1[NIN], rq2[NIN], rq3[NIN];
+        bf16x8 rws[NWS];
+        int m0, m1, m2, m3;
+#define CRFP_WS_LOAD_IN(CH)                                                                               \
+        {                                                                                                 \
+            const QuadDesc d0 = a.qd[4 * (CH)], d1 = a.qd[4 * (CH) + 1], d2 = a.qd[4 * (CH) + 2],         \
+                           d3 = a.qd[4 * (CH) + 3];                                                       \
+            const float* b0 = d0.base + (long long)n * d0.bstride;                                        \
+            const float* b1 = d1.base + (long long)n * d1.bstride;                                        \
+            const float* b2 = d2.base + (long long)n * d2.bstride;                                        \
+            const float* b3 = d3.base + (long long)n * d3.bstride;                                        \
+            m0 = d0.mask; m1 = d1.mask; m2 = d2.mask; m3 = d3.mask;                                       \
+            _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                             \
+                rq0[t] = *reinterpret_cast<const f32x4*>(b0 + cgy[t] * d0.rs + cgx[t] * d0.cs);           \
+                rq1[t] = *reinterpret_cast<const f32x4*>(b1 + cgy[t] * d1.rs + cgx[t] * d1.cs);           \
+                rq2[t] = *reinterpret_cast<const f32x4*>(b2 + cgy[t] * d2.rs + cgx[t] * d2.cs);           \
+                rq3[t] = *reinterpret_cast<const f32x4*>(b3 + cgy[t] * d3.rs + cgx[t] * d3.cs);           \
+            }                                                                                             \
+        }
+#define CRFP_WS_LOAD_W(WSTEP)                                                                             \
+        _Pragma("unroll") for (int k = 0; k < NWS; ++k)                                                   \
+            rws[k] = wp[(long long)(WSTEP) * 1728 + min(lt + NLT * k, 1727)];
+#define CRFP_WS_WRITE_IN(BUF)                                                                             \
+        _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                                 \
+            const int idx = lt + NLT * t;                                                                 \
+            if (idx < WS_NEL) {                                                                           \
+                bf16x8 p0, p1, p2;                                                                        \
+                split_bf16x8(mask_quad(rq0[t], sval[t] ? m0 : 0), mask_quad(rq1[t], sval[t] ? m1 : 0), p0, p1, p2); \
+                tile[BUF][0][0][idx] = p0; tile[BUF][1][0][idx] = p1; tile[BUF][2][0][idx] = p2;          \
+                split_bf16x8(mask_quad(rq2[t], sval[t] ? m2 : 0), mask_quad(rq3[t], sval[t] ? m3 : 0), p0, p1, p2); \
+                tile[BUF][0][1][idx] = p0; tile[BUF][1][1][idx] = p1; tile[BUF][2][1][idx] = p2;          \
+            }                                                                                             \
+        }
+        // packed weight image of (cout tile T, chunk ch) starts at ((T*nchunks + ch)*27)*64 vectors
+        const long long wbase = (long long)T0 * nchunks;
+        CRFP_WS_LOAD_IN(0)
+        CRFP_WS_LOAD_W(wbase)
+        CRFP_WS_WRITE_IN(0)
+        if (IS && nchunks > 1) {
+            CRFP_WS_LOAD_IN(1)
+            CRFP_WS_WRITE_IN(1)
+        }
+        for (int step = 0; step < nsteps; ++step) {
+            __syncthreads();  // X: compute waves are done with wlds; tile for this step is complete
+#pragma unroll
+            for (int k = 0; k < NWS; ++k) {
+                const int idx = lt + NLT * k;
+                if (idx < 1728) wlds[idx] = rws[k];
+            }
+            __syncthreads();  // Y: weight image visible
+            if (step + 1 < nsteps) {
+                if (!IS) CRFP_WS_LOAD_IN(step + 1)
+                CRFP_WS_LOAD_W(wbase + step + 1)
+                if (!IS) CRFP_WS_WRITE_IN((step + 1) & 1)
+            }
+        }
+#undef CRFP_WS_LOAD_IN
+#undef CRFP_WS_LOAD_W
+#undef CRFP_WS_WRITE_IN
+        return;
+    }
+
+    // ---------------------------------------------------------------- compute role: wave = output row
+    const int j = lane & 31, h = lane >> 5;
+    f32x16 acc[1][2];
+    float2 flpre[2] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
+    if (a.store == ST_OFFMASK) {
+        const int y = min(ty0 + wave, H - 1);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+            flpre[pt] = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride +
+                                                         ((long long)y * W + min(tx0 + pt * 32 + j, W - 1)) * 2);
+    }
+    long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
+    for (int step = 0; step < nsteps; ++step) {
+        const int ch = IS ? step % nchunks : step;
+        const int buf = IS ? ch : (step & 1);
+        if (!IS ? step == 0 : ch == 0) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[0][pt][e] = 0.0f;
+        }
+        __syncthreads();  // X
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tA += t - t0; t0 = t; }
+        __syncthreads();  // Y
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
+#pragma unroll CRFP_TAP_UNROLL
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const bf16x8 w0 = wlds[(tap * 3 + 0) * 64 + lane], w1 = wlds[(tap * 3 + 1) * 64 + lane],
+                         w2 = wlds[(tap * 3 + 2) * 64 + lane];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int pix = (wave + ky) * LW + pt * 32 + j + kx;
+                const bf16x8 b0 = tile[buf][0][h][pix], b1 = tile[buf][1][h][pix], b2 = tile[buf][2][h][pix];
+                f32x16 c = acc[0][pt];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b2, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, c, 0, 0, 0);
+                acc[0][pt] = c;
+            }
+        }
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
+        if (IS && ch == nchunks - 1) conv_epilogue<1, 2, 1>(a, acc, n, step / nchunks, tx0, ty0, wave, j, h, flpre);
+        if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
+    }
+    if (a.stamps && tid == 0) {
+        long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD;
+    }
+    if (!IS) conv_epilogue<1, 2, 1>(a, acc, n, T0, tx0, ty0, wave, j, h, flpre);
+}
+
 // split weight pack: wsplit bf16 index =
 //   (((((T*nchunks + ch)*9 + tap)*3 + part)*64 + lane)*8 + jj),  lane = half*32 + row,
 //   K-quad = 4*ch + 2*half + (jj>>2), component = jj&3
@@ -676,7 +971,21 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
                 }
             }
     }
-    if (split) {
+    static const bool use_ws = !(getenv("CRFP_SPLIT_WS") && atoi(getenv("CRFP_SPLIT_WS")) == 0);
+    static const bool use_is = !(getenv("CRFP_SPLIT_IS") && atoi(getenv("CRFP_SPLIT_IS")) == 0);
+    if (split && use_ws) {
+        const int wtiles = ((a.W + TW - 1) / TW) * ((a.H + WS_TH - 1) / WS_TH);
+        if (use_is && a.kq <= 8 && a.ctiles >= 2) {
+            conv3x3_split_ws_kernel<true><<<dim3(wtiles, 1, a.N), WS_NT, 0, s>>>(a);
+        } else {
+            conv3x3_split_ws_kernel<false><<<dim3(wtiles, a.ctiles, a.N), WS_NT, 0, s>>>(a);
+        }
+    } else if (split && use_is && a.kq <= 8 && a.ctiles >= 2) {
+        // input-stationary: whole K in LDS, one workgroup per 4x64 tile walks every cout tile
+        dim3 grid(((a.W + TW - 1) / TW) * ((a.H + 7) / 8), 1, a.N);
+        if (a.kq == 4) conv3x3_split_is_kernel<1, 8><<<grid, 512, 0, s>>>(a);
+        else conv3x3_split_is_kernel<2, 8><<<grid, 512, 0, s>>>(a);
+    } else if (split) {
         if (ct2) {
             dim3 grid(tiles, a.ctiles / 2, a.N);
             conv3x3_split_kernel<2, 1><<<grid, 256, 0, s>>>(a);
