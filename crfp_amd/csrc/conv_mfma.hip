@@ -712,10 +712,15 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
             cgy[t] = min(max(gy, 0), H - 1);
             cgx[t] = min(max(gx, 0), W - 1);
         }
-        f32x4 rq0[NIN], rq1[NIN], rq2[NIN], rq3[NIN];
-        bf16x8 rws[NWS];
-        int m0, m1, m2, m3;
-#define CRFP_WS_LOAD_IN(CH)                                                                               \
+        // Loader schedule, two register sets (A, B): right after barrier Y(s) the loads of chunk s+2 are
+        // issued into the set that was just consumed, THEN the other set (chunk s+1, issued a whole step
+        // earlier) is split and written to the idle tile half.  Every load is unconditional (chunk index
+        // clamped) so that the in-order vmcnt counts are compile-time constants and the compiler can wait
+        // for "all but the loads just issued" instead of vmcnt(0).
+        f32x4 qa0[NIN], qa1[NIN], qa2[NIN], qa3[NIN], qb0[NIN], qb1[NIN], qb2[NIN], qb3[NIN];
+        bf16x8 wa_[NWS], wb_[NWS];
+        int ma0 = 0, ma1 = 0, ma2 = 0, ma3 = 0, mb0 = 0, mb1 = 0, mb2 = 0, mb3 = 0;
+#define CRFP_WS_LOAD_IN(R0, R1, R2, R3, M0, M1, M2, M3, CH)                                               \
         {                                                                                                 \
             const QuadDesc d0 = a.qd[4 * (CH)], d1 = a.qd[4 * (CH) + 1], d2 = a.qd[4 * (CH) + 2],         \
                            d3 = a.qd[4 * (CH) + 3];                                                       \
@@ -723,54 +728,92 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
             const float* b1 = d1.base + (long long)n * d1.bstride;                                        \
             const float* b2 = d2.base + (long long)n * d2.bstride;                                        \
             const float* b3 = d3.base + (long long)n * d3.bstride;                                        \
-            m0 = d0.mask; m1 = d1.mask; m2 = d2.mask; m3 = d3.mask;                                       \
+            M0 = d0.mask; M1 = d1.mask; M2 = d2.mask; M3 = d3.mask;                                       \
             _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                             \
-                rq0[t] = *reinterpret_cast<const f32x4*>(b0 + cgy[t] * d0.rs + cgx[t] * d0.cs);           \
-                rq1[t] = *reinterpret_cast<const f32x4*>(b1 + cgy[t] * d1.rs + cgx[t] * d1.cs);           \
-                rq2[t] = *reinterpret_cast<const f32x4*>(b2 + cgy[t] * d2.rs + cgx[t] * d2.cs);           \
-                rq3[t] = *reinterpret_cast<const f32x4*>(b3 + cgy[t] * d3.rs + cgx[t] * d3.cs);           \
+                R0[t] = *reinterpret_cast<const f32x4*>(b0 + cgy[t] * d0.rs + cgx[t] * d0.cs);            \
+                R1[t] = *reinterpret_cast<const f32x4*>(b1 + cgy[t] * d1.rs + cgx[t] * d1.cs);            \
+                R2[t] = *reinterpret_cast<const f32x4*>(b2 + cgy[t] * d2.rs + cgx[t] * d2.cs);            \
+                R3[t] = *reinterpret_cast<const f32x4*>(b3 + cgy[t] * d3.rs + cgx[t] * d3.cs);            \
             }                                                                                             \
         }
-#define CRFP_WS_LOAD_W(WSTEP)                                                                             \
+#define CRFP_WS_LOAD_W(RW, WSTEP)                                                                         \
         _Pragma("unroll") for (int k = 0; k < NWS; ++k)                                                   \
-            rws[k] = wp[(long long)(WSTEP) * 1728 + min(lt + NLT * k, 1727)];
-#define CRFP_WS_WRITE_IN(BUF)                                                                             \
+            RW[k] = wp[(long long)(WSTEP) * 1728 + min(lt + NLT * k, 1727)];
+#define CRFP_WS_WRITE_IN(R0, R1, R2, R3, M0, M1, M2, M3, BUF)                                             \
         _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                                 \
             const int idx = lt + NLT * t;                                                                 \
             if (idx < WS_NEL) {                                                                           \
                 bf16x8 p0, p1, p2;                                                                        \
-                split_bf16x8(mask_quad(rq0[t], sval[t] ? m0 : 0), mask_quad(rq1[t], sval[t] ? m1 : 0), p0, p1, p2); \
+                split_bf16x8(mask_quad(R0[t], sval[t] ? M0 : 0), mask_quad(R1[t], sval[t] ? M1 : 0), p0, p1, p2); \
                 tile[BUF][0][0][idx] = p0; tile[BUF][1][0][idx] = p1; tile[BUF][2][0][idx] = p2;          \
-                split_bf16x8(mask_quad(rq2[t], sval[t] ? m2 : 0), mask_quad(rq3[t], sval[t] ? m3 : 0), p0, p1, p2); \
+                split_bf16x8(mask_quad(R2[t], sval[t] ? M2 : 0), mask_quad(R3[t], sval[t] ? M3 : 0), p0, p1, p2); \
                 tile[BUF][0][1][idx] = p0; tile[BUF][1][1][idx] = p1; tile[BUF][2][1][idx] = p2;          \
             }                                                                                             \
         }
+#define CRFP_WS_WRITE_W(RW)                                                                               \
+        _Pragma("unroll") for (int k = 0; k < NWS; ++k) {                                                 \
+            const int idx = lt + NLT * k;                                                                 \
+            if (idx < 1728) wlds[idx] = RW[k];                                                            \
+        }
         // packed weight image of (cout tile T, chunk ch) starts at ((T*nchunks + ch)*27)*64 vectors
         const long long wbase = (long long)T0 * nchunks;
-        CRFP_WS_LOAD_IN(0)
-        CRFP_WS_LOAD_W(wbase)
-        CRFP_WS_WRITE_IN(0)
-        if (IS && nchunks > 1) {
-            CRFP_WS_LOAD_IN(1)
-            CRFP_WS_WRITE_IN(1)
-        }
-        for (int step = 0; step < nsteps; ++step) {
-            __syncthreads();  // X: compute waves are done with wlds; tile for this step is complete
-#pragma unroll
-            for (int k = 0; k < NWS; ++k) {
-                const int idx = lt + NLT * k;
-                if (idx < 1728) wlds[idx] = rws[k];
+        const int last = nsteps - 1, lastc = nchunks - 1;
+        if (IS) {
+            CRFP_WS_LOAD_IN(qa0, qa1, qa2, qa3, ma0, ma1, ma2, ma3, 0)
+            CRFP_WS_LOAD_W(wa_, wbase)
+            CRFP_WS_WRITE_IN(qa0, qa1, qa2, qa3, ma0, ma1, ma2, ma3, 0)
+            if (nchunks > 1) {
+                CRFP_WS_LOAD_IN(qa0, qa1, qa2, qa3, ma0, ma1, ma2, ma3, 1)
+                CRFP_WS_WRITE_IN(qa0, qa1, qa2, qa3, ma0, ma1, ma2, ma3, 1)
             }
-            __syncthreads();  // Y: weight image visible
-            if (step + 1 < nsteps) {
-                if (!IS) CRFP_WS_LOAD_IN(step + 1)
-                CRFP_WS_LOAD_W(wbase + step + 1)
-                if (!IS) CRFP_WS_WRITE_IN((step + 1) & 1)
+            for (int step = 0; step < nsteps; ++step) {
+                __syncthreads();  // X
+                CRFP_WS_WRITE_W(wa_)
+                __syncthreads();  // Y
+                CRFP_WS_LOAD_W(wa_, wbase + min(step + 1, last))
             }
+        } else {
+            CRFP_WS_LOAD_IN(qa0, qa1, qa2, qa3, ma0, ma1, ma2, ma3, 0)
+            CRFP_WS_LOAD_W(wa_, wbase)
+            CRFP_WS_LOAD_IN(qb0, qb1, qb2, qb3, mb0, mb1, mb2, mb3, min(1, lastc))
+            CRFP_WS_LOAD_W(wb_, wbase + min(1, last))
+            CRFP_WS_WRITE_IN(qa0, qa1, qa2, qa3, ma0, ma1, ma2, ma3, 0)
+            // top of an even step s: tile[s&1] = chunk s, wa_ = weights(s), set B = chunk s+1 (in flight)
+            long long sA = 0, sB = 0, sC = 0, sD = 0, t0 = __builtin_amdgcn_s_memtime();
+#define CRFP_ST(ACC) if (a.stamps) { const long long t_ = __builtin_amdgcn_s_memtime(); ACC += t_ - t0; t0 = t_; }
+            for (int step = 0; step < nsteps; step += 2) {
+                __syncthreads();  // X: compute done with wlds and with tile[(step+1)&1]
+                CRFP_ST(sD)
+                CRFP_WS_WRITE_W(wa_)
+                __syncthreads();  // Y
+                CRFP_ST(sC)
+                CRFP_WS_LOAD_IN(qa0, qa1, qa2, qa3, ma0, ma1, ma2, ma3, min(step + 2, lastc))
+                CRFP_WS_LOAD_W(wa_, wbase + min(step + 2, last))
+                CRFP_ST(sA)
+                if (step + 1 >= nsteps) break;
+                CRFP_WS_WRITE_IN(qb0, qb1, qb2, qb3, mb0, mb1, mb2, mb3, (step + 1) & 1)
+                CRFP_ST(sB)
+                __syncthreads();  // X
+                CRFP_ST(sD)
+                CRFP_WS_WRITE_W(wb_)
+                __syncthreads();  // Y
+                CRFP_ST(sC)
+                CRFP_WS_LOAD_IN(qb0, qb1, qb2, qb3, mb0, mb1, mb2, mb3, min(step + 3, lastc))
+                CRFP_WS_LOAD_W(wb_, wbase + min(step + 3, last))
+                CRFP_ST(sA)
+                if (step + 2 < nsteps) CRFP_WS_WRITE_IN(qa0, qa1, qa2, qa3, ma0, ma1, ma2, ma3, step & 1)
+                CRFP_ST(sB)
+            }
+            if (a.stamps && lt == 0) {
+                long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + 4 * 8192;
+                o[0] = sA; o[1] = sB; o[2] = sC; o[3] = sD;
+            }
+#undef CRFP_ST
         }
 #undef CRFP_WS_LOAD_IN
 #undef CRFP_WS_LOAD_W
 #undef CRFP_WS_WRITE_IN
+#undef CRFP_WS_WRITE_W
         return;
     }
 
@@ -971,7 +1014,9 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
                 }
             }
     }
-    static const bool use_ws = !(getenv("CRFP_SPLIT_WS") && atoi(getenv("CRFP_SPLIT_WS")) == 0);
+    // warp-specialised variant: measured 346 vs 351.5 frames/s for the single-role kernels (loader issue is
+    // throttled by the ~12 B/clk/CU the memory system delivers) -> kept as an opt-in experiment
+    static const bool use_ws = getenv("CRFP_SPLIT_WS") && atoi(getenv("CRFP_SPLIT_WS")) == 1;
     static const bool use_is = !(getenv("CRFP_SPLIT_IS") && atoi(getenv("CRFP_SPLIT_IS")) == 0);
     if (split && use_ws) {
         const int wtiles = ((a.W + TW - 1) / TW) * ((a.H + WS_TH - 1) / WS_TH);

@@ -19,3 +19,8 @@ print(site, "blocks", len(nz))
 for i, nm in enumerate(["A: barrier1 (wait prev MFMA + loads land)", "B: split + LDS write + barrier2", "C: issue next loads", "D: MFMA loop"]):
     print(f"  {nm:45s} mean {nz[:, i].mean():10.0f}  max {nz[:, i].max():10.0f}  (x100MHz ticks -> cycles: s_memtime is shader clock)")
 print("  total mean", nz.sum(1).mean())
+lb = buf.view(-1, 4)[8192:].cpu().double(); lnz = lb[(lb.sum(1) > 0)]
+if len(lnz):
+    print(" loader wave: blocks", len(lnz))
+    for i, nm in enumerate(["issue loads", "split + write tile", "X..Y (weight image write)", "wait at X"]):
+        print(f"  {nm:45s} mean {lnz[:, i].mean():10.0f}  max {lnz[:, i].max():10.0f}")
