@@ -37,7 +37,7 @@ SIGNATURES = {
     "crfp_dsv_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "crfp_dsv_forward_clip": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 +
                               [C.c_void_p, C.c_size_t, C.c_void_p]),
-    "crfp_dsv_stream_frame": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 3 +
+    "crfp_dsv_stream_frame": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 3 +
                               [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_fnet_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_prof_enable": (C.c_int, [C.c_int]),

@@ -222,6 +222,10 @@ int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, i
 int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s);
 int launch_offmask_nchw_to_q4(const float* offset, const float* mask, float* out, int N, int noff, int nmask, int H,
                               int W, hipStream_t s);
+int launch_fg_prep(const uint8_t* fg, float* fg2, int H8, int W8, hipStream_t s);
+// dst = src * scale(y,x); scale is float [H][W] (scale_f) or u8 [H][W] (scale_u8)
+int launch_scale_q4(const float* src, int src_pad, float* dst, int nq, int H, int W, const float* scale_f,
+                    const uint8_t* scale_u8, hipStream_t s);
 int launch_psnr_partial(const float* a, const float* b, double* acc, int N, int C, int H, int W, hipStream_t s);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

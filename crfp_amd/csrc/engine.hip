@@ -292,7 +292,7 @@ struct Layout {
     size_t fa0, fa1, fp1, fb0, fb1, fp2, fc0, fc1, fp3, fd0, fd1, fu1, fe0, fe1, fu2, ff0, ff1, fu3, fg0, fg1;
     // frame-level
     size_t xin8, eh, x_hr, prop_a, prop_b, flow2, flow8, prev2, prev2w, prevhrw, carryw, fa, fb, offfeat[3], offmask,
-        aligned, y0, y1, up, poff, g0, g1, g2, om3, al3, z0, z1, feat;
+        aligned, y0, y1, up, poff, g0, g1, g2, om3, al3, z0, z1, feat, fg2, sc_prop, sc_cw, sc_al, sc_up, sc_al3;
     int h1, w1, h2, w2, h3, w3;
 
     Layout(int t_, int h_, int w_) : t(t_), h(h_), w(w_) {
@@ -352,6 +352,13 @@ struct Layout {
         z0 = A.take("res3.z0", 1, 1, H8, W8);
         z1 = A.take("res3.z1", 1, 1, H8, W8);
         feat = A.take("feat", 1, 1, H8, W8);
+        // regional-mask (fgs) copies of the streaming variant
+        fg2 = A.take("fg2", 1, 0, H2 / 2, W2, 1);   // H2*W2 floats (kind 1 stores 2 floats per element)
+        sc_prop = A.take("fg.prop", 1, 6, H2, W2);
+        sc_cw = A.take("fg.carry", 1, 2, H2, W2);
+        sc_al = A.take("fg.aligned", 1, 8, H2, W2);
+        sc_up = A.take("fg.up", 1, 1, H8, W8);
+        sc_al3 = A.take("fg.aligned3", 1, 1, H8, W8);
     }
     size_t bytes() const { return A.cur; }
 };
@@ -462,7 +469,7 @@ struct Runner {
 
     // one iteration of the recurrent loop (reference model/CRFP.py:1555-1684)
     void frame(bool first, const float* lr, const float* fv, const uint8_t* mk, const float* flow_lr_q4,
-               const float* x_lr_i, float* out) {
+               const float* x_lr_i, float* out, const uint8_t* fg = nullptr) {
         const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         const long long P8q = (long long)H8 * W8 * 4, P2q = (long long)H2 * W2 * 4;
         const long long P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;   // padded (P4) plane at 2x resolution
@@ -483,6 +490,7 @@ struct Runner {
             RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, 1, s));
             RUN(launch_flow_warp_q4(carry, 0, flow2, 0, F(L.carryw), 0, 1, 6, H2, W2, 0, 1, s));
             const float* offprev = nullptr;
+            if (fg) RUN(launch_fg_prep(fg, F(L.fg2), H8, W8, s));
             for (int l = 0; l < 3; ++l) {
                 const float* cw = F(L.carryw) + 2 * l * P2q;
                 mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
@@ -498,7 +506,13 @@ struct Runner {
                 const Item& dw = M.items[it_lvl(l, L_DCNW)];
                 RUN(launch_dcn_g8(F(L.prev2), 0, F(L.offmask), 0, packed + dw.off_w, packed + dw.off_b, F(L.aligned), 0,
                                   1, H2, W2, s));
-                mfma(it_lvl(l, L_RB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.aligned), 0}}, {{F(L.y0), 0, 0, 8}});
+                if (fg && l > 0) {  // model/CRFP_test.py:2361,2375: resblock input * fg (x0.25) for levels 1, 2
+                    RUN(launch_scale_q4(prop, 0, F(L.sc_prop), 6, H2, W2, F(L.fg2), nullptr, s));
+                    RUN(launch_scale_q4(cw, 0, F(L.sc_cw), 2, H2, W2, F(L.fg2), nullptr, s));
+                    RUN(launch_scale_q4(F(L.aligned), 0, F(L.sc_al), 8, H2, W2, F(L.fg2), nullptr, s));
+                    mfma(it_lvl(l, L_RB0), 1, H2, W2, {{F(L.sc_prop), 0}, {F(L.sc_cw), 0}, {F(L.sc_al), 0}}, {{F(L.y0), 0, 0, 8}});
+                } else
+                    mfma(it_lvl(l, L_RB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.aligned), 0}}, {{F(L.y0), 0, 0, 8}});
                 mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
                 mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2qp, 0, 6, 8, 1}}, 0, 0,
                      F(L.y0), 0);
@@ -513,7 +527,12 @@ struct Runner {
             narrow(IT_D3OM, H8, W8, {F(L.g2)}, F(L.om3), nullptr, flow8);
             const Item& d3 = M.items[IT_D3W];
             RUN(launch_dcn3(F(L.state_hr), 0, F(L.om3), 0, packed + d3.off_w, packed + d3.off_b, F(L.al3), 0, 1, H8, W8, s));
-            narrow(IT_R3_0, H8, W8, {F(L.up), F(L.al3)}, F(L.z0));
+            if (fg) {           // model/CRFP_test.py:2389
+                RUN(launch_scale_q4(F(L.up), 0, F(L.sc_up), 1, H8, W8, nullptr, fg, s));
+                RUN(launch_scale_q4(F(L.al3), 0, F(L.sc_al3), 1, H8, W8, nullptr, fg, s));
+                narrow(IT_R3_0, H8, W8, {F(L.sc_up), F(L.sc_al3)}, F(L.z0));
+            } else
+                narrow(IT_R3_0, H8, W8, {F(L.up), F(L.al3)}, F(L.z0));
         } else {
             for (int l = 0; l < 3; ++l) {
                 mfma(it_lvl(l, L_RB0F), 1, H2, W2, {{prop, 0}, {nullptr, 0}}, {{F(L.y0), 0, 0, 8}});
@@ -622,7 +641,7 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
 }
 
 int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const float* lr_prev, const float* fv,
-                          const uint8_t* mk, float* out, int first, int h, int w, void* workspace,
+                          const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream) {
     Layout L(1, h, w);
     int rc = check_common(packed, 1, h, w, workspace, workspace_bytes, L);
@@ -632,7 +651,7 @@ int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const
     if (first) R.reset_state();
     if (!first) R.fnet(1, lr, 0, lr_prev, 0);
     R.encode_lr(1, lr, 0);
-    R.frame(first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr), out);
+    R.frame(first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr), out, fg);
     return R.rc;
 }
 

@@ -262,6 +262,44 @@ int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* o
     return 0;
 }
 
+// Regional mask of the streaming variant (reference model/CRFP_test.py:2296-2298): fg [8h,8w] (bool) ->
+// nn.Upsample(scale_factor=0.25, bilinear, align_corners=False) = mean of the centre 2x2 of each 4x4 block
+// (source index 4*d + 1.5 -> taps 4d+1, 4d+2 with weight 0.5 each), at 2x resolution.
+__global__ void fg_prep_kernel(const uint8_t* __restrict__ fg, float* __restrict__ fg2, int H2, int W2) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W2 || y >= H2) return;
+    const int W8 = 4 * W2;
+    const uint8_t* p = fg + (long long)(4 * y + 1) * W8 + 4 * x + 1;
+    const float a = p[0] ? 1.0f : 0.0f, b = p[1] ? 1.0f : 0.0f, c = p[W8] ? 1.0f : 0.0f, d = p[W8 + 1] ? 1.0f : 0.0f;
+    fg2[(long long)y * W2 + x] = 0.5f * (0.5f * a + 0.5f * b) + 0.5f * (0.5f * c + 0.5f * d);
+}
+
+int launch_fg_prep(const uint8_t* fg, float* fg2, int H8, int W8, hipStream_t s) {
+    const int H2 = H8 / 4, W2 = W8 / 4;
+    ProfScope prof("fg_prep", s, (double)H8 * W8 + 4.0 * H2 * W2, 0);
+    fg_prep_kernel<<<dim3((W2 + 63) / 64, (H2 + 3) / 4), 256, 0, s>>>(fg, fg2, H2, W2);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void scale_q4_kernel(const float* __restrict__ src, int src_pad, float* __restrict__ dst, int H, int W,
+                                const float* __restrict__ sf, const uint8_t* __restrict__ su) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), q = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const long long pix = (long long)y * W + x;
+    const float sc = sf ? sf[pix] : (su[pix] ? 1.0f : 0.0f);
+    const float4 v = *reinterpret_cast<const float4*>(src + (((long long)q * (H + src_pad) + y) * (W + src_pad) + x) * 4);
+    *reinterpret_cast<float4*>(dst + ((long long)q * H * W + pix) * 4) = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+}
+
+int launch_scale_q4(const float* src, int src_pad, float* dst, int nq, int H, int W, const float* scale_f,
+                    const uint8_t* scale_u8, hipStream_t s) {
+    ProfScope prof("scale_q4_fg", s, (double)nq * H * W * 32.0, 0);
+    scale_q4_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, nq), 256, 0, s>>>(src, src_pad, dst, H, W, scale_f, scale_u8);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
 // acc[0] += sum (a-b)^2 ; acc[1] += sum (Y(a)-Y(b))^2 with Y = 24.966*c0 + 128.553*c1 + 65.481*c2 + 16
 __global__ void psnr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ acc,
                                     int C, long long HW) {

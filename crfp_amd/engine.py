@@ -87,10 +87,12 @@ class DSVEngine:
     def clear_states(self):
         self._stream_prev = None
 
-    def stream_frame(self, lr, fv, mk):
-        """lr[3,h,w], fv[3,8h,8w], mk[1,8h,8w] -> [3|1,8h,8w]; first call after clear_states() starts a clip."""
+    def stream_frame(self, lr, fv, mk, fg=None):
+        """lr[3,h,w], fv[3,8h,8w], mk[1,8h,8w], optional regional mask fg[1,8h,8w] -> [3|1,8h,8w]; the first
+        call after clear_states() starts a sequence."""
         lr, fv = _dev(lr, "lr"), _dev(fv, "fv")
         mk8 = self._mask_u8(mk)
+        fg8 = None if fg is None else self._mask_u8(fg)
         _, h, w = lr.shape
         if self._stream_ws is None or self._stream_hw != (h, w):
             nb = _lib.lib().crfp_dsv_workspace_bytes(1, h, w)
@@ -102,7 +104,8 @@ class DSVEngine:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().crfp_dsv_stream_frame(
                 self.packed.data_ptr(), self.y_only, lr.data_ptr(),
-                None if first else self._stream_prev.data_ptr(), fv.data_ptr(), mk8.data_ptr(), out.data_ptr(),
+                None if first else self._stream_prev.data_ptr(), fv.data_ptr(), mk8.data_ptr(),
+                None if fg8 is None else fg8.data_ptr(), out.data_ptr(),
                 1 if first else 0, h, w, self._stream_ws.data_ptr(), self._stream_ws.numel(), _stream()),
                 "crfp_dsv_stream_frame")
         self._stream_prev = lr

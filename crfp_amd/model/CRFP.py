@@ -250,10 +250,14 @@ class CRFP_DSV(nn.Module):
             self._engine.clear_states()
 
     @torch.no_grad()
-    def forward_stream(self, lrs, fvs, mks):
-        """lrs[1,1,3,h,w], fvs[1,1,3,8h,8w], mks[1,1,1,8h,8w] -> [1,1,3|1,8h,8w], state kept between calls."""
-        out = self.engine().stream_frame(lrs[0, 0], fvs[0, 0], mks[0, 0])
-        return out[None, None]
+    def forward_stream(self, lrs, fvs, mks, fgs=None):
+        """lrs[1,t,3,h,w], fvs[1,t,3,8h,8w], mks / fgs[1,t,1,8h,8w] -> [1,t,3|1,8h,8w]; recurrent state and
+        the previous LR frame persist between calls (reference model/CRFP_test.py:2234-2239,2438-2441)."""
+        assert lrs.shape[0] == 1, "streaming runs one sequence at a time"
+        eng = self.engine()
+        outs = [eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i], None if fgs is None else fgs[0, i])
+                for i in range(lrs.shape[1])]
+        return torch.stack(outs, dim=0)[None]
 
     def init_weights(self, pretrained=None, strict=True):
         if isinstance(pretrained, str):
@@ -263,3 +267,18 @@ class CRFP_DSV(nn.Module):
             self.load_state_dict(sd, strict=strict)
         elif pretrained is not None:
             raise TypeError(f'"pretrained" must be a str or None. But received {type(pretrained)}.')
+
+
+class MRCF_simple_v18(CRFP_DSV):
+    """The reference's one-frame-per-call model (model/CRFP_test.py:2114-2478; built by test_video.py and
+    test_runtime.py through ``from model import MRCF_test / MRCF_runtime``): same parameters as CRFP_DSV,
+    ``forward(lrs, fvs, mks, fgs)`` keeps its state between calls, ``clear_states()`` starts a new sequence."""
+
+    def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, split_ratio=3,
+                 spynet_pretrained=None):
+        if split_ratio != 3:
+            raise NotImplementedError("split_ratio 3 only (the reference's shipped configuration)")
+        super().__init__(device, mid_channels, y_only, hr_dcn, offset_prop, spynet_pretrained)
+
+    def forward(self, lrs, fvs, mks, fgs=None):
+        return self.forward_stream(lrs, fvs, mks, fgs)

@@ -100,9 +100,10 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
 
 /* Streaming: one frame per call, recurrent state kept inside `workspace` (same buffer every call).
  * `first` != 0 resets the state (clear_states of the reference's streaming model). lr_prev may be
- * NULL when first != 0. */
+ * NULL when first != 0.  fg: optional regional mask [8h,8w] u8 (the reference's `fgs`,
+ * model/CRFP_test.py:2296-2298,2361,2375,2389), NULL = all ones. */
 int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const float* lr_prev, const float* fv,
-                          const uint8_t* mk, float* out, int first, int h, int w, void* workspace,
+                          const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream);
 
 /* FNet alone (compute_flow): pairs cur[n,3,h,w], prev[n,3,h,w] -> flow[n,2,h,w] (NCHW). */

@@ -238,17 +238,25 @@ def dsv_frame(P, cfg: DSVConfig, st, lr: Tensor, fv: Tensor, mk: Tensor, flow: O
         carry = torch.chunk(flow_warp(torch.cat(st["carry"], dim=1), flow2.permute(0, 2, 3, 1)), 3, dim=1)  # :1573-1582
         off_feat = None
         new_carry = []
+        # streaming variant only (model/CRFP_test.py:2296-2298): regional mask, bilinear x0.25 at 2x res
+        fg2 = None if fg is None else F.interpolate(fg.float(), scale_factor=0.25, mode="bilinear", align_corners=False)
         for lvl in range(3):                                                  # :1585-1622
             cur = torch.cat((prop, carry[lvl]), dim=1)
             aligned, off_feat = dcn_module(P, f"dcn_{lvl}.", cur, prev2, prev2_w, flow2, off_feat,
                                            dg=cfg.dg, repeat=False, interpolate="none")
-            y = resblocks_with_input_conv(P, f"forward_resblocks_{lvl}.", torch.cat([cur, aligned], dim=1))
+            res_in = torch.cat([cur, aligned], dim=1)
+            if fg2 is not None and lvl > 0:     # CRFP_test.py:2361,2375 (the level-0 product :2347 is a no-op)
+                res_in = res_in * fg2
+            y = resblocks_with_input_conv(P, f"forward_resblocks_{lvl}.", res_in)
             prop, c_new = y[:, :cfg.prop], y[:, cfg.prop:]
             new_carry.append(c_new)
         up = lrelu(pixel_shuffle_pack(P, "upsample_post.", prop, 4))          # :1625
         aligned, _ = dcn_module(P, "dcn_3.", up, prev_hr, prev_hr_w, flow8, off_feat,
                                 dg=1, repeat=True, interpolate="pixelshuffle")  # :1626
-        feat = resblocks_with_input_conv(P, "forward_resblocks_3.", torch.cat([up, aligned], dim=1))  # :1629-1630
+        res_in = torch.cat([up, aligned], dim=1)
+        if fg is not None:                      # CRFP_test.py:2389
+            res_in = res_in * fg.float()
+        feat = resblocks_with_input_conv(P, "forward_resblocks_3.", res_in)   # :1629-1630
     else:
         zeros2 = lr.new_zeros(n, cfg.mid, 2 * h, 2 * w)
         new_carry = []
@@ -279,6 +287,37 @@ def crfp_dsv_forward(P, lrs: Tensor, fvs: Tensor, mks: Tensor, cfg: Optional[DSV
         out, st = dsv_frame(P, cfg, st, lrs[:, i], fvs[:, i], mks[:, i], flows[:, i - 1] if i > 0 else None)
         outs.append(out)
     return torch.stack(outs, dim=1)
+
+
+class StreamOracle:
+    """One-frame-per-call variant (model/CRFP_test.py:2114-2478, MRCF_simple_v18): recurrent state and
+    the previous LR frame persist between calls; ``clear_states`` (:2473-2478) starts a new sequence.
+    Flow of the first frame of a sequence is FNet(frame, last frame of the same call) (:2234-2239) but
+    unused, because that frame takes the state-less branch (:2309 ``torch.is_tensor(self.feat_prop_lv3)``)."""
+
+    def __init__(self, P, cfg: Optional[DSVConfig] = None):
+        self.P, self.cfg = P, cfg or DSVConfig()
+        self.clear_states()
+
+    def clear_states(self):
+        self.prev_lr = None
+        self.st = None
+
+    def __call__(self, lrs: Tensor, fvs: Tensor, mks: Tensor, fgs: Optional[Tensor] = None) -> Tensor:
+        n, t, c, h, w = lrs.shape
+        if self.st is None:
+            self.st = new_state(self.cfg, n, h, w, lrs)
+        outs = []
+        for i in range(t):
+            lr = lrs[:, i]
+            flow = None
+            if not self.st["first"]:
+                flow = fnet(self.P, "spynet.", lr, self.prev_lr)
+            out, self.st = dsv_frame(self.P, self.cfg, self.st, lr, fvs[:, i], mks[:, i], flow,
+                                     None if fgs is None else fgs[:, i])
+            self.prev_lr = lr
+            outs.append(out)
+        return torch.stack(outs, dim=1)
 
 
 # ----------------------------------------------------------------------------- metrics

@@ -199,5 +199,32 @@ def main():
         print(name, "out", tuple(y.shape), "mean %.6f" % float(y.mean()), "flow absmax %.3f" % float(flows.abs().max()))
 
 
+    # ---- streaming variant (model/CRFP_test.py:2114-2478): 5 calls of one frame each with a regional
+    #      mask fgs, then clear_states() and 2 more calls
+    from model import CRFP_test
+    sdm = synth.make_state_dict(SEED)
+    sm = CRFP_test.MRCF_simple_v18(mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True, split_ratio=3,
+                                   spynet_pretrained=fnet_path, device=torch.device("cpu"))
+    assert list(sm.state_dict().keys()) == synth.state_dict_keys()
+    sm.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sdm.items()}, strict=True)
+    sm.eval()
+    h, w, t = 16, 24, 7
+    lrs, fvs, mks = synth.make_clip(seed=13, n=1, t=t, h=h, w=w, fv_size=48, sigma_t=10.0)
+    rs2 = np.random.RandomState(99)
+    fgs = np.zeros((1, t, 1, 8 * h, 8 * w), np.bool_)
+    for i in range(t):
+        y0, x0 = rs2.randint(0, 8 * h - 70), rs2.randint(0, 8 * w - 90)
+        fgs[0, i, 0, y0:y0 + 70, x0:x0 + 90] = True
+    outs = []
+    for i in range(t):
+        if i == 5:
+            sm.clear_states()
+        outs.append(sm(T(lrs[:, i:i + 1]), T(fvs[:, i:i + 1]), T(mks[:, i:i + 1]), T(fgs[:, i:i + 1])).numpy())
+    np.savez_compressed(os.path.join(HERE, "stream_16x24_t7.npz"), weights_seed=np.int64(SEED), clip_seed=np.int64(13),
+                        h=np.int64(h), w=np.int64(w), t=np.int64(t), fv_size=np.int64(48), clear_at=np.int64(5),
+                        fgs=fgs, out=np.concatenate(outs, axis=1))
+    print("stream_16x24_t7 out", np.concatenate(outs, axis=1).shape)
+
+
 if __name__ == "__main__":
     main()

@@ -243,3 +243,24 @@ def test_psnr_sums(orc, ops_golden):
     psnr_y = -10.0 * np.log10(float(acc[1]) / (n / 3) / 255.0 ** 2)
     assert abs(psnr - float(g["metric_psnr"])) < 1e-3
     assert abs(psnr_y - float(g["metric_psnr_y"])) < 1e-3
+
+
+def test_streaming_variant_golden():
+    """reference model/CRFP_test.py MRCF_simple_v18 (one frame per call, fgs regional mask, clear_states)."""
+    from crfp_amd import synth
+    from crfp_amd.model import CRFP
+    g = dict(np.load(os.path.join(GOLDEN, "stream_16x24_t7.npz")))
+    sd = synth.make_state_dict(int(g["weights_seed"]))
+    t, h, w = int(g["t"]), int(g["h"]), int(g["w"])
+    lrs, fvs, mks = synth.make_clip(int(g["clip_seed"]), 1, t, h, w, fv_size=int(g["fv_size"]), sigma_t=10.0)
+    d = dev()
+    m = CRFP.MRCF_simple_v18(device=d, mid_channels=32, split_ratio=3)
+    m.load_state_dict({k: T(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.to(d).eval()
+    L, Fv, M, Fg = T(lrs).to(d), T(fvs).to(d), T(mks).to(d), T(g["fgs"]).to(d)
+    outs = []
+    for i in range(t):
+        if i == int(g["clear_at"]):
+            m.clear_states()
+        outs.append(m(L[:, i:i + 1], Fv[:, i:i + 1], M[:, i:i + 1], Fg[:, i:i + 1]))
+    assert maxdiff(torch.cat(outs, dim=1), g["out"]) < 2e-4

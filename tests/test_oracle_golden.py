@@ -121,3 +121,18 @@ def test_full_forward(name):
     close(orc.compute_flow(P, T(lrs)), g["flows"], 1e-4)
     out = orc.crfp_dsv_forward(P, T(lrs), T(fvs), T(mks), orc.DSVConfig(y_only=y_only))
     close(out, g["out"], 2e-5)
+
+
+def test_streaming_variant_with_regional_mask():
+    """model/CRFP_test.py MRCF_simple_v18: one frame per call, fgs mask, clear_states mid-way."""
+    g = dict(np.load(os.path.join(GOLDEN, "stream_16x24_t7.npz")))
+    sd = synth.make_state_dict(int(g["weights_seed"]))
+    t, h, w = int(g["t"]), int(g["h"]), int(g["w"])
+    lrs, fvs, mks = synth.make_clip(int(g["clip_seed"]), 1, t, h, w, fv_size=int(g["fv_size"]), sigma_t=10.0)
+    so = orc.StreamOracle(orc.load_numpy_state(sd))
+    outs = []
+    for i in range(t):
+        if i == int(g["clear_at"]):
+            so.clear_states()
+        outs.append(so(T(lrs[:, i:i + 1]), T(fvs[:, i:i + 1]), T(mks[:, i:i + 1]), T(g["fgs"][:, i:i + 1])))
+    close(torch.cat(outs, dim=1), g["out"], 2e-5)
