@@ -264,3 +264,32 @@ def test_streaming_variant_golden():
             m.clear_states()
         outs.append(m(L[:, i:i + 1], Fv[:, i:i + 1], M[:, i:i + 1], Fg[:, i:i + 1]))
     assert maxdiff(torch.cat(outs, dim=1), g["out"]) < 2e-4
+
+
+@pytest.mark.parametrize("env", [{"CRFP_CONV_MODE": "f32"}, {"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "0"},
+                                 {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"}, {"CRFP_SPLIT_RPW": "2"}])
+def test_alternate_kernel_paths(env):
+    """Every selectable conv main loop (fp32 MFMA, split-bf16 single-role / input-stationary /
+    warp-specialised, 4- and 8-row tiles) must give the same clip within the parity tolerance."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "run_golden_check.py")],
+                         capture_output=True, text=True, env=e, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("MAXDIFF")]
+    assert line, out.stderr[-2000:]
+    assert float(line[0].split()[1]) < 2e-4
+
+
+def test_config_b_geometry_vs_oracle(orc):
+    """BASELINE config 5 geometry (270x480 -> 2160x3840): partial tiles in y at 2x and 8x resolution."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    P = orc.load_numpy_state(sd)
+    lrs, fvs, mks = synth.make_clip(77, 1, 2, 270, 480, fv_size=144, sigma_t=10.0)
+    m = _model(sd)
+    d = dev()
+    out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    ref = orc.crfp_dsv_forward(P, T(lrs), T(fvs), T(mks))
+    assert maxdiff(out, ref) < 1e-3
