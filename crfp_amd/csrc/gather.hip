@@ -323,35 +323,72 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int n = blockIdx.z;
-    if (px >= W || py >= H) return;
-    const long long pix = (long long)py * W + px;
+    const bool live = px < W && py < H;
+    const int cpx = min(px, W - 1), cpy = min(py, H - 1);
+    const long long pix = (long long)cpy * W + cpx;
     const float4 om = *reinterpret_cast<const float4*>(offmask3 + (long long)n * omb + pix * 4);
     const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
     const int guard = pitch + 16;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(x + (long long)n * xb) - (guard >> 2), 0, plane_b + guard, 0x00020000);
-    const float fy0 = (float)(py - 1), fx0 = (float)(px - 1), fH = (float)H, fW = (float)W;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float fy0 = (float)(cpy - 1), fx0 = (float)(cpx - 1), fH = (float)H, fW = (float)W;
+    // per-row / per-column sampling coordinates exactly as the reference forms them per tap:
+    // (float)(y - 1 + ky) + dy, clamped into [-1, H] (outside that range the sample is 0 either way)
+    float ly[3], lx[3];
+    int iy[3], ix[3];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        // per-tap coordinates exactly as the reference forms them ((float)(y-1+ky) + dy), no sharing of
-        // the fractional part between taps
-        float sy = (fy0 + (float)(tap / 3)) + om.x;
-        float sx = (fx0 + (float)(tap % 3)) + om.y;
-        sy = fminf(fmaxf(sy, -1.0f), fH);
-        sx = fminf(fmaxf(sx, -1.0f), fW);
+    for (int k = 0; k < 3; ++k) {
+        const float sy = fminf(fmaxf((fy0 + (float)k) + om.x, -1.0f), fH);
+        const float sx = fminf(fmaxf((fx0 + (float)k) + om.y, -1.0f), fW);
         const float fy = floorf(sy), fx = floorf(sx);
-        const float ly = sy - fy, lx = sx - fx, hy = 1.0f - ly, hx = 1.0f - lx;
-        const int vo = ((int)fy * PW + (int)fx) * 16 + guard;
-        const f32x4 a = bload(rx, vo, 0), b = bload(rx, vo, 16), c = bload(rx, vo, pitch), d = bload(rx, vo, pitch + 16);
-        const f32x4 v = a * (hy * hx) + b * (hy * lx) + c * (ly * hx) + d * (ly * lx);
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            acc[o] = fmaf(w[(o * 4 + 3) * 9 + tap], v.w,
-                          fmaf(w[(o * 4 + 2) * 9 + tap], v.z,
-                               fmaf(w[(o * 4 + 1) * 9 + tap], v.y, fmaf(w[(o * 4 + 0) * 9 + tap], v.x, acc[o]))));
+        ly[k] = sy - fy; lx[k] = sx - fx;
+        iy[k] = (int)fy; ix[k] = (int)fx;
     }
-    *reinterpret_cast<float4*>(out + (long long)n * ob + pix * 4) =
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // The 9 taps share one (dy,dx): away from the borders their integer parts advance by exactly one
+    // per tap, so the 36 bilinear corners are a 4x4 neighbourhood -> 16 loads instead of 36.  The
+    // fractional parts stay per row / column (float rounding of y-1+ky+dy differs per ky).
+    const bool regular = iy[1] == iy[0] + 1 && iy[2] == iy[0] + 2 && ix[1] == ix[0] + 1 && ix[2] == ix[0] + 2;
+    if (__all(regular)) {
+        const int vo = (iy[0] * PW + ix[0]) * 16 + guard;
+        f32x4 nb[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nb[r][c] = bload(rx, vo, r * pitch + c * 16);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tap = ky * 3 + kx;
+                const float hy = 1.0f - ly[ky], hx = 1.0f - lx[kx];
+                const f32x4 v = nb[ky][kx] * (hy * hx) + nb[ky][kx + 1] * (hy * lx[kx]) + nb[ky + 1][kx] * (ly[ky] * hx) +
+                                nb[ky + 1][kx + 1] * (ly[ky] * lx[kx]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    acc[o] = fmaf(w[(o * 4 + 3) * 9 + tap], v.w,
+                                  fmaf(w[(o * 4 + 2) * 9 + tap], v.z,
+                                       fmaf(w[(o * 4 + 1) * 9 + tap], v.y, fmaf(w[(o * 4 + 0) * 9 + tap], v.x, acc[o]))));
+            }
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tap = ky * 3 + kx;
+                const float hy = 1.0f - ly[ky], hx = 1.0f - lx[kx];
+                const int vo = (iy[ky] * PW + ix[kx]) * 16 + guard;
+                const f32x4 a = bload(rx, vo, 0), b = bload(rx, vo, 16), c = bload(rx, vo, pitch), d = bload(rx, vo, pitch + 16);
+                const f32x4 v = a * (hy * hx) + b * (hy * lx[kx]) + c * (ly[ky] * hx) + d * (ly[ky] * lx[kx]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    acc[o] = fmaf(w[(o * 4 + 3) * 9 + tap], v.w,
+                                  fmaf(w[(o * 4 + 2) * 9 + tap], v.z,
+                                       fmaf(w[(o * 4 + 1) * 9 + tap], v.y, fmaf(w[(o * 4 + 0) * 9 + tap], v.x, acc[o]))));
+            }
+    }
+    if (!live) return;
+    *reinterpret_cast<float4*>(out + (long long)n * ob + ((long long)py * W + px) * 4) =
         make_float4(acc[0] * om.z + bias[0], acc[1] * om.z + bias[1], acc[2] * om.z + bias[2], acc[3] * om.z + bias[3]);
 }
 
