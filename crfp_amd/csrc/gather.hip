@@ -191,17 +191,17 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast
 
 // x is P4 (see above).  VALU budget per sampling position: position (2), clamp (4), floor/frac (6),
 // modulated bilinear weights (6), byte offset (4), 16 FMAs for the 4-channel sample.
-__global__ __launch_bounds__(256, 3) void dcn_g8_kernel(const float* __restrict__ x, long long xb,
+template <int NW, int NP, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __restrict__ x, long long xb,
                                                         const float* __restrict__ offmask, long long omb,
                                                         const float* __restrict__ wpk, const float* __restrict__ bias,
-                                                        float* __restrict__ out, long long ob, int H, int W, int dbg) {
+                                                        float* __restrict__ out, long long ob, int H, int W) {
     // packed DCN weights (36 KB) are shared by the 4 waves of the workgroup through LDS
     __shared__ f32x4 wl[36 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (!(dbg & 32))
-        for (int i = tid; i < 36 * 64; i += 256) wl[i] = reinterpret_cast<const f32x4*>(wpk)[i];
+    for (int i = tid; i < 36 * 64; i += 64 * NW) wl[i] = reinterpret_cast<const f32x4*>(wpk)[i];
     const int j = lane & 31, h = lane >> 5;
-    const int px = blockIdx.x * 32 + j, py = blockIdx.y * 4 + wave;
+    const int px = blockIdx.x * 32 + j, py = blockIdx.y * NW + wave;
     const int n = blockIdx.z;
     const bool valid = px < W && py < H;
     const int cx = min(px, W - 1), cy = min(py, H - 1);
@@ -225,54 +225,50 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_kernel(const float* __restrict_
     f32x4 ob4 = ldg4(om + (18 * h + 1) * plane);
     __syncthreads();
 #pragma unroll 1
-    for (int v = 0; v < ((dbg & 16) ? 1 : 9); ++v) {
+    for (int v = 0; v < 9; ++v) {
         const float dy[4] = {oa.x, oa.z, ob4.x, ob4.z};
         const float dx[4] = {oa.y, oa.w, ob4.y, ob4.w};
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
-        if (v < 8 && !(dbg & 4)) {
+        if (v < 8) {
             m4 = ldg4(om + (36 + 9 * h + v + 1) * plane);
             oa = ldg4(om + (18 * h + 2 * v + 2) * plane);
             ob4 = ldg4(om + (18 * h + 2 * v + 3) * plane);
         }
-        float w00[4], w01[4], w10[4], w11[4];
-        f32x4 q00[4], q01[4], q10[4], q11[4];
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            const int p36 = 4 * v + pp, gi = p36 / 9, tap = p36 - 9 * gi, ky = tap / 3, kx = tap - 3 * ky;
-            // (float)(cy-1) + (float)ky is exact, so this equals the reference's (float)(y - pad + ky) + dy
-            float sy = (fy0 + (float)ky) + dy[pp];
-            float sx = (fx0 + (float)kx) + dx[pp];
-            sy = fminf(fmaxf(sy, -1.0f), fH);
-            sx = fminf(fmaxf(sx, -1.0f), fW);
-            const float fy = floorf(sy), fx = floorf(sx);
-            const float ly = sy - fy, lx = sx - fx;
-            const float a = (1.0f - ly) * mm[pp], b = ly * mm[pp], hx = 1.0f - lx;
-            w00[pp] = a * hx; w01[pp] = a * lx; w10[pp] = b * hx; w11[pp] = b * lx;
-            const int vo = ((int)fy * PW + (int)fx) * 16 + hbase + gi * plane_b;
-            if (dbg & 2) {
-                q00[pp] = q01[pp] = q10[pp] = q11[pp] = f32x4{sy, sx, (float)vo, 2.0f};
-            } else {
-                q00[pp] = bload(rx, vo, 0);
-                q01[pp] = bload(rx, vo, 16);
-                q10[pp] = bload(rx, vo, pitch);
-                q11[pp] = bload(rx, vo, pitch + 16);
-            }
-        }
+        for (int hb = 0; hb < 4; hb += NP) {
+            float w00[NP], w01[NP], w10[NP], w11[NP];
+            f32x4 q00[NP], q01[NP], q10[NP], q11[NP];
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            f32x4 val = q00[pp] * w00[pp];
-            val = __builtin_elementwise_fma(q01[pp], f32x4{w01[pp], w01[pp], w01[pp], w01[pp]}, val);
-            val = __builtin_elementwise_fma(q10[pp], f32x4{w10[pp], w10[pp], w10[pp], w10[pp]}, val);
-            val = __builtin_elementwise_fma(q11[pp], f32x4{w11[pp], w11[pp], w11[pp], w11[pp]}, val);
-            const f32x4 wa = (dbg & 8) ? f32x4{1.0f, 2.0f, 3.0f, (float)lane} : wl[(4 * v + pp) * 64 + lane];
-            if (dbg & 1) {
-                acc[pp] += wa.x * val.x + wa.y * val.y + wa.z * val.z + wa.w * val.w;
-                continue;
+            for (int pi = 0; pi < NP; ++pi) {
+                const int pp = hb + pi;
+                const int p36 = 4 * v + pp, gi = p36 / 9, tap = p36 - 9 * gi, ky = tap / 3, kx = tap - 3 * ky;
+                // (float)(cy-1) + (float)ky is exact, so this equals the reference's (float)(y - pad + ky) + dy
+                float sy = (fy0 + (float)ky) + dy[pp];
+                float sx = (fx0 + (float)kx) + dx[pp];
+                sy = fminf(fmaxf(sy, -1.0f), fH);
+                sx = fminf(fmaxf(sx, -1.0f), fW);
+                const float fy = floorf(sy), fx = floorf(sx);
+                const float ly = sy - fy, lx = sx - fx;
+                const float a = (1.0f - ly) * mm[pp], b = ly * mm[pp], hx = 1.0f - lx;
+                w00[pi] = a * hx; w01[pi] = a * lx; w10[pi] = b * hx; w11[pi] = b * lx;
+                const int vo = ((int)fy * PW + (int)fx) * 16 + hbase + gi * plane_b;
+                q00[pi] = bload(rx, vo, 0);
+                q01[pi] = bload(rx, vo, 16);
+                q10[pi] = bload(rx, vo, pitch);
+                q11[pi] = bload(rx, vo, pitch + 16);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, val.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, val.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, val.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, val.w, acc, 0, 0, 0);
+#pragma unroll
+            for (int pi = 0; pi < NP; ++pi) {
+                f32x4 val = q00[pi] * w00[pi];
+                val = __builtin_elementwise_fma(q01[pi], f32x4{w01[pi], w01[pi], w01[pi], w01[pi]}, val);
+                val = __builtin_elementwise_fma(q10[pi], f32x4{w10[pi], w10[pi], w10[pi], w10[pi]}, val);
+                val = __builtin_elementwise_fma(q11[pi], f32x4{w11[pi], w11[pi], w11[pi], w11[pi]}, val);
+                const f32x4 wa = wl[(4 * v + hb + pi) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, val.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, val.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, val.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, val.w, acc, 0, 0, 0);
+            }
         }
     }
     if (!valid) return;
@@ -305,9 +301,14 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
                   const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s) {
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * (32 + 144 + 72 + 32) * 4.0 + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
-    dim3 grid((W + 31) / 32, (H + 3) / 4, N);
-    static const int dbg = getenv("CRFP_DCN_DBG") ? atoi(getenv("CRFP_DCN_DBG")) : 0;  // ablation switch (timing only)
-    dcn_g8_kernel<<<grid, 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, dbg);
+    static const int variant = getenv("CRFP_DCN_VARIANT") ? atoi(getenv("CRFP_DCN_VARIANT")) : 3;  // tuning knob (A/B: 3 fastest)
+    switch (variant) {
+        case 1: dcn_g8_kernel<8, 2, 6><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        case 2: dcn_g8_kernel<8, 4, 4><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        case 3: dcn_g8_kernel<4, 2, 4><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        case 4: dcn_g8_kernel<8, 1, 8><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        default: dcn_g8_kernel<4, 4, 3><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+    }
     CRFP_CHECK_LAUNCH();
     return 0;
 }
