@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--sigma-t", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-multi-stream", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=3)
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
     args = ap.parse_args()
@@ -201,6 +202,28 @@ def main():
                                   "traffic": {n: pmc_traffic(n) for n in fam if n.startswith("flow_warp") or n.startswith("dcnv2")},
                                   "note": "dcn_3 priced at its compact 2+1 offset/mask channels (162.2 MB/frame), "
                                           "not the 9x-replicated API tensors (516.1 MB/frame)"}
+
+    if rank == 0 and world == 1 and not args.no_multi_stream:
+        # extra (not the headline): independent clips in flight on separate HIP streams of the same GPU fill
+        # each other's tails and pipeline bubbles (BASELINE config 4 runs 4 clips per GPU)
+        from crfp_amd.engine import DSVEngine
+        sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+        ms = {}
+        for C in (2, 4):
+            engs = [DSVEngine(sdt, dev) for _ in range(C)]
+            streams = [torch.cuda.Stream(device=dev) for _ in range(C)]
+            with torch.no_grad():
+                for it in range(1 + min(args.steps, 5)):
+                    if it == 1:
+                        torch.cuda.synchronize()
+                        tm = time.perf_counter()
+                    for e, st in zip(engs, streams):
+                        with torch.cuda.stream(st):
+                            e.forward(lrs, fvs, mks)
+                torch.cuda.synchronize()
+            ms[str(C)] = C * min(args.steps, 5) * t / (time.perf_counter() - tm)
+            del engs
+        result["multi_stream_frames_per_sec"] = ms
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The oracle (CPU port of the reference path; checker / baseline only, never on the product
