@@ -209,6 +209,7 @@ def main():
         from crfp_amd.engine import DSVEngine
         sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
         ms = {}
+        exact = True
         for C in (2, 4):
             engs = [DSVEngine(sdt, dev) for _ in range(C)]
             streams = [torch.cuda.Stream(device=dev) for _ in range(C)]
@@ -217,12 +218,16 @@ def main():
                     if it == 1:
                         torch.cuda.synchronize()
                         tm = time.perf_counter()
+                    outs = []
                     for e, st in zip(engs, streams):
                         with torch.cuda.stream(st):
-                            e.forward(lrs, fvs, mks)
+                            outs.append(e.forward(lrs, fvs, mks))
                 torch.cuda.synchronize()
             ms[str(C)] = C * min(args.steps, 5) * t / (time.perf_counter() - tm)
-            del engs
+            # concurrent kernels must not disturb each other: every in-flight clip == the sequential result, bit for bit
+            exact = exact and all(bool(torch.equal(o, out)) for o in outs)
+            del engs, outs
+        ms["bit_exact_vs_sequential"] = exact
         result["multi_stream_frames_per_sec"] = ms
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrfp_hip.so")
+# CRFP_HIP_LIB points at an alternative build of the same C-ABI (diagnostic variants); default: the in-tree build
+LIB_PATH = os.environ.get("CRFP_HIP_LIB") or os.path.join(_HERE, "libcrfp_hip.so")
 
 NUM_PARAMS = 118
 

@@ -8,6 +8,7 @@
 // produces the new recurrent state (model/CRFP.py:1672-1675), the RGB head + bilinear base
 // (:1678-1683) and dcn_3's shared (dy,dx,mask) triple (:337-347).
 #include "crfp_common.h"
+#include <cstdlib>
 
 namespace crfp {
 

@@ -15,6 +15,7 @@
 //   * fovea blend + LeakyReLU (:1674-1675) and conv_last + bilinear base (:1678-1683) -> epilogues
 #include "crfp_common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -291,7 +292,7 @@ struct Layout {
     // FNet
     size_t fa0, fa1, fp1, fb0, fb1, fp2, fc0, fc1, fp3, fd0, fd1, fu1, fe0, fe1, fu2, ff0, ff1, fu3, fg0, fg1;
     // frame-level
-    size_t xin8, eh, x_hr, prop_a, prop_b, flow2, flow8, prev2, prev2w, prevhrw, carryw, fa, fb, offfeat[3], offmask,
+    size_t xin8[2], eh[2], x_hr[2], prop0[2], prop_a, prop_b, flow2[2], flow8[2], prev2, prev2w, prevhrw, carryw, fa, fb, offfeat[3], offmask,
         aligned, y0, y1, up, poff, g0, g1, g2, om3, al3, z0, z1, feat, fg2, sc_prop, sc_cw, sc_al, sc_up, sc_al3;
     int h1, w1, h2, w2, h3, w3;
 
@@ -324,13 +325,18 @@ struct Layout {
         fu3 = A.take("fnet.u3", nb, 16, 8 * h3, 8 * w3);
         fg0 = A.take("fnet.g0", nb, 8, 8 * h3, 8 * w3);
         fg1 = A.take("fnet.g1", nb, 1, 8 * h3, 8 * w3);
-        xin8 = A.take("xin8", 1, 2, H8, W8);
-        eh = A.take("enc_hr0", 1, 1, H8, W8);
-        x_hr = A.take("x_hr", 1, 1, H8, W8);
+        // state-independent per-frame work (fovea blend, encoder_hr, upsample conv, flow upsampling) is
+        // produced one or two frames ahead on a side stream -> two buffer sets, indexed by frame parity
+        for (int p = 0; p < 2; ++p) {
+            xin8[p] = A.take(p ? "xin8.1" : "xin8", 1, 2, H8, W8);
+            eh[p] = A.take(p ? "enc_hr0.1" : "enc_hr0", 1, 1, H8, W8);
+            x_hr[p] = A.take(p ? "x_hr.1" : "x_hr", 1, 1, H8, W8);
+            prop0[p] = A.take(p ? "prop0.1" : "prop0", 1, 6, H2, W2);
+            flow2[p] = A.take(p ? "flow2.1" : "flow2", 1, 0, H2, W2, 1);
+            flow8[p] = A.take(p ? "flow8.1" : "flow8", 1, 0, H8, W8, 1);
+        }
         prop_a = A.take("prop_a", 1, 6, H2, W2);
         prop_b = A.take("prop_b", 1, 6, H2, W2);
-        flow2 = A.take("flow2", 1, 0, H2, W2, 1);
-        flow8 = A.take("flow8", 1, 0, H8, W8, 1);
         prev2 = A.take("prev2", 1, 8, H2, W2, 0, 1);
         prev2w = A.take("prev2w", 1, 8, H2, W2);
         prevhrw = A.take("prevhrw", 1, 1, H8, W8);
@@ -362,6 +368,28 @@ struct Layout {
     }
     size_t bytes() const { return A.cur; }
 };
+
+// One non-blocking side stream + an event pool per process: state-independent work of upcoming frames is
+// forked onto it (fork/join through events recorded on the caller's stream, so the call stays ordered
+// on `stream` and remains graph-capturable).
+struct SideStream {
+    hipStream_t s = nullptr;
+    std::vector<hipEvent_t> ev;
+    bool ok = true;
+    hipEvent_t event(size_t i) {
+        while (ev.size() <= i) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ok = false; return nullptr; }
+            ev.push_back(e);
+        }
+        return ev[i];
+    }
+};
+static SideStream& side_stream() {
+    static thread_local SideStream ss;
+    if (!ss.s && ss.ok && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
+    return ss;
+}
 
 struct Runner {
     const Model& M;
@@ -468,23 +496,33 @@ struct Runner {
     }
 
     // one iteration of the recurrent loop (reference model/CRFP.py:1555-1684)
-    void frame(bool first, const float* lr, const float* fv, const uint8_t* mk, const float* flow_lr_q4,
-               const float* x_lr_i, float* out, const uint8_t* fg = nullptr) {
+    // state-independent part of a frame (reference model/CRFP.py:1538-1547,1560,1565-1566): buffer set `par`
+    void frame_pre(int par, bool first, const float* lr, const float* fv, const uint8_t* mk, const float* flow_lr_q4,
+                   const float* x_lr_i) {
+        const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
+        const long long P8q = (long long)H8 * W8 * 4;
+        RUN(launch_hr_prep(lr, fv, mk, F(L.xin8[par]), h, w, s));
+        narrow(IT_EH0, H8, W8, {F(L.xin8[par]), F(L.xin8[par]) + P8q}, F(L.eh[par]));
+        narrow(IT_EH1, H8, W8, {F(L.eh[par])}, F(L.x_hr[par]));
+        mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0[par]), 0, 0, 6}}, H2, W2);
+        if (!first) {
+            RUN(launch_upflow(flow_lr_q4, 0, F(L.flow2[par]), 0, 1, h, w, 2, s));
+            RUN(launch_upflow(flow_lr_q4, 0, F(L.flow8[par]), 0, 1, h, w, 8, s));
+        }
+    }
+
+    // recurrent part of a frame (reference model/CRFP.py:1562-1684)
+    void frame(int par, bool first, const uint8_t* mk, float* out, const uint8_t* fg = nullptr) {
         const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         const long long P8q = (long long)H8 * W8 * 4, P2q = (long long)H2 * W2 * 4;
         const long long P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;   // padded (P4) plane at 2x resolution
-        RUN(launch_hr_prep(lr, fv, mk, F(L.xin8), h, w, s));
-        narrow(IT_EH0, H8, W8, {F(L.xin8), F(L.xin8) + P8q}, F(L.eh));
-        narrow(IT_EH1, H8, W8, {F(L.eh)}, F(L.x_hr));
-        float* prop = F(L.prop_a);
-        float* prop_next = F(L.prop_b);
-        mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{prop, 0, 0, 6}}, H2, W2);
+        float* prop = F(L.prop0[par]);
+        float* prop_next = F(L.prop_a);
+        float* prop_other = F(L.prop_b);
         float* carry = F(L.carry);
         if (!first) {
-            float* flow2 = F(L.flow2);
-            float* flow8 = F(L.flow8);
-            RUN(launch_upflow(flow_lr_q4, 0, flow2, 0, 1, h, w, 2, s));
-            RUN(launch_upflow(flow_lr_q4, 0, flow8, 0, 1, h, w, 8, s));
+            float* flow2 = F(L.flow2[par]);
+            float* flow8 = F(L.flow8[par]);
             mfma(IT_DOWN, 1, H2, W2, {{F(L.state_hr), 0, 1}}, {{F(L.prev2), 0, 0, 8, 1}});
             RUN(launch_flow_warp_q4(F(L.prev2), 0, flow2, 0, F(L.prev2w), 0, 1, 8, H2, W2, 0, 1, s));
             RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, 1, s));
@@ -516,7 +554,8 @@ struct Runner {
                 mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
                 mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2qp, 0, 6, 8, 1}}, 0, 0,
                      F(L.y0), 0);
-                std::swap(prop, prop_next);
+                prop = prop_next;
+                std::swap(prop_next, prop_other);
                 offprev = f;
             }
             mfma(IT_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up), 0, 0, 1}}, H8, W8);
@@ -539,15 +578,16 @@ struct Runner {
                 mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
                 mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2qp, 0, 6, 8, 1}}, 0, 0,
                      F(L.y0), 0);
-                std::swap(prop, prop_next);
+                prop = prop_next;
+                std::swap(prop_next, prop_other);
             }
             mfma(IT_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up), 0, 0, 1}}, H8, W8);
             narrow(IT_R3_0F, H8, W8, {F(L.up)}, F(L.z0));
         }
         narrow(IT_R3_1, H8, W8, {F(L.z0)}, F(L.z1));
         narrow(IT_R3_2, H8, W8, {F(L.z1)}, F(L.feat), F(L.z0));
-        narrow(IT_TTTF, H8, W8, {F(L.feat), F(L.x_hr)}, F(L.state_hr), nullptr, nullptr, nullptr, mk, 0, 1);
-        narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, F(L.xin8) + P8q, nullptr, 1, 0);
+        narrow(IT_TTTF, H8, W8, {F(L.feat), F(L.x_hr[par])}, F(L.state_hr), nullptr, nullptr, nullptr, mk, 0, 1);
+        narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, F(L.xin8[par]) + P8q, nullptr, 1, 0);
     }
 };
 
@@ -630,13 +670,49 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
     Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     const long long lr_f = 3LL * h * w, hr_px = 64LL * h * w;
     const int co = y_only ? 1 : 3;
-    R.reset_state();
-    if (t > 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
-    R.encode_lr(t, lrs, lr_f);
     const long long xq = 8LL * h * w * 4, fq = 1LL * h * w * 4;
-    for (int i = 0; i < t && !R.rc; ++i)
-        R.frame(i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
-                i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq, out + (long long)i * co * hr_px);
+    const bool use_side = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);
+    SideStream& ss = side_stream();
+    hipStream_t main_s = (hipStream_t)stream;
+    if (!use_side || !ss.ok || prof_enabled()) {
+        // single-stream schedule (also used while per-kernel timing is on: events bracket launches per stream)
+        R.reset_state();
+        if (t > 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
+        R.encode_lr(t, lrs, lr_f);
+        for (int i = 0; i < t && !R.rc; ++i) {
+            R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
+                        i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq);
+            R.frame(i & 1, i == 0, mks + i * hr_px, out + (long long)i * co * hr_px);
+        }
+        return R.rc;
+    }
+    // two-stream schedule: the side stream runs FNet and the state-independent part of every frame up to two
+    // frames ahead of the recurrent chain on the caller's stream
+    auto fail = [&](const char* what) { set_error("dsv_forward_clip: %s failed", what); return 1; };
+    hipEvent_t ev_start = ss.event(0), ev_xlr = ss.event(1);
+    if (!ss.ok) return fail("hipEventCreate");
+    if (hipEventRecord(ev_start, main_s) != hipSuccess || hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
+    R.reset_state();
+    R.encode_lr(t, lrs, lr_f);
+    if (hipEventRecord(ev_xlr, main_s) != hipSuccess) return fail("record");
+    R.s = ss.s;
+    if (t > 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
+    if (hipStreamWaitEvent(ss.s, ev_xlr, 0) != hipSuccess) return fail("wait");
+    for (int i = 0; i < t && !R.rc; ++i) {
+        hipEvent_t pre_done = ss.event(2 + 2 * i), main_done = ss.event(3 + 2 * i);
+        if (!ss.ok) return fail("hipEventCreate");
+        // side: pre-work of frame i into set i&1 (free once the recurrent part of frame i-2 is done)
+        R.s = ss.s;
+        if (i >= 2 && hipStreamWaitEvent(ss.s, ss.event(3 + 2 * (i - 2)), 0) != hipSuccess) return fail("wait");
+        R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
+                    i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq);
+        if (hipEventRecord(pre_done, ss.s) != hipSuccess) return fail("record");
+        // main: recurrent part of frame i
+        R.s = main_s;
+        if (hipStreamWaitEvent(main_s, pre_done, 0) != hipSuccess) return fail("wait");
+        R.frame(i & 1, i == 0, mks + i * hr_px, out + (long long)i * co * hr_px);
+        if (hipEventRecord(main_done, main_s) != hipSuccess) return fail("record");
+    }
     return R.rc;
 }
 
@@ -651,7 +727,8 @@ int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const
     if (first) R.reset_state();
     if (!first) R.fnet(1, lr, 0, lr_prev, 0);
     R.encode_lr(1, lr, 0);
-    R.frame(first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr), out, fg);
+    R.frame_pre(0, first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr));
+    R.frame(0, first != 0, mk, out, fg);
     return R.rc;
 }
 

@@ -267,7 +267,7 @@ def test_streaming_variant_golden():
 
 
 @pytest.mark.parametrize("env", [{"CRFP_CONV_MODE": "f32"}, {"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "0"},
-                                 {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"}, {"CRFP_SPLIT_RPW": "2"}])
+                                 {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"}, {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SIDE_STREAM": "0"}])
 def test_alternate_kernel_paths(env):
     """Every selectable conv main loop (fp32 MFMA, split-bf16 single-role / input-stationary /
     warp-specialised, 4- and 8-row tiles) must give the same clip within the parity tolerance."""
@@ -293,3 +293,46 @@ def test_config_b_geometry_vs_oracle(orc):
     out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
     ref = orc.crfp_dsv_forward(P, T(lrs), T(fvs), T(mks))
     assert maxdiff(out, ref) < 1e-3
+
+
+def _full_clip(seed, t):
+    from crfp_amd import synth
+    lrs, fvs, mks = synth.make_clip(seed, 1, t, 180, 320, fv_size=96, sigma_t=10.0)
+    d = dev()
+    return T(lrs).to(d), T(fvs).to(d), T(mks).to(d)
+
+
+def test_two_stream_schedule_is_bit_exact():
+    """crfp_dsv_forward_clip forks state-independent work onto an internal side stream; the result must not
+    depend on the schedule (this caught the packed-FP32 / bf16-MFMA co-residency hazard)."""
+    from crfp_amd import synth
+    m = _model(synth.make_state_dict(7))
+    clip = _full_clip(1234, 7)
+    os.environ["CRFP_SIDE_STREAM"] = "0"
+    try:
+        ref = m(lrs=clip[0], fvs=clip[1], mks=clip[2]).clone()
+    finally:
+        os.environ.pop("CRFP_SIDE_STREAM")
+    for _ in range(4):
+        out = m(lrs=clip[0], fvs=clip[1], mks=clip[2])
+        torch.cuda.synchronize()
+        assert maxdiff(out, ref) == 0.0
+
+
+def test_concurrent_clips_on_two_streams_are_bit_exact():
+    """Two engines, two caller streams, clips in flight together == the same clips run one after the other."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    models = [_model(sd), _model(sd)]
+    clips = [_full_clip(100, 4), _full_clip(101, 4)]
+    refs = [models[k](lrs=clips[k][0], fvs=clips[k][1], mks=clips[k][2]).clone() for k in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(4):
+        outs = [None, None]
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs[k] = models[k](lrs=clips[k][0], fvs=clips[k][1], mks=clips[k][2])
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert maxdiff(outs[k], refs[k]) == 0.0
