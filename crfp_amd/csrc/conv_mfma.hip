@@ -132,38 +132,97 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
 
 // Epilogue shared by the fp32-MFMA and the split-bf16-MFMA main loops (identical C/D lane map):
 // bias, activation, scale, residual, layout-aware store.
-// flpre: flow vectors of this lane's PT pixels preloaded by the caller (ST_OFFMASK), or null.  Inside a
-// loop over cout tiles a vector load here would force s_waitcnt vmcnt(0), i.e. drain every store of the
-// previous tile's epilogue (vmcnt is in-order and counts stores on CDNA4): 12k cycles per tile measured.
-// For the same reason the bias comes through wave-uniform (scalar) loads, selected per lane half.
-template <int CT, int PT, int RPW>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[CT][PT], int n, int T0, int tx0, int ty0,
-                                              int wave, int j, int h, const float2* flpre = nullptr) {
-    const int H = a.H, W = a.W;
-    const int nrows = conv_packed_rows(a.cout, a.store, a.ps_r);
-    const int ncq = (nrows + 3) >> 2;
-    const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+//
+// Everything that comes from the kernel arguments (destinations, strides, activation, store mode) is read
+// ONCE into registers and the store mode is a template parameter: the first version re-read descriptors through
+// scalar loads inside the (pt, g, dst) loops and carried every mode's code -- 7 300 ISA lines, 146 branches,
+// 15 k cycles per workgroup (38 % of a 32->32 conv's workgroup lifetime, measured with s_memtime stamps).
+// Bias quads and the residual are loaded up front so that the stores leave back to back.
+//
+// VBIAS: bias through per-lane vector loads (single epilogue per workgroup).  Inside a loop over cout tiles a vector
+// load would force s_waitcnt vmcnt(0), i.e. drain every store of the previous tile's epilogue (vmcnt is in-order and
+// counts stores on CDNA4: 12k cycles per tile measured); those callers pass VBIAS=false (wave-uniform scalar loads,
+// selected per lane half) and preload the flow vectors of the lane's PT pixels (flpre, ST_OFFMASK).
+struct EpiCtx {
+    int H, W, cout, ncq, act, store, n_off_quads, dstH, dstW, lr;
+    float slope, post;
+    const float4* bp;
+    const float* rp;
+    const float* flp;
+    float* dp[CRFP_MAX_DST];
+    long long dplane[CRFP_MAX_DST];
+    int dpitch[CRFP_MAX_DST], dq0[CRFP_MAX_DST], dq1[CRFP_MAX_DST];
+};
+
+__device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
+    EpiCtx e;
+    e.H = a.H; e.W = a.W; e.cout = a.cout; e.act = a.act; e.store = a.store;
+    e.ncq = (conv_packed_rows(a.cout, a.store, a.ps_r) + 3) >> 2;
+    e.n_off_quads = a.n_off_quads; e.dstH = a.dstH; e.dstW = a.dstW;
+    e.lr = a.ps_r == 4 ? 2 : 1;                           // ST_PS: r in {2, 4} (checked by the launcher)
+    // NONE / RELU / LRELU(0.1) as max(v,0) + slope*min(v,0): exact (one term is 0), branch-free
+    e.slope = a.act == CRFP_ACT_RELU ? 0.0f : (a.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    e.post = a.post_scale;
+    e.bp = reinterpret_cast<const float4*>(a.bpk);
+    e.rp = a.resid ? a.resid + (long long)n * a.resid_bstride : nullptr;
+    e.flp = a.flow + (long long)n * a.flow_bstride;
+#pragma unroll
+    for (int d = 0; d < CRFP_MAX_DST; ++d) {
+        const bool on = d < a.ndst;
+        e.dp[d] = a.dst[d].p + (long long)n * a.dst[d].bstride;
+        e.dpitch[d] = a.W + a.dst[d].pad;
+        e.dplane[d] = (long long)(a.H + a.dst[d].pad) * e.dpitch[d] * 4;
+        e.dq0[d] = on ? a.dst[d].q0 : 0;
+        e.dq1[d] = on ? a.dst[d].q1 : 0;
+    }
+    return e;
+}
+
+template <int CT, int PT, int RPW, int STORE, bool VBIAS, bool SLOWACT>
+__device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[CT][PT], int T0, int tx0, int ty0,
+                                                int wave, int j, int h, const float2* flpre) {
+    const int H = e.H, W = e.W;
+    float4 bb[CT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cq0 = (T0 + ct) * 8 + 2 * g;          // wave-uniform
+            if (VBIAS) {
+                bb[ct][g] = e.bp[cq0 + h];
+            } else {
+                const float4 b0 = e.bp[cq0], b1 = e.bp[cq0 + 1];
+                bb[ct][g] = h ? b1 : b0;
+            }
+        }
+
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int y = ty0 + wave * RPW + (pt >> 1), x = tx0 + (pt & 1) * 32 + j;
         if (y >= H || x >= W) continue;
         float2 fl = make_float2(0.0f, 0.0f);
-        if (a.store == ST_OFFMASK)
-            fl = flpre ? flpre[pt]
-                       : *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + ((long long)y * W + x) * 2);
+        if (STORE == ST_OFFMASK) fl = flpre ? flpre[pt] : *reinterpret_cast<const float2*>(e.flp + ((long long)y * W + x) * 2);
+        float4 rr[CT][4];
+        if (e.rp) {   // wave-uniform; all residual quads of this pixel in flight together, before the first store
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cq = min((T0 + ct) * 8 + 2 * g + h, e.ncq - 1);
+                    rr[ct][g] = *reinterpret_cast<const float4*>(e.rp + (((long long)cq * H + y) * W + x) * 4);
+                }
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cq0 = (T0 + ct) * 8 + 2 * g;      // wave-uniform: both halves' bias rows via s_load
-                const int cq = cq0 + h;
-                if (cq >= ncq) continue;
-                const float4 bb0 = bp[cq0], bb1 = bp[cq0 + 1];
-                const float4 bb = h ? bb1 : bb0;
-                float v[4] = {acc[ct][pt][4 * g + 0] + bb.x, acc[ct][pt][4 * g + 1] + bb.y,
-                              acc[ct][pt][4 * g + 2] + bb.z, acc[ct][pt][4 * g + 3] + bb.w};
-                if (a.store == ST_OFFMASK) {
-                    if (cq < a.n_off_quads) {  // (dy,dx) pairs: 10*tanh(.) + flow flipped to (y,x)
+                const int cq = (T0 + ct) * 8 + 2 * g + h;
+                if (cq >= e.ncq) continue;
+                const float4 b = bb[ct][g];
+                float v[4] = {acc[ct][pt][4 * g + 0] + b.x, acc[ct][pt][4 * g + 1] + b.y,
+                              acc[ct][pt][4 * g + 2] + b.z, acc[ct][pt][4 * g + 3] + b.w};
+                if (STORE == ST_OFFMASK) {
+                    if (cq < e.n_off_quads) {  // (dy,dx) pairs: 10*tanh(.) + flow flipped to (y,x)
                         v[0] = 10.0f * fast_tanh(v[0]) + fl.y;
                         v[1] = 10.0f * fast_tanh(v[1]) + fl.x;
                         v[2] = 10.0f * fast_tanh(v[2]) + fl.y;
@@ -172,43 +231,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[C
 #pragma unroll
                         for (int c = 0; c < 4; ++c) v[c] = fast_sigmoid(v[c]);
                     }
+                } else if (SLOWACT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], e.act) * e.post;
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], a.act) * a.post_scale;
+                    for (int c = 0; c < 4; ++c) v[c] = (fmaxf(v[c], 0.0f) + e.slope * fminf(v[c], 0.0f)) * e.post;
                 }
-                if (a.store != ST_PS) {  // zero the padding components of a ragged last quad
+                if (STORE != ST_PS) {  // zero the padding components of a ragged last quad
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (4 * cq + c >= a.cout) v[c] = 0.0f;
+                        if (4 * cq + c >= e.cout) v[c] = 0.0f;
                 }
-                if (a.resid) {
-                    const float4 r = *reinterpret_cast<const float4*>(
-                        a.resid + (long long)n * a.resid_bstride + (((long long)cq * H + y) * W + x) * 4);
-                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-                }
-                if (a.store == ST_Q4 || a.store == ST_OFFMASK) {
+                if (e.rp) { v[0] += rr[ct][g].x; v[1] += rr[ct][g].y; v[2] += rr[ct][g].z; v[3] += rr[ct][g].w; }
+                if (STORE == ST_Q4 || STORE == ST_OFFMASK) {
 #pragma unroll
                     for (int d = 0; d < CRFP_MAX_DST; ++d)
-                        if (d < a.ndst && cq >= a.dst[d].q0 && cq < a.dst[d].q1)
-                            *reinterpret_cast<float4*>(a.dst[d].p + (long long)n * a.dst[d].bstride +
-                                                       (((long long)(cq - a.dst[d].q0) * (H + a.dst[d].pad) + y) *
-                                                            (W + a.dst[d].pad) + x) * 4) =
+                        if (cq >= e.dq0[d] && cq < e.dq1[d])
+                            *reinterpret_cast<float4*>(e.dp[d] + (cq - e.dq0[d]) * e.dplane[d] + ((long long)y * e.dpitch[d] + x) * 4) =
                                 make_float4(v[0], v[1], v[2], v[3]);
-                } else if (a.store == ST_PS) {
-                    const int r = a.ps_r, r2 = r * r;
-                    const int Q = cq / r2, s = cq - Q * r2, i = s / r, jj = s - i * r;
-                    *reinterpret_cast<float4*>(a.dst[0].p + (long long)n * a.dst[0].bstride +
-                                               (((long long)Q * a.dstH + y * r + i) * a.dstW + x * r + jj) * 4) =
+                } else if (STORE == ST_PS) {
+                    const int lr = e.lr;
+                    const int Q = cq >> (2 * lr), sidx = cq & ((1 << (2 * lr)) - 1), i = sidx >> lr, jj = sidx & ((1 << lr) - 1);
+                    *reinterpret_cast<float4*>(e.dp[0] + (((long long)Q * e.dstH + (y << lr) + i) * e.dstW + (x << lr) + jj) * 4) =
                         make_float4(v[0], v[1], v[2], v[3]);
                 } else {  // ST_NCHW
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int ch = 4 * cq + c;
-                        if (ch < a.cout)
-                            a.dst[0].p[(long long)n * a.dst[0].bstride + ((long long)ch * H + y) * W + x] = v[c];
+                        if (ch < e.cout) e.dp[0][((long long)ch * H + y) * W + x] = v[c];
                     }
                 }
             }
+    }
+}
+
+// e: epi_ctx() made once per workgroup (outside any loop over cout tiles)
+template <int CT, int PT, int RPW, bool VBIAS = true>
+__device__ __forceinline__ void conv_epilogue(const EpiCtx& e, f32x16 (&acc)[CT][PT], int T0, int tx0, int ty0,
+                                              int wave, int j, int h, const float2* flpre = nullptr) {
+    const bool slow = e.act == CRFP_ACT_TANH || e.act == CRFP_ACT_SIGMOID;   // API only; the engine never uses them here
+    switch (e.store) {   // wave-uniform
+        case ST_Q4:
+            if (slow) conv_epilogue_t<CT, PT, RPW, ST_Q4, VBIAS, true>(e, acc, T0, tx0, ty0, wave, j, h, flpre);
+            else conv_epilogue_t<CT, PT, RPW, ST_Q4, VBIAS, false>(e, acc, T0, tx0, ty0, wave, j, h, flpre);
+            break;
+        case ST_PS: conv_epilogue_t<CT, PT, RPW, ST_PS, VBIAS, false>(e, acc, T0, tx0, ty0, wave, j, h, flpre); break;
+        case ST_OFFMASK: conv_epilogue_t<CT, PT, RPW, ST_OFFMASK, VBIAS, false>(e, acc, T0, tx0, ty0, wave, j, h, flpre); break;
+        default:
+            if (slow) conv_epilogue_t<CT, PT, RPW, ST_NCHW, VBIAS, true>(e, acc, T0, tx0, ty0, wave, j, h, flpre);
+            else conv_epilogue_t<CT, PT, RPW, ST_NCHW, VBIAS, false>(e, acc, T0, tx0, ty0, wave, j, h, flpre);
+            break;
     }
 }
 
@@ -325,7 +398,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     }
 #undef CRFP_ISSUE_LOADS
 
-    conv_epilogue<CT, PT, RPW>(a, acc, n, T0, tx0, ty0, wave, j, h);
+    const EpiCtx ec = epi_ctx(a, n);
+    conv_epilogue<CT, PT, RPW>(ec, acc, T0, tx0, ty0, wave, j, h);
 }
 
 // ================================================================ split-bf16 ("bf16x6") main loop
@@ -412,6 +486,7 @@ __device__ __forceinline__ void load_quad_batch_v(f32x4 (&r)[NIN], const ConvSrc
 
 template <int CT, int RPW>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a) {
+    const long long t_entry = __builtin_amdgcn_s_memtime();
     constexpr int TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
     constexpr int NEL = LH * LW;                 // halo pixels
     constexpr int NIN = (NEL + 255) / 256;       // halo pixels per thread; each carries the chunk's 4 quads
@@ -544,11 +619,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
     if (a.stamps) {
         const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t;
         if (tid == 0) {
-            long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-            o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD;
+            long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+            o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD; o[4] = t_entry; o[5] = t;
         }
     }
-    conv_epilogue<CT, PT, RPW>(a, acc, n, T0, tx0, ty0, wave, j, h);
+    const EpiCtx ec = epi_ctx(a, n);
+    conv_epilogue<CT, PT, RPW>(ec, acc, T0, tx0, ty0, wave, j, h);
+    if (a.stamps) {
+        const long long ti = __builtin_amdgcn_s_memtime();      // epilogue issued (stores in flight)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            a.stamps[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ti;
+            a.stamps[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memtime();
+        }
+    }
 }
 
 // ---------------------------------------------------------------- input-stationary variant (short K, many couts)
@@ -616,6 +700,14 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void conv3x3_split_is_kernel(const 
     long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
     if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tA += t - t0; t0 = t; }
     f32x16 acc[1][PT];
+    const EpiCtx ec = epi_ctx(a, n);
+    float2 flpre[PT];   // flow of this lane's pixels (ST_OFFMASK): loaded here, not between two epilogues' stores
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int y = min(ty0 + wave * RPW + (pt >> 1), H - 1), x = min(tx0 + (pt & 1) * 32 + j, W - 1);
+        flpre[pt] = a.store == ST_OFFMASK ? *reinterpret_cast<const float2*>(ec.flp + ((long long)y * W + x) * 2)
+                                          : make_float2(0.0f, 0.0f);
+    }
     for (int step = 0; step < nsteps; ++step) {
         const int ch = step % NCH, ct = step / NCH;
         if (ch == 0) {
@@ -653,7 +745,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void conv3x3_split_is_kernel(const 
             }
         }
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
-        if (ch == NCH - 1) conv_epilogue<1, PT, RPW>(a, acc, n, ct, tx0, ty0, wave, j, h);
+        if (ch == NCH - 1) conv_epilogue<1, PT, RPW, false>(ec, acc, ct, tx0, ty0, wave, j, h, flpre);
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
     }
     if (a.stamps && tid == 0) {
@@ -820,6 +912,7 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
     // ---------------------------------------------------------------- compute role: wave = output row
     const int j = lane & 31, h = lane >> 5;
     f32x16 acc[1][2];
+    const EpiCtx ec = epi_ctx(a, n);
     float2 flpre[2] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
     if (a.store == ST_OFFMASK) {
         const int y = min(ty0 + wave, H - 1);
@@ -862,14 +955,14 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
             }
         }
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
-        if (IS && ch == nchunks - 1) conv_epilogue<1, 2, 1>(a, acc, n, step / nchunks, tx0, ty0, wave, j, h, flpre);
+        if (IS && ch == nchunks - 1) conv_epilogue<1, 2, 1, false>(ec, acc, step / nchunks, tx0, ty0, wave, j, h, flpre);
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
     }
     if (a.stamps && tid == 0) {
         long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4;
         o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD;
     }
-    if (!IS) conv_epilogue<1, 2, 1>(a, acc, n, T0, tx0, ty0, wave, j, h, flpre);
+    if (!IS) conv_epilogue<1, 2, 1, false>(ec, acc, T0, tx0, ty0, wave, j, h, flpre);
 }
 
 // split weight pack: wsplit bf16 index =
@@ -971,6 +1064,10 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     if (a.kq & 1 || a.kq < 2 || a.ctiles < 1 || a.nsrc < 1 || a.nsrc > CRFP_MAX_SRC) {
         set_error("conv_mfma %s: bad plan (kq=%d ctiles=%d nsrc=%d)", name, a.kq, a.ctiles, a.nsrc);
         return CRFP_E_BADARG;
+    }
+    if (a.store == ST_PS && (a.ps_r != 2 && a.ps_r != 4 || a.act == CRFP_ACT_TANH || a.act == CRFP_ACT_SIGMOID)) {
+        set_error("conv_mfma %s: pixel-shuffle store supports r in {2, 4} with none/relu/lrelu (r=%d act=%d)", name, a.ps_r, a.act);
+        return CRFP_E_UNSUPPORTED;
     }
     static const int max_ct = getenv("CRFP_CONV_CT") ? atoi(getenv("CRFP_CONV_CT")) : 2;  // tuning knob
     bool ct2 = a.ctiles % 2 == 0 && max_ct >= 2;
