@@ -428,6 +428,57 @@ __device__ __forceinline__ void split_bf16x8(const f32x4& lo, const f32x4& hi, b
     }
 }
 
+// ---- split-fp16 ("f16x3"): x = x0 + 2^-11 * x1s with x0 = fp16(x), x1s = fp16((x - x0) * 2^11) (the subtraction and the
+// scaling are exact; the scale keeps the residual out of fp16's subnormal range, where the MFMA would flush it).
+// Product = x0w0 + 2^-11 * (x0w1s + x1sw0): two fp32 accumulators (hi, lo), THREE MFMAs per 16-channel tap instead of
+// six, two LDS images per operand instead of three, and the dropped term x1w1 is <= 2^-22 relative.  CPU emulation
+// of the whole 7-frame clip: max |err| 2.2e-6 vs 2.5e-6 for bf16x6 (both at the fp32 summation-order noise floor);
+// without the scaling 6.7e-6 if subnormals survive and 1.0e-3 if they are flushed.  Needs |x| < 65504.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float F16_RES_SCALE = 2048.0f;
+
+__device__ __forceinline__ void split_f16x8(const f32x4& lo, const f32x4& hi, bf16x8& p0, bf16x8& p1) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    f16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        a[i] = h;
+        b[i] = (_Float16)((x[i] - (float)h) * F16_RES_SCALE);
+    }
+    p0 = __builtin_bit_cast(bf16x8, a);   // LDS / register containers are typed bf16x8 for both schemes
+    p1 = __builtin_bit_cast(bf16x8, b);
+}
+
+// NP = 3: bf16x6, NP = 2: f16x3.  p[] receives the NP images of 8 channels.
+template <int NP>
+__device__ __forceinline__ void split_parts(const f32x4& lo, const f32x4& hi, bf16x8 (&p)[NP]);
+template <>
+__device__ __forceinline__ void split_parts<3>(const f32x4& lo, const f32x4& hi, bf16x8 (&p)[3]) { split_bf16x8(lo, hi, p[0], p[1], p[2]); }
+template <>
+__device__ __forceinline__ void split_parts<2>(const f32x4& lo, const f32x4& hi, bf16x8 (&p)[2]) { split_f16x8(lo, hi, p[0], p[1]); }
+
+// all products of one (tap, 32-pixel tile): w[] / b[] are the NP images of the A / B fragments
+template <int NP>
+__device__ __forceinline__ void split_mfma(f32x16& hi, f32x16& lo, const bf16x8 (&w)[NP], const bf16x8 (&b)[NP]) {
+    if (NP == 3) {
+        f32x16 c = hi;
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[NP - 1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[NP - 1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[0], c, 0, 0, 0);
+        hi = c;
+    } else {
+        const f16x8 w0 = __builtin_bit_cast(f16x8, w[0]), w1 = __builtin_bit_cast(f16x8, w[1]);
+        const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, hi, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, lo, 0, 0, 0);
+    }
+}
+
 __device__ __forceinline__ f32x4 mask_quad(const f32x4& v, int m) {
     return f32x4{(m & 1) ? v.x : 0.0f, (m & 2) ? v.y : 0.0f, (m & 4) ? v.z : 0.0f, (m & 8) ? v.w : 0.0f};
 }
@@ -484,15 +535,16 @@ __device__ __forceinline__ void load_quad_batch_v(f32x4 (&r)[NIN], const ConvSrc
     }
 }
 
-template <int CT, int RPW>
-__global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a) {
+template <int CT, int RPW, int NP>
+__global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void conv3x3_split_kernel(const ConvArgs a) {
     const long long t_entry = __builtin_amdgcn_s_memtime();
     constexpr int TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
     constexpr int NEL = LH * LW;                 // halo pixels
     constexpr int NIN = (NEL + 255) / 256;       // halo pixels per thread; each carries the chunk's 4 quads
-    __shared__ bf16x8 tile[3][2][NEL];           // [split part][quad pair][halo pixel], 16 B each
-    __shared__ bf16x8 wlds[CT][27 * 64];         // [cout tile][(tap, part)][lane]: this chunk's A fragments
-    constexpr int NWS = (CT * 27 * 64 + 255) / 256;
+    constexpr int WPC = 9 * NP * 64;             // weight vectors per (cout tile, chunk)
+    __shared__ bf16x8 tile[NP][2][NEL];          // [split part][quad pair][halo pixel], 16 B each
+    __shared__ bf16x8 wlds[CT][WPC];             // [cout tile][(tap, part)][lane]: this chunk's A fragments
+    constexpr int NWS = (CT * WPC + 255) / 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
@@ -515,16 +567,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
         cgx[t] = min(max(gx, 0), W - 1);
     }
 
-    f32x16 acc[CT][PT];
+    f32x16 acc[CT][PT], acl[CT][PT];   // acl: the 2^-11-scaled partial sums of the f16x3 scheme (dead for bf16x6)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
+            for (int e = 0; e < 16; ++e) { acc[ct][pt][e] = 0.0f; acl[ct][pt][e] = 0.0f; }
 
     const int nchunks = a.kq >> 2;
-    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit);
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(NP == 3 ? a.wsplit : a.wsplit16);
     f32x4 rq0[NIN], rq1[NIN], rq2[NIN], rq3[NIN];   // the chunk's 4 quads of each of this thread's halo pixels
     bf16x8 rws[NWS];   // weights ride in the same prefetch batch: no global load (vmcnt is in-order!) may sit
                        // inside the MFMA loop, or every tap would wait for the whole input prefetch to land
@@ -551,9 +603,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
             rq3[t] = *reinterpret_cast<const f32x4*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
         }                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < NWS; ++k) {                                                 \
-            const int idx = min(tid + 256 * k, CT * 1728 - 1);                                            \
-            const int ct = idx / 1728, rem = idx - ct * 1728;                                             \
-            rws[k] = wp[(((long long)(T0 + ct) * nchunks + (CH)) * 27) * 64 + rem];                       \
+            const int idx = min(tid + 256 * k, CT * WPC - 1);                                             \
+            const int ct = idx / WPC, rem = idx - ct * WPC;                                               \
+            rws[k] = wp[((long long)(T0 + ct) * nchunks + (CH)) * WPC + rem];                             \
         }                                                                                                 \
     }
 
@@ -571,17 +623,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
         for (int t = 0; t < NIN; ++t) {
             const int idx = tid + 256 * t;
             if (idx < NEL) {
-                bf16x8 p0, p1, p2;
-                split_bf16x8(mask_quad(rq0[t], sval[t] ? m0 : 0), mask_quad(rq1[t], sval[t] ? m1 : 0), p0, p1, p2);
-                tile[0][0][idx] = p0; tile[1][0][idx] = p1; tile[2][0][idx] = p2;
-                split_bf16x8(mask_quad(rq2[t], sval[t] ? m2 : 0), mask_quad(rq3[t], sval[t] ? m3 : 0), p0, p1, p2);
-                tile[0][1][idx] = p0; tile[1][1][idx] = p1; tile[2][1][idx] = p2;
+                bf16x8 pp[NP];
+                split_parts<NP>(mask_quad(rq0[t], sval[t] ? m0 : 0), mask_quad(rq1[t], sval[t] ? m1 : 0), pp);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) tile[p][0][idx] = pp[p];
+                split_parts<NP>(mask_quad(rq2[t], sval[t] ? m2 : 0), mask_quad(rq3[t], sval[t] ? m3 : 0), pp);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) tile[p][1][idx] = pp[p];
             }
         }
 #pragma unroll
         for (int k = 0; k < NWS; ++k) {
             const int idx = tid + 256 * k;
-            if (idx < CT * 1728) (&wlds[0][0])[idx] = rws[k];
+            if (idx < CT * WPC) (&wlds[0][0])[idx] = rws[k];
         }
         __syncthreads();
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
@@ -590,26 +644,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
 #pragma unroll CRFP_TAP_UNROLL
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
-            bf16x8 wa[CT][3];
+            bf16x8 wa[CT][NP];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wa[ct][p] = wlds[ct][(tap * 3 + p) * 64 + lane];
+                for (int p = 0; p < NP; ++p) wa[ct][p] = wlds[ct][(tap * NP + p) * 64 + lane];
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 const int pix = (wave * RPW + (pt >> 1) + ky) * LW + (pt & 1) * 32 + j + kx;
-                const bf16x8 b0 = tile[0][h][pix], b1 = tile[1][h][pix], b2 = tile[2][h][pix];
+                bf16x8 bq[NP];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    f32x16 c = acc[ct][pt];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][1], b1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][0], b2, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][2], b0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][0], b1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][1], b0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ct][0], b0, c, 0, 0, 0);
-                    acc[ct][pt] = c;
-                }
+                for (int p = 0; p < NP; ++p) bq[p] = tile[p][h][pix];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) split_mfma<NP>(acc[ct][pt], acl[ct][pt], wa[ct], bq);
             }
         }
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
@@ -623,6 +670,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
             o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD; o[4] = t_entry; o[5] = t;
         }
     }
+    if (NP == 2) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ct][pt][e] += acl[ct][pt][e] * (1.0f / F16_RES_SCALE);
+    }
     const EpiCtx ec = epi_ctx(a, n);
     conv_epilogue<CT, PT, RPW>(ec, acc, T0, tx0, ty0, wave, j, h);
     if (a.stamps) {
@@ -635,34 +690,229 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const ConvArgs a)
     }
 }
 
+// ---------------------------------------------------------------- software-pipelined persistent variant
+// One 512-thread workgroup per CU (two waves per SIMD) walks a strided list of 8x64 output tiles; wave = one output
+// row (two 32-pixel MFMA column tiles).  The work is a stream of items (tile, K-chunk).  LDS holds the halo tile
+// images of TWO items (2 x 63 KB) and the weight fragments of one (27 KB); the registers hold two more items in raw
+// fp32 form.  While the MFMAs of item s run out of tile buffer s&1 the same waves
+//   * issue the global loads of item s+2 (a full item of latency budget; measured wait at use: 16 cycles),
+//   * split item s+1 (loaded during item s-1) into its three bf16 images and write them to tile buffer (s+1)&1,
+// slice by slice between the taps: the MFMA is asynchronous (32 cycles per 32x32x16), so VALU/LDS instructions
+// issued between two of them ride in its shadow.  The code between two barriers is branch-free (every thread
+// writes both of its halo slots; surplus threads hit a dummy slot), otherwise the scheduler cannot interleave.
+// Why 8 waves and 8 rows: with 4x64 tiles and one wave per SIMD (first version) the tap stream took 6.9 k cycles per
+// item against 3.5 k of MFMA -- LDS operand traffic (0.75 ds_read_b128 per MFMA, 93 % of the LDS pipe) and in-order
+// issue behind a full LDS queue; a second wave per SIMD covers those stalls.
+// The single-buffered kernel above serialises load wait, split, MFMA and epilogue inside a workgroup and relies on
+// a second workgroup per CU to fill the gaps: 45 % MFMA-busy at best (s_memtime stamps).
+constexpr int PIPE_NW = 8, PIPE_NT = 64 * PIPE_NW;
+constexpr int PIPE_NEL = (PIPE_NW + 2) * LW;            // 660 halo pixels
+constexpr int PIPE_NWS = (27 * 64 + PIPE_NT - 1) / PIPE_NT;   // 4 weight vectors per thread
+
+struct PipeRegs {
+    f32x4 q[4][2];        // [K-quad of the chunk][halo element of this thread]
+    bf16x8 w[PIPE_NWS];   // this thread's share of the chunk's 27 KB weight fragment image
+    int m[4];             // component masks of the 4 quads (wave-uniform)
+    bool ok[2];           // halo element inside the image
+};
+
+__device__ __forceinline__ void pipe_issue(PipeRegs& R, const ConvArgs& a, const bf16x8* __restrict__ wp, int n, int T0,
+                                           int nchunks, int ch, int tx0, int ty0, int tid) {
+    const int H = a.H, W = a.W;
+    int cgy[2], cgx[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int idx = min(tid + PIPE_NT * t, PIPE_NEL - 1);
+        const int r = idx / LW, c = idx - r * LW;
+        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+        R.ok[t] = tid + PIPE_NT * t < PIPE_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        cgy[t] = min(max(gy, 0), H - 1);
+        cgx[t] = min(max(gx, 0), W - 1);
+    }
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+        const QuadDesc d = a.qd[4 * ch + qi];
+        const float* qb = d.base + (long long)n * d.bstride;
+        R.m[qi] = d.mask;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) R.q[qi][t] = *reinterpret_cast<const f32x4*>(qb + cgy[t] * d.rs + cgx[t] * d.cs);
+    }
+#pragma unroll
+    for (int k = 0; k < PIPE_NWS; ++k)
+        R.w[k] = wp[((long long)(T0 * nchunks + ch) * 27) * 64 + min(tid + PIPE_NT * k, 1727)];
+}
+
+// unit U in 0..3: halo element U>>1, quad pair U&1 -> three bf16x8 images.  Slot PIPE_NEL is a dummy.
+template <int U>
+__device__ __forceinline__ void pipe_split_unit(const PipeRegs& R, bf16x8 (*tl)[2][PIPE_NEL + 1], int tid) {
+    constexpr int t = U >> 1, pr = U & 1;
+    const int idx = min(tid + PIPE_NT * t, PIPE_NEL);
+    bf16x8 p0, p1, p2;
+    split_bf16x8(mask_quad(R.q[2 * pr][t], R.ok[t] ? R.m[2 * pr] : 0), mask_quad(R.q[2 * pr + 1][t], R.ok[t] ? R.m[2 * pr + 1] : 0),
+                 p0, p1, p2);
+    tl[0][pr][idx] = p0; tl[1][pr][idx] = p1; tl[2][pr][idx] = p2;
+}
+
+struct PipeOps { bf16x8 w[3], b[2][3]; };
+
+__device__ __forceinline__ void pipe_read_ops(PipeOps& o, const bf16x8* wl, const bf16x8 (*tl)[2][PIPE_NEL + 1], int tap,
+                                              int wave, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) o.w[p] = wl[(tap * 3 + p) * 64 + lane];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int pix = (wave + ky) * LW + pt * 32 + j + kx;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) o.b[pt][p] = tl[p][h][pix];
+    }
+}
+
+__device__ __forceinline__ void pipe_mfma(f32x16 (&acc)[1][2], const PipeOps& o) {
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        f32x16 c = acc[0][pt];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[1], o.b[pt][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[0], o.b[pt][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[2], o.b[pt][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[0], o.b[pt][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[1], o.b[pt][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[0], o.b[pt][0], c, 0, 0, 0);
+        acc[0][pt] = c;
+    }
+}
+
+__global__ __launch_bounds__(PIPE_NT, 1) void conv3x3_split_pipe_kernel(const ConvArgs a) {
+    __shared__ bf16x8 tile[2][3][2][PIPE_NEL + 1];   // [buffer][split part][quad pair][halo pixel (+1 dummy)]  127 KB
+    __shared__ bf16x8 wlds[27 * 64 + 1];             // [(tap, part)][lane] (+1 dummy)                            27 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tiles_x = (a.W + TW - 1) / TW, ntiles = tiles_x * ((a.H + PIPE_NW - 1) / PIPE_NW);
+    const int T0 = blockIdx.y, n = blockIdx.z;
+    const int nchunks = a.kq >> 2;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nitems = my_tiles * nchunks;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit);
+    const EpiCtx ec = epi_ctx(a, n);
+
+    // issue cursor (items are issued two ahead of the one being multiplied)
+    int ik = 0, ich = 0;
+    PipeRegs RA, RB;
+#define CRFP_PIPE_ISSUE(R)                                                                                \
+    {                                                                                                     \
+        if (ik < my_tiles) {                                                                              \
+            const int t_ = blockIdx.x + ik * gridDim.x, ty_ = t_ / tiles_x, tx_ = t_ - ty_ * tiles_x;     \
+            pipe_issue(R, a, wp, n, T0, nchunks, ich, tx_ * TW, ty_ * PIPE_NW, tid);                      \
+        }                                                                                                 \
+        if (++ich == nchunks) { ich = 0; ++ik; }                                                          \
+    }
+#define CRFP_PIPE_PUT_WEIGHTS(R)                                                                          \
+    _Pragma("unroll") for (int k = 0; k < PIPE_NWS; ++k) wlds[min(tid + PIPE_NT * k, 1728)] = R.w[k];
+    CRFP_PIPE_ISSUE(RA)
+    CRFP_PIPE_ISSUE(RB)
+    // item 0 -> tile buffer 0 + the weight buffer
+    pipe_split_unit<0>(RA, tile[0], tid); pipe_split_unit<1>(RA, tile[0], tid);
+    pipe_split_unit<2>(RA, tile[0], tid); pipe_split_unit<3>(RA, tile[0], tid);
+    CRFP_PIPE_PUT_WEIGHTS(RA)
+    __syncthreads();
+
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][pt][e] = 0.0f;
+    int mk = 0, mch = 0;   // item being multiplied
+
+#ifdef CRFP_PIPE_STAMPS
+    long long st_wait = 0, st_taps = 0, st_epi = 0, st_bar = 0, st_t = __builtin_amdgcn_s_memtime();
+#define CRFP_PST(ACC) { const long long t_ = __builtin_amdgcn_s_memtime(); ACC += t_ - st_t; st_t = t_; }
+#else
+#define CRFP_PST(ACC)
+#endif
+    // one item: MFMAs out of tile buffer BUF (+ the weight buffer); RNEXT (item s+1, landed) is split into tile
+    // buffer BUF^1 between the taps and its weights replace the weight buffer between the two barriers at the end;
+    // RFREE (consumed by the previous item) receives the loads of item s+2 first of all
+#define CRFP_PIPE_ITEM(BUF, RNEXT, RFREE)                                                                 \
+    {                                                                                                     \
+        CRFP_PST(st_bar)                                                                                  \
+        CRFP_PIPE_ISSUE(RFREE)                                                                            \
+        PipeOps o;                                                                                        \
+        pipe_read_ops(o, wlds, tile[BUF], 0, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_split_unit<0>(RNEXT, tile[(BUF) ^ 1], tid);                                                  \
+        pipe_read_ops(o, wlds, tile[BUF], 1, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_read_ops(o, wlds, tile[BUF], 2, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_split_unit<1>(RNEXT, tile[(BUF) ^ 1], tid);                                                  \
+        pipe_read_ops(o, wlds, tile[BUF], 3, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_read_ops(o, wlds, tile[BUF], 4, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_split_unit<2>(RNEXT, tile[(BUF) ^ 1], tid);                                                  \
+        pipe_read_ops(o, wlds, tile[BUF], 5, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_read_ops(o, wlds, tile[BUF], 6, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_split_unit<3>(RNEXT, tile[(BUF) ^ 1], tid);                                                  \
+        pipe_read_ops(o, wlds, tile[BUF], 7, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_read_ops(o, wlds, tile[BUF], 8, wave, lane); pipe_mfma(acc, o);                              \
+        CRFP_PST(st_taps)                                                                                 \
+        if (++mch == nchunks) {                                                                           \
+            const int t_ = blockIdx.x + mk * gridDim.x, ty_ = t_ / tiles_x, tx_ = t_ - ty_ * tiles_x;     \
+            conv_epilogue<1, 2, 1>(ec, acc, T0, tx_ * TW, ty_ * PIPE_NW, wave, j, h);                     \
+            _Pragma("unroll") for (int pt = 0; pt < 2; ++pt)                                              \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[0][pt][e] = 0.0f;                      \
+            mch = 0; ++mk;                                                                                \
+        }                                                                                                 \
+        CRFP_PST(st_epi)                                                                                  \
+        __syncthreads();               /* every wave is done with the weight buffer and tile[BUF] */     \
+        CRFP_PIPE_PUT_WEIGHTS(RNEXT)                                                                      \
+        __syncthreads();                                                                                  \
+    }
+
+    for (int s = 0; s < nitems; s += 2) {
+        CRFP_PIPE_ITEM(0, RB, RA)
+        if (s + 1 < nitems) CRFP_PIPE_ITEM(1, RA, RB)
+    }
+#undef CRFP_PIPE_ITEM
+#undef CRFP_PIPE_ISSUE
+#undef CRFP_PIPE_PUT_WEIGHTS
+#ifdef CRFP_PIPE_STAMPS
+    if (a.stamps && tid == 0) {
+        long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        o[0] = st_wait; o[1] = st_taps; o[2] = st_epi; o[3] = st_bar; o[4] = nitems;
+    }
+    if (a.stamps && lane == 0 && blockIdx.x == 3) {   // per-wave view of one workgroup
+        long long* o = a.stamps + (8192 + wave) * 8;
+        o[0] = st_wait; o[1] = st_taps; o[2] = st_epi; o[3] = st_bar; o[4] = nitems;
+    }
+#endif
+}
+
 // ---------------------------------------------------------------- input-stationary variant (short K, many couts)
 // For convolutions whose whole K fits in LDS (Cin <= 32: the 32->216 offset/mask conv, the pixel-shuffle
 // expanders 32->96 / 24->64 / 32->64) the halo tile is staged and split ONCE per workgroup and the
 // workgroup then walks all cout tiles, streaming only the packed weights (27 KB per (cout tile, chunk),
 // prefetched into registers during the previous step's MFMAs).  The regular kernel re-stages the same
 // input once per cout tile and pays its prologue/epilogue bubble 7x for the 216-channel conv.
-template <int NCH, int NWAVES>
+template <int NCH, int NWAVES, int NP>
 __global__ __launch_bounds__(64 * NWAVES, 1) void conv3x3_split_is_kernel(const ConvArgs a) {
     constexpr int RPW = 1, TH = NWAVES, LH = TH + 2, PT = 2, NT = 64 * NWAVES;
     constexpr int NEL = LH * LW;
     constexpr int NIN = (NEL + NT - 1) / NT;
-    constexpr int NWS = (27 * 64 + NT - 1) / NT;
-    __shared__ bf16x8 tile[NCH][3][2][NEL];
-    __shared__ bf16x8 wlds[27 * 64];
+    constexpr int WPC = 9 * NP * 64;
+    constexpr int NWS = (WPC + NT - 1) / NT;
+    __shared__ bf16x8 tile[NCH][NP][2][NEL];
+    __shared__ bf16x8 wlds[WPC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
     const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
-    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit);
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(NP == 3 ? a.wsplit : a.wsplit16);
     const int nsteps = a.ctiles * NCH;
 
     bf16x8 rws[NWS];
 #define CRFP_IS_WLOAD(STEP)                                                                               \
     _Pragma("unroll") for (int k = 0; k < NWS; ++k)                                                       \
-        rws[k] = wp[(long long)(STEP) * 1728 + min(tid + NT * k, 1727)];
-    CRFP_IS_WLOAD(0)   // (cout tile 0, chunk 0): packed index ((T*nchunks + ch)*27)*64 == step*1728
+        rws[k] = wp[(long long)(STEP) * WPC + min(tid + NT * k, WPC - 1)];
+    CRFP_IS_WLOAD(0)   // (cout tile 0, chunk 0): packed index (T*nchunks + ch)*WPC == step*WPC
 
     // ---- stage + split the whole input tile once
 #pragma unroll
@@ -688,18 +938,20 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void conv3x3_split_is_kernel(const 
         for (int t = 0; t < NIN; ++t) {
             const int idx = tid + NT * t;
             if (idx < NEL) {
-                bf16x8 p0, p1, p2;
-                split_bf16x8(mask_quad(rq[0][t], ok[t] ? msk[0] : 0), mask_quad(rq[1][t], ok[t] ? msk[1] : 0), p0, p1, p2);
-                tile[ch][0][0][idx] = p0; tile[ch][1][0][idx] = p1; tile[ch][2][0][idx] = p2;
-                split_bf16x8(mask_quad(rq[2][t], ok[t] ? msk[2] : 0), mask_quad(rq[3][t], ok[t] ? msk[3] : 0), p0, p1, p2);
-                tile[ch][0][1][idx] = p0; tile[ch][1][1][idx] = p1; tile[ch][2][1][idx] = p2;
+                bf16x8 pp[NP];
+                split_parts<NP>(mask_quad(rq[0][t], ok[t] ? msk[0] : 0), mask_quad(rq[1][t], ok[t] ? msk[1] : 0), pp);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) tile[ch][p][0][idx] = pp[p];
+                split_parts<NP>(mask_quad(rq[2][t], ok[t] ? msk[2] : 0), mask_quad(rq[3][t], ok[t] ? msk[3] : 0), pp);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) tile[ch][p][1][idx] = pp[p];
             }
         }
     }
 
     long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
     if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tA += t - t0; t0 = t; }
-    f32x16 acc[1][PT];
+    f32x16 acc[1][PT], acl[1][PT];
     const EpiCtx ec = epi_ctx(a, n);
     float2 flpre[PT];   // flow of this lane's pixels (ST_OFFMASK): loaded here, not between two epilogues' stores
 #pragma unroll
@@ -714,13 +966,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void conv3x3_split_is_kernel(const 
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[0][pt][e] = 0.0f;
+                for (int e = 0; e < 16; ++e) { acc[0][pt][e] = 0.0f; acl[0][pt][e] = 0.0f; }
         }
         __syncthreads();  // all waves done with the previous step's weights (and, first time, tile staged)
 #pragma unroll
         for (int k = 0; k < NWS; ++k) {
             const int idx = tid + NT * k;
-            if (idx < 1728) wlds[idx] = rws[k];
+            if (idx < WPC) wlds[idx] = rws[k];
         }
         __syncthreads();
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
@@ -728,24 +980,28 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void conv3x3_split_is_kernel(const 
 #pragma unroll CRFP_TAP_UNROLL
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const bf16x8 w0 = wlds[(tap * 3 + 0) * 64 + lane], w1 = wlds[(tap * 3 + 1) * 64 + lane],
-                         w2 = wlds[(tap * 3 + 2) * 64 + lane];
+            bf16x8 wa[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) wa[p] = wlds[(tap * NP + p) * 64 + lane];
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 const int pix = (wave * RPW + (pt >> 1) + ky) * LW + (pt & 1) * 32 + j + kx;
-                const bf16x8 b0 = tile[ch][0][h][pix], b1 = tile[ch][1][h][pix], b2 = tile[ch][2][h][pix];
-                f32x16 c = acc[0][pt];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b2, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, c, 0, 0, 0);
-                acc[0][pt] = c;
+                bf16x8 bq[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bq[p] = tile[ch][p][h][pix];
+                split_mfma<NP>(acc[0][pt], acl[0][pt], wa, bq);
             }
         }
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
-        if (ch == NCH - 1) conv_epilogue<1, PT, RPW, false>(ec, acc, ct, tx0, ty0, wave, j, h, flpre);
+        if (ch == NCH - 1) {
+            if (NP == 2) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[0][pt][e] += acl[0][pt][e] * (1.0f / F16_RES_SCALE);
+            }
+            conv_epilogue<1, PT, RPW, false>(ec, acc, ct, tx0, ty0, wave, j, h, flpre);
+        }
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
     }
     if (a.stamps && tid == 0) {
@@ -968,8 +1224,9 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
 // split weight pack: wsplit bf16 index =
 //   (((((T*nchunks + ch)*9 + tap)*3 + part)*64 + lane)*8 + jj),  lane = half*32 + row,
 //   K-quad = 4*ch + 2*half + (jj>>2), component = jj&3
+//   np = 3: bf16 triple (bf16x6 scheme); np = 2: fp16 pair, second term scaled by 2^11 (f16x3 scheme), same index with 3 -> 2
 __global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict__ w, const float* __restrict__ w2,
-                                       int cout_split, __bf16* __restrict__ wsplit) {
+                                       int cout_split, unsigned short* __restrict__ wsplit, int np) {
     const int nchunks = a.kq >> 2;
     const long long total = (long long)a.ctiles * nchunks * 9 * 64 * 8;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -990,25 +1247,37 @@ __global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict
         if (co >= 0 && ci >= 0 && ci < a.cin_total)
             val = co < cout_split ? w[((long long)co * a.cin_total + ci) * 9 + tap]
                                   : w2[((long long)(co - cout_split) * a.cin_total + ci) * 9 + tap];
-        const __bf16 p0 = (__bf16)val;
-        const float r = val - (float)p0;
-        const __bf16 p1 = (__bf16)r;
-        const __bf16 p2 = (__bf16)(r - (float)p1);
-        const long long base = (((((long long)T * nchunks + ch) * 9 + tap) * 3) * 64 + lane) * 8 + jj;
-        wsplit[base] = p0;
-        wsplit[base + 64 * 8] = p1;
-        wsplit[base + 2 * 64 * 8] = p2;
+        const long long base = (((((long long)T * nchunks + ch) * 9 + tap) * np) * 64 + lane) * 8 + jj;
+        if (np == 3) {
+            const __bf16 p0 = (__bf16)val;
+            const float r = val - (float)p0;
+            const __bf16 p1 = (__bf16)r;
+            const __bf16 p2 = (__bf16)(r - (float)p1);
+            wsplit[base] = __builtin_bit_cast(unsigned short, p0);
+            wsplit[base + 64 * 8] = __builtin_bit_cast(unsigned short, p1);
+            wsplit[base + 2 * 64 * 8] = __builtin_bit_cast(unsigned short, p2);
+        } else {
+            const _Float16 p0 = (_Float16)val;
+            const _Float16 p1 = (_Float16)((val - (float)p0) * F16_RES_SCALE);
+            wsplit[base] = __builtin_bit_cast(unsigned short, p0);
+            wsplit[base + 64 * 8] = __builtin_bit_cast(unsigned short, p1);
+        }
     }
 }
 
-size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 3 * 64 * 16; }
+// bf16 triple image followed by the fp16 pair image
+size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * (3 + 2) * 64 * 16; }
+size_t conv_split16_offset_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 3 * 64 * 16; }
 
 int launch_conv_pack_split(const ConvArgs& a, const float* w, const float* w2, int cout_split, void* wsplit,
                            hipStream_t s) {
     if (a.kq & 3) { set_error("conv_pack_split: kq %d not a multiple of 4", a.kq); return CRFP_E_BADARG; }
     const long long total = (long long)a.ctiles * (a.kq >> 2) * 9 * 64 * 8;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout, (__bf16*)wsplit);
+    conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout, (unsigned short*)wsplit, 3);
+    CRFP_CHECK_LAUNCH();
+    conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout,
+                                                  (unsigned short*)((char*)wsplit + conv_split16_offset_bytes(a)), 2);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1071,7 +1340,9 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     }
     static const int max_ct = getenv("CRFP_CONV_CT") ? atoi(getenv("CRFP_CONV_CT")) : 2;  // tuning knob
     bool ct2 = a.ctiles % 2 == 0 && max_ct >= 2;
+    // CRFP_CONV_MODE: f16x3 (default) | bf16x6 | f32 -- all three are fp32-grade (see the scheme comments above)
     static const bool use_split = !(getenv("CRFP_CONV_MODE") && !strcmp(getenv("CRFP_CONV_MODE"), "f32"));
+    static const bool use_f16 = !(getenv("CRFP_CONV_MODE") && !strcmp(getenv("CRFP_CONV_MODE"), "bf16x6"));
     static const int split_rpw = getenv("CRFP_SPLIT_RPW") ? atoi(getenv("CRFP_SPLIT_RPW")) : 1;  // tuning knob
     bool nchw_src = false;
     for (int i = 0; i < a.nsrc; ++i) nchw_src |= a.src[i].kind == SRC_NCHW;
@@ -1090,6 +1361,7 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     static long long* stamp_ptr = getenv("CRFP_STAMP_PTR") ? (long long*)strtoull(getenv("CRFP_STAMP_PTR"), nullptr, 0) : nullptr;
     ConvArgs& am = const_cast<ConvArgs&>(a);  // callers pass a private, mutable plan copy
     am.stamps = (stamp_ptr && stamp_name && !strcmp(stamp_name, name)) ? stamp_ptr : nullptr;
+    am.wsplit16 = a.wsplit ? (const char*)a.wsplit + conv_split16_offset_bytes(a) : nullptr;   // fp16 pair image follows the bf16 triple
     if (a.kq <= CRFP_MAX_KQ) {  // per-quad load descriptors (wave-uniform in the kernel: one s_load per quad)
         int q = 0;
         for (int i = 0; i < a.nsrc; ++i)
@@ -1115,6 +1387,8 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     // throttled by the ~12 B/clk/CU the memory system delivers) -> kept as an opt-in experiment
     static const bool use_ws = getenv("CRFP_SPLIT_WS") && atoi(getenv("CRFP_SPLIT_WS")) == 1;
     static const bool use_is = !(getenv("CRFP_SPLIT_IS") && atoi(getenv("CRFP_SPLIT_IS")) == 0);
+    static const bool use_pipe = getenv("CRFP_SPLIT_PIPE") && atoi(getenv("CRFP_SPLIT_PIPE")) == 1;
+    static const int pipe_wgs = getenv("CRFP_PIPE_WGS") ? atoi(getenv("CRFP_PIPE_WGS")) : 256;
     if (split && use_ws) {
         const int wtiles = ((a.W + TW - 1) / TW) * ((a.H + WS_TH - 1) / WS_TH);
         if (use_is && a.kq <= 8 && a.ctiles >= 2) {
@@ -1125,18 +1399,32 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     } else if (split && use_is && a.kq <= 8 && a.ctiles >= 2) {
         // input-stationary: whole K in LDS, one workgroup per 4x64 tile walks every cout tile
         dim3 grid(((a.W + TW - 1) / TW) * ((a.H + 7) / 8), 1, a.N);
-        if (a.kq == 4) conv3x3_split_is_kernel<1, 8><<<grid, 512, 0, s>>>(a);
-        else conv3x3_split_is_kernel<2, 8><<<grid, 512, 0, s>>>(a);
+        if (use_f16) {
+            if (a.kq == 4) conv3x3_split_is_kernel<1, 8, 2><<<grid, 512, 0, s>>>(am);
+            else conv3x3_split_is_kernel<2, 8, 2><<<grid, 512, 0, s>>>(am);
+        } else {
+            if (a.kq == 4) conv3x3_split_is_kernel<1, 8, 3><<<grid, 512, 0, s>>>(am);
+            else conv3x3_split_is_kernel<2, 8, 3><<<grid, 512, 0, s>>>(am);
+        }
+    } else if (split && use_pipe) {
+        // persistent: one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+        const int ntl = ((a.W + TW - 1) / TW) * ((a.H + PIPE_NW - 1) / PIPE_NW);
+        const int per = (ntl + pipe_wgs - 1) / pipe_wgs;           // tiles per workgroup
+        dim3 grid((ntl + per - 1) / per, a.ctiles, a.N);           // balanced shares
+        conv3x3_split_pipe_kernel<<<grid, PIPE_NT, 0, s>>>(a);
     } else if (split) {
         if (ct2) {
             dim3 grid(tiles, a.ctiles / 2, a.N);
-            conv3x3_split_kernel<2, 1><<<grid, 256, 0, s>>>(a);
+            if (use_f16) conv3x3_split_kernel<2, 1, 2><<<grid, 256, 0, s>>>(am);
+            else conv3x3_split_kernel<2, 1, 3><<<grid, 256, 0, s>>>(am);
         } else if (split_rpw == 1) {
             dim3 grid(tiles, a.ctiles, a.N);
-            conv3x3_split_kernel<1, 1><<<grid, 256, 0, s>>>(a);
+            if (use_f16) conv3x3_split_kernel<1, 1, 2><<<grid, 256, 0, s>>>(am);
+            else conv3x3_split_kernel<1, 1, 3><<<grid, 256, 0, s>>>(am);
         } else {
             dim3 grid(tiles, a.ctiles, a.N);
-            conv3x3_split_kernel<1, 2><<<grid, 256, 0, s>>>(a);
+            if (use_f16) conv3x3_split_kernel<1, 2, 2><<<grid, 256, 0, s>>>(am);
+            else conv3x3_split_kernel<1, 2, 3><<<grid, 256, 0, s>>>(am);
         }
     } else if (ct2) {
         dim3 grid(tiles, a.ctiles / 2, a.N);

@@ -267,7 +267,8 @@ def test_streaming_variant_golden():
 
 
 @pytest.mark.parametrize("env", [{"CRFP_CONV_MODE": "f32"}, {"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "0"},
-                                 {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"}, {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SIDE_STREAM": "0"}])
+                                 {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"}, {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SIDE_STREAM": "0"}, {"CRFP_SPLIT_PIPE": "1"}, {"CRFP_CONV_MODE": "bf16x6"},
+                                 {"CRFP_CONV_MODE": "bf16x6", "CRFP_SPLIT_IS": "0"}])
 def test_alternate_kernel_paths(env):
     """Every selectable conv main loop (fp32 MFMA, split-bf16 single-role / input-stationary /
     warp-specialised, 4- and 8-row tiles) must give the same clip within the parity tolerance."""
