@@ -35,8 +35,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measu
 HBM_COPY_CEILING_GBS = 6290.0
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
-# The wide convs run as 6 bf16 MFMA products per algorithmic fp32 MAC (split-bf16, fp32-grade result),
-# so their algorithmic-flop ceiling is the bf16 peak / 6.
+# The wide convs run as 3 fp16 MFMA products per algorithmic fp32 MAC (split-fp16 "f16x3", fp32-grade result:
+# DESIGN.md section 3.1), or 6 bf16 products with CRFP_CONV_MODE=bf16x6; fp16 and bf16 MFMAs share the 2.5 PF dense
+# peak, so the algorithmic-flop ceiling is that peak / 3 (/ 6).
+SPLIT_F16_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 SPLIT_BF16_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
@@ -146,6 +148,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: single MI355X, 7-frame 180x320 -> 1440x2560 x8 SR, "
                                "batch=1, fp32, sigma_T=10 (one clip per GPU per step; clips sharded over GPUs)",
+                   "conv_arithmetic": "fp32 in / fp32 accumulate / fp32 out; products on the fp16 MFMA via an exact 2-term split "
+                                      "(3 MFMAs per MAC, error at the fp32 summation-order floor, see `parity`)",
                    "frames_per_clip": t, "lr": [h, w], "sr": [8 * h, 8 * w], "fv_size": args.fv_size,
                    "sigma_t": args.sigma_t, "clips_per_gpu_per_step": 1, "parallelism": f"clip-sharded x{world}"},
         "per_gpu_frames_per_sec": args.steps * t / elapsed,
@@ -179,15 +183,19 @@ def main():
         dom = table[0]
         domf = fam[dom["kernel"]]
         if dom["kernel"] == "conv3x3_mfma":
-            f32_mode = os.environ.get("CRFP_CONV_MODE") == "f32"
-            peak = F32_MFMA_PEAK_TFLOPS if f32_mode else SPLIT_BF16_EQUIV_PEAK_TFLOPS
+            mode = os.environ.get("CRFP_CONV_MODE", "f16x3")
+            f32_mode = mode == "f32"
+            peak = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16x6": SPLIT_BF16_EQUIV_PEAK_TFLOPS}.get(mode, SPLIT_F16_EQUIV_PEAK_TFLOPS)
+            note = {"f32": "fp32 MFMA",
+                    "bf16x6": "algorithmic fp32 flops; executed as 6 bf16 MFMA products per MAC (split-bf16), so peak = 2.5 PF / 6"}.get(
+                        mode, "algorithmic fp32 flops; executed as 3 fp16 MFMA products per MAC (split-fp16, fp32-grade), so peak = "
+                              "2.5 PF dense fp16 / 3; the kernel is LDS-bandwidth bound (1.0 ds_read_b128 per MFMA), not MFMA bound")
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["TFLOPs"],
                                   "peak": peak, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / peak,
                                   "traffic": pmc_traffic(dom["kernel"]), "avg_launch_us": dom["avg_us"],
                                   "algorithmic_flops_per_launch": domf["flops"] / domf["launches"],
                                   "frac_of_fp32_mfma_peak": dom["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                                  "note": "algorithmic fp32 flops; executed as 6 bf16 MFMA products per MAC (split-bf16), "
-                                          "so peak = 2.5 PF dense bf16 / 6" if not f32_mode else "fp32 MFMA"}
+                                  "conv_scheme": mode, "note": note}
         else:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"]),

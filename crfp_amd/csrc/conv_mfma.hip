@@ -891,7 +891,7 @@ __global__ __launch_bounds__(PIPE_NT, 1) void conv3x3_split_pipe_kernel(const Co
 // prefetched into registers during the previous step's MFMAs).  The regular kernel re-stages the same
 // input once per cout tile and pays its prologue/epilogue bubble 7x for the 216-channel conv.
 template <int NCH, int NWAVES, int NP>
-__global__ __launch_bounds__(64 * NWAVES, 1) void conv3x3_split_is_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_split_is_kernel(const ConvArgs a) {
     constexpr int RPW = 1, TH = NWAVES, LH = TH + 2, PT = 2, NT = 64 * NWAVES;
     constexpr int NEL = LH * LW;
     constexpr int NIN = (NEL + NT - 1) / NT;
@@ -1386,7 +1386,9 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     // warp-specialised variant: measured 346 vs 351.5 frames/s for the single-role kernels (loader issue is
     // throttled by the ~12 B/clk/CU the memory system delivers) -> kept as an opt-in experiment
     static const bool use_ws = getenv("CRFP_SPLIT_WS") && atoi(getenv("CRFP_SPLIT_WS")) == 1;
-    static const bool use_is = !(getenv("CRFP_SPLIT_IS") && atoi(getenv("CRFP_SPLIT_IS")) == 0);
+    // input-stationary variant: wins for bf16x6 (65 KB workgroups, 2 per CU); with f16x3 the plain kernel runs 3 workgroups
+    // per CU and is faster even for the 216-channel conv (139.8 vs 147.6 us), so it is opt-in there
+    static const bool use_is = getenv("CRFP_SPLIT_IS") ? atoi(getenv("CRFP_SPLIT_IS")) != 0 : !use_f16;
     static const bool use_pipe = getenv("CRFP_SPLIT_PIPE") && atoi(getenv("CRFP_SPLIT_PIPE")) == 1;
     static const int pipe_wgs = getenv("CRFP_PIPE_WGS") ? atoi(getenv("CRFP_PIPE_WGS")) : 256;
     if (split && use_ws) {
@@ -1399,7 +1401,12 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     } else if (split && use_is && a.kq <= 8 && a.ctiles >= 2) {
         // input-stationary: whole K in LDS, one workgroup per 4x64 tile walks every cout tile
         dim3 grid(((a.W + TW - 1) / TW) * ((a.H + 7) / 8), 1, a.N);
-        if (use_f16) {
+        static const int is_waves = getenv("CRFP_IS_WAVES") ? atoi(getenv("CRFP_IS_WAVES")) : 8;   // tuning knob
+        if (use_f16 && is_waves == 4) {
+            dim3 grid4(((a.W + TW - 1) / TW) * ((a.H + 3) / 4), 1, a.N);
+            if (a.kq == 4) conv3x3_split_is_kernel<1, 4, 2><<<grid4, 256, 0, s>>>(am);
+            else conv3x3_split_is_kernel<2, 4, 2><<<grid4, 256, 0, s>>>(am);
+        } else if (use_f16) {
             if (a.kq == 4) conv3x3_split_is_kernel<1, 8, 2><<<grid, 512, 0, s>>>(am);
             else conv3x3_split_is_kernel<2, 8, 2><<<grid, 512, 0, s>>>(am);
         } else {

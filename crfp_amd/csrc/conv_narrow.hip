@@ -9,6 +9,7 @@
 // (:1678-1683) and dcn_3's shared (dy,dx,mask) triple (:337-347).
 #include "crfp_common.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace crfp {
 
@@ -33,126 +34,169 @@ __device__ __forceinline__ float n_act(float v, int act) {
     }
 }
 
-// Workgroup = 256 threads = one 64 x 16 output tile; the (16+2) x (64+2) halo of every input quad
-// is staged in LDS once (coalesced 16-B loads), then thread (tx, ty) produces the 4 vertically
-// adjacent pixels (tx, 4*ty .. 4*ty+3): 18 ds_read_b128 per input quad feed 4 x 9 x 16 FMAs, and
-// the 144*KQ weights (wave-uniform scalar loads) are amortised over 4 pixels.
+// Workgroup = 256 threads walks a strided list of 64 x 16 output tiles (persistent).  Per tile the (16+2) x (64+2)
+// halo of every input quad goes global -> registers -> LDS (coalesced 16-B loads); thread (tx, ty) then produces the 4
+// vertically adjacent pixels (tx, 4*ty .. 4*ty+3): 18 ds_read_b128 per input quad feed 4 x 9 x 16 FMAs; the weights sit
+// in LDS too (broadcast reads).  The loads of tile t+1 are issued right after tile t reached LDS, so they fly during
+// the FMAs and stores of tile t: the one-tile-per-workgroup version spent 7.7-12 k cycles per tile waiting for its
+// loads and 4 k in an epilogue that re-read its arguments (s_memtime stamps), i.e. HBM idled while it computed.
 constexpr int NTW = 64, NTH = 16, NLW = NTW + 2, NLH = NTH + 2;
+constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per quad
 
 template <int KQ, int EPI>
-__global__ __launch_bounds__(256, 4) void conv3x3_narrow_kernel(const NarrowArgs a) {
+__global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_narrow_kernel(const NarrowArgs a) {
     __shared__ float4 tile[KQ][NLH][NLW];
     __shared__ float4 wl[9 * KQ * 4];  // weights as [tap][kq][cin comp] -> float4 over cout (broadcast reads)
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     if (tid < 9 * KQ * 4) wl[tid] = reinterpret_cast<const float4*>(a.wpk)[tid];
-    const int x0 = blockIdx.x * NTW, y0 = blockIdx.y * NTH;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
+    const int tiles_x = (W + NTW - 1) / NTW, ntiles = tiles_x * ((H + NTH - 1) / NTH);
 
-    constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per quad
+    // ---- everything that comes from the kernel arguments, once
+    const float* qbase[KQ];   // plane of K-quad k of its source
+    int qpitch[KQ];           // row pitch in pixels
+    bool qflow[KQ];           // [H][W][2] flow field instead of a Q4 plane
 #pragma unroll
     for (int k = 0; k < KQ; ++k) {
         int kql = k, s = 0;
         while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
         const ConvSrc src = a.src[s];
-        const int SPW = W + src.pad;
-        const float* base = src.p + (long long)n * src.bstride +
-                            (src.kind == SRC_FLOW2 ? 0 : (long long)kql * (H + src.pad) * SPW * 4);
-        f32x4 r[NST];
-        // issue every load of this quad before the first LDS write (independent loads in flight together)
+        qflow[k] = src.kind == SRC_FLOW2;
+        qpitch[k] = W + src.pad;
+        qbase[k] = src.p + (long long)n * src.bstride + (qflow[k] ? 0 : (long long)kql * (H + src.pad) * qpitch[k] * 4);
+    }
+    const float4 bias = *reinterpret_cast<const float4*>(a.bpk);
+    const int cout = a.cout, act = a.act;
+    // NONE / RELU / LRELU(0.1) as max(v,0) + slope*min(v,0) (exact); tanh / sigmoid take the slow branch
+    const float slope = act == CRFP_ACT_RELU ? 0.0f : (act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const bool slow_act = act == CRFP_ACT_TANH || act == CRFP_ACT_SIGMOID;
+    const float post = a.post_scale;
+    float* const dst = a.dst + (long long)n * a.dst_bstride;
+    const int dpitch = W + a.dst_pad;                       // Q4 destination may be padded (P4)
+    const float* const resid = a.resid ? a.resid + (long long)n * a.resid_bstride : nullptr;
+    const uint8_t* const mask = EPI == NE_BLEND ? a.mask + (long long)n * a.mask_bstride : nullptr;
+    const float* const basep = EPI == NE_LAST ? a.base + (long long)n * a.base_bstride : nullptr;
+    const float* const flowp = EPI == NE_OFFMASK3 ? a.flow + (long long)n * a.flow_bstride : nullptr;
+    const bool y_only = a.y_only != 0;
+
+    f32x4 r[KQ][NST];
+    // issue every load of a tile before anything consumes them (independent loads in flight together)
+#define CRFP_NARROW_LOAD(T)                                                                               \
+    {                                                                                                     \
+        const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * NTW, y0_ = ty_ * NTH;                \
+        _Pragma("unroll") for (int k = 0; k < KQ; ++k)                                                    \
+            _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                             \
+                const int idx = tid + 256 * t;                                                            \
+                const int rr = idx / NLW, c = idx - rr * NLW;                                             \
+                const int gy = y0_ + rr - 1, gx = x0_ + c - 1;                                            \
+                r[k][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                                                  \
+                if (idx < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W) {                          \
+                    if (qflow[k]) {                                                                       \
+                        const float2 f = *reinterpret_cast<const float2*>(qbase[k] + ((long long)gy * W + gx) * 2); \
+                        r[k][t] = f32x4{f.x, f.y, 0.0f, 0.0f};                                            \
+                    } else {                                                                              \
+                        r[k][t] = *reinterpret_cast<const f32x4*>(qbase[k] + ((long long)gy * qpitch[k] + gx) * 4); \
+                    }                                                                                     \
+                }                                                                                         \
+            }                                                                                             \
+    }
+
+    int t_cur = blockIdx.x;
+    CRFP_NARROW_LOAD(t_cur)
+    for (;;) {
 #pragma unroll
-        for (int t = 0; t < NST; ++t) {
-            const int idx = tid + 256 * t;
-            const int rr = idx / NLW, c = idx - rr * NLW;
-            const int gy = y0 + rr - 1, gx = x0 + c - 1;
-            r[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (idx < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                if (src.kind == SRC_FLOW2) {
-                    const float2 f = *reinterpret_cast<const float2*>(base + ((long long)gy * W + gx) * 2);
-                    r[t] = f32x4{f.x, f.y, 0.0f, 0.0f};
-                } else {
-                    r[t] = *reinterpret_cast<const f32x4*>(base + ((long long)gy * SPW + gx) * 4);
+        for (int k = 0; k < KQ; ++k)
+#pragma unroll
+            for (int t = 0; t < NST; ++t) {
+                const int idx = tid + 256 * t;
+                if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = r[k][t];
+            }
+        __syncthreads();
+        const int t_next = t_cur + gridDim.x;
+        if (t_next < ntiles) CRFP_NARROW_LOAD(t_next)     // flies during the FMAs and stores below
+
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] = bias.x; acc[i][1] = bias.y; acc[i][2] = bias.z; acc[i][3] = bias.w; }
+        // (k, ky) loops are deliberately NOT unrolled: hipcc otherwise hoists all 36 weight reads and
+        // 18 halo reads of a quad and blows past 200 VGPRs (or spills at a lower cap).
+#pragma unroll 1
+        for (int k = 0; k < KQ; ++k) {
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4* wq = &wl[((ky * 3 + kx) * KQ + k) * 4];
+                    const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 u = tile[k][4 * ty + ky + i][tx + kx];
+                        acc[i][0] = fmaf(w3.x, u.w, fmaf(w2.x, u.z, fmaf(w1.x, u.y, fmaf(w0.x, u.x, acc[i][0]))));
+                        acc[i][1] = fmaf(w3.y, u.w, fmaf(w2.y, u.z, fmaf(w1.y, u.y, fmaf(w0.y, u.x, acc[i][1]))));
+                        acc[i][2] = fmaf(w3.z, u.w, fmaf(w2.z, u.z, fmaf(w1.z, u.y, fmaf(w0.z, u.x, acc[i][2]))));
+                        acc[i][3] = fmaf(w3.w, u.w, fmaf(w2.w, u.z, fmaf(w1.w, u.y, fmaf(w0.w, u.x, acc[i][3]))));
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < NST; ++t) {
-            const int idx = tid + 256 * t;
-            if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = r[t];
-        }
-    }
-    __syncthreads();
 
-    float acc[4][4];
+        const int tyi = t_cur / tiles_x, x = (t_cur - tyi * tiles_x) * NTW + tx, y0 = tyi * NTH;
+        if (x < W) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                const int y = y0 + 4 * ty + i;
+                if (y >= H) break;
+                const long long pix = (long long)y * W + x;
+                const long long dpix = (long long)y * dpitch + x;
+                if (EPI == NE_PLAIN) {
+                    float v[4];
+                    if (slow_act) {
 #pragma unroll
-        for (int o = 0; o < 4; ++o) acc[i][o] = a.bpk[o];
-    // (k, ky) loops are deliberately NOT unrolled: hipcc otherwise hoists all 36 weight reads and
-    // 18 halo reads of a quad and blows past 200 VGPRs (or spills at a lower cap).
-#pragma unroll 1
-    for (int k = 0; k < KQ; ++k) {
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
+                        for (int o = 0; o < 4; ++o) v[o] = n_act(acc[i][o], act) * post;
+                    } else {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float4* wq = &wl[((ky * 3 + kx) * KQ + k) * 4];
-                const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
+                        for (int o = 0; o < 4; ++o) v[o] = (fmaxf(acc[i][o], 0.0f) + slope * fminf(acc[i][o], 0.0f)) * post;
+                    }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 u = tile[k][4 * ty + ky + i][tx + kx];
-                    acc[i][0] = fmaf(w3.x, u.w, fmaf(w2.x, u.z, fmaf(w1.x, u.y, fmaf(w0.x, u.x, acc[i][0]))));
-                    acc[i][1] = fmaf(w3.y, u.w, fmaf(w2.y, u.z, fmaf(w1.y, u.y, fmaf(w0.y, u.x, acc[i][1]))));
-                    acc[i][2] = fmaf(w3.z, u.w, fmaf(w2.z, u.z, fmaf(w1.z, u.y, fmaf(w0.z, u.x, acc[i][2]))));
-                    acc[i][3] = fmaf(w3.w, u.w, fmaf(w2.w, u.z, fmaf(w1.w, u.y, fmaf(w0.w, u.x, acc[i][3]))));
+                    for (int o = 0; o < 4; ++o)
+                        if (o >= cout) v[o] = 0.0f;
+                    if (resid) {
+                        const float4 rv = *reinterpret_cast<const float4*>(resid + pix * 4);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    *reinterpret_cast<float4*>(dst + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (EPI == NE_BLEND) {
+                    const float4 centre = tile[0][4 * ty + i + 1][tx + 1];
+                    const bool m = mask[pix] != 0;
+                    float v[4] = {m ? acc[i][0] : centre.x, m ? acc[i][1] : centre.y, m ? acc[i][2] : centre.z,
+                                  m ? acc[i][3] : centre.w};
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) v[o] = v[o] > 0.0f ? v[o] : 0.1f * v[o];
+                    *reinterpret_cast<float4*>(dst + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (EPI == NE_LAST) {
+                    const float4 b = *reinterpret_cast<const float4*>(basep + pix * 4);
+                    if (y_only) {
+                        dst[pix] = acc[i][0] + (0.299f * b.x + 0.587f * b.y + 0.114f * b.z);
+                    } else {
+                        const long long plane = (long long)H * W;
+                        dst[pix] = acc[i][0] + b.x;
+                        dst[plane + pix] = acc[i][1] + b.y;
+                        dst[2 * plane + pix] = acc[i][2] + b.z;
+                    }
+                } else {  // NE_OFFMASK3
+                    const float2 f = *reinterpret_cast<const float2*>(flowp + pix * 2);
+                    *reinterpret_cast<float4*>(dst + dpix * 4) =
+                        make_float4(10.0f * tanhf(acc[i][0]) + f.y, 10.0f * tanhf(acc[i][1]) + f.x,
+                                    1.0f / (1.0f + expf(-acc[i][2])), 0.0f);
                 }
             }
         }
+        if (t_next >= ntiles) break;
+        t_cur = t_next;
+        __syncthreads();   // every wave is done reading the tile before it is overwritten
     }
-
-    const int x = x0 + tx;
-    if (x >= W) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0 + 4 * ty + i;
-        if (y >= H) break;
-        const long long pix = (long long)y * W + x;
-        const long long dpix = (long long)y * (W + a.dst_pad) + x;  // Q4 destination may be padded (P4)
-        if (EPI == NE_PLAIN) {
-            float v[4];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) v[o] = o < a.cout ? n_act(acc[i][o], a.act) * a.post_scale : 0.0f;
-            if (a.resid) {
-                const float4 r = *reinterpret_cast<const float4*>(a.resid + (long long)n * a.resid_bstride + pix * 4);
-                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-            }
-            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (EPI == NE_BLEND) {
-            const float4 centre = tile[0][4 * ty + i + 1][tx + 1];
-            const bool m = a.mask[(long long)n * a.mask_bstride + pix] != 0;
-            float v[4] = {m ? acc[i][0] : centre.x, m ? acc[i][1] : centre.y, m ? acc[i][2] : centre.z,
-                          m ? acc[i][3] : centre.w};
-#pragma unroll
-            for (int o = 0; o < 4; ++o) v[o] = v[o] > 0.0f ? v[o] : 0.1f * v[o];
-            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (EPI == NE_LAST) {
-            const float4 b = *reinterpret_cast<const float4*>(a.base + (long long)n * a.base_bstride + pix * 4);
-            float* o = a.dst + (long long)n * a.dst_bstride;
-            if (a.y_only) {
-                o[pix] = acc[i][0] + (0.299f * b.x + 0.587f * b.y + 0.114f * b.z);
-            } else {
-                const long long plane = (long long)H * W;
-                o[pix] = acc[i][0] + b.x;
-                o[plane + pix] = acc[i][1] + b.y;
-                o[2 * plane + pix] = acc[i][2] + b.z;
-            }
-        } else {  // NE_OFFMASK3
-            const float2 f = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_bstride + pix * 2);
-            *reinterpret_cast<float4*>(a.dst + (long long)n * a.dst_bstride + dpix * 4) =
-                make_float4(10.0f * tanhf(acc[i][0]) + f.y, 10.0f * tanhf(acc[i][1]) + f.x,
-                            1.0f / (1.0f + expf(-acc[i][2])), 0.0f);
-        }
-    }
+#undef CRFP_NARROW_LOAD
 }
 
 // wpk[((tap*KQ + kq)*4 + comp)*4 + o] = W[o][cin(kq,comp)][tap]
@@ -188,7 +232,11 @@ int launch_narrow_pack(const NarrowArgs& a, const float* w, const float* bias, c
     return 0;
 }
 
-int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s) {
+int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
+    NarrowArgs a = a_in;
+    static const char* stamp_name = getenv("CRFP_STAMP_NAME");
+    static long long* stamp_ptr = getenv("CRFP_STAMP_PTR") ? (long long*)strtoull(getenv("CRFP_STAMP_PTR"), nullptr, 0) : nullptr;
+    a.stamps = (stamp_ptr && stamp_name && !strcmp(stamp_name, name)) ? stamp_ptr : nullptr;
     if (a.kq < 1 || a.kq > 3 || a.cout < 1 || a.cout > 4) {
         set_error("conv_narrow %s: unsupported kq=%d cout=%d", name, a.kq, a.cout);
         return CRFP_E_UNSUPPORTED;
@@ -203,7 +251,12 @@ int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s) {
     if (a.resid) extra += 4;
     ProfScope prof(name, s, px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * 4.0,
                    2.0 * px * in_ch * a.cout * 9.0);
-    dim3 grid((a.W + NTW - 1) / NTW, (a.H + NTH - 1) / NTH, a.N);
+    // persistent: a few workgroups per CU walk the tiles (ceil-balanced shares)
+    const int ntl = ((a.W + NTW - 1) / NTW) * ((a.H + NTH - 1) / NTH);
+    static const int per_cu_env = getenv("CRFP_NARROW_WGS_PER_CU") ? atoi(getenv("CRFP_NARROW_WGS_PER_CU")) : 0;   // tuning knob
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? 4 : (a.kq == 2 ? 3 : 2));
+    const int share = (ntl + 256 * per_cu - 1) / (256 * per_cu);
+    dim3 grid((ntl + share - 1) / share, 1, a.N);
 #define CRFP_NARROW_LAUNCH(KQ_)                                                                    \
     switch (a.epi) {                                                                               \
         case NE_PLAIN: conv3x3_narrow_kernel<KQ_, NE_PLAIN><<<grid, 256, 0, s>>>(a); break;        \

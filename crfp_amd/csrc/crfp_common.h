@@ -163,6 +163,7 @@ struct NarrowArgs {
     int act, epi, y_only;
     float post_scale;
     int dst_pad, rsv;
+    long long* stamps;  // diagnostic builds (-DCRFP_NARROW_STAMPS) only
 };
 
 // ------------------------------------------------------------------ profiling + errors

@@ -8,6 +8,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float pat(unsigned r, unsigned c, unsigned comp, unsigned salt) {
     unsigned h = (r * 73856093u) ^ (c * 19349663u) ^ (comp * 83492791u) ^ (salt * 2654435761u);
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256, 4) void victim(unsigned* errs, unsigned* where
     }
 }
 
-// MODE 0: bf16 32x32x16 MFMA fed from LDS; 1: bf16 MFMA from registers only; 2: f32 32x32x2 MFMA fed from LDS; 3: LDS reads + VALU only
+// MODE 0: bf16 32x32x16 MFMA fed from LDS; 1: bf16 MFMA from registers only; 2: f32 32x32x2 MFMA fed from LDS; 3: LDS reads + VALU only;
+// 4: f16 32x32x16 MFMA fed from LDS
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void aggressor(float* sink, int iters) {
     __shared__ bf16x8 big[4100];   // 65.6 KB
@@ -94,6 +96,13 @@ __global__ __launch_bounds__(256, 2) void aggressor(float* sink, int iters) {
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, d, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d, b, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, d, c1, 0, 0, 0);
+        } else if (MODE == 4) {
+            const f16x8 a = __builtin_bit_cast(f16x8, big[base + lane]), b = __builtin_bit_cast(f16x8, big[base + 64 + lane]),
+                        d = __builtin_bit_cast(f16x8, big[base + 128 + lane]);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, d, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(d, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, d, c1, 0, 0, 0);
         } else if (MODE == 1) {
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra, rb, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rb, ra, c1, 0, 0, 0);
@@ -202,8 +211,8 @@ int main(int argc, char** argv) {
     hipStream_t a, b;
     hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
-    const char* names[5] = {"bf16 mfma + LDS", "bf16 mfma regs", "f32 mfma + LDS", "LDS + VALU", "none"};
-    for (int mode = 0; mode < 5; ++mode) {
+    const char* names[6] = {"bf16 mfma + LDS", "bf16 mfma regs", "f32 mfma + LDS", "LDS + VALU", "f16 mfma + LDS", "none"};
+    for (int mode = 0; mode < 6; ++mode) {
         hipMemset(errs, 0, 4);
         hipDeviceSynchronize();
         for (int r = 0; r < rounds; ++r) {
@@ -213,6 +222,7 @@ int main(int argc, char** argv) {
                 case 1: aggressor<1><<<1800, 256, 0, b>>>(sink, 300); break;
                 case 2: aggressor<2><<<1800, 256, 0, b>>>(sink, 300); break;
                 case 3: aggressor<3><<<1800, 256, 0, b>>>(sink, 300); break;
+                case 4: aggressor<4><<<1800, 256, 0, b>>>(sink, 300); break;
                 default: break;
             }
         }
