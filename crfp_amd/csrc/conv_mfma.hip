@@ -1426,7 +1426,8 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
             else conv3x3_split_kernel<2, 1, 3><<<grid, 256, 0, s>>>(am);
         } else if (split_rpw == 1) {
             dim3 grid(tiles, a.ctiles, a.N);
-            if (use_f16) conv3x3_split_kernel<1, 1, 2><<<grid, 256, 0, s>>>(am);
+            static const int dyn_lds = getenv("CRFP_SPLIT_DYNLDS") ? atoi(getenv("CRFP_SPLIT_DYNLDS")) : 0;  // occupancy experiment
+            if (use_f16) conv3x3_split_kernel<1, 1, 2><<<grid, 256, dyn_lds, s>>>(am);
             else conv3x3_split_kernel<1, 1, 3><<<grid, 256, 0, s>>>(am);
         } else {
             dim3 grid(tiles, a.ctiles, a.N);
