@@ -123,6 +123,12 @@ int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, 
     return launch_upsample_nchw(x, out, n, c, h, w, oh, ow, scale_h, scale_w, mul, (hipStream_t)stream);
 }
 
+int crfp_psnr_ssim_partial_f32(const float* a, const float* b, const unsigned char* mask, double* acc, int n, int c, int h, int w,
+                               float mul, float add, void* stream) {
+    if (!a || !b || !acc || n < 1 || c < 1 || h < 1 || w < 1) { set_error("psnr_ssim_partial: bad argument"); return CRFP_E_BADARG; }
+    return launch_psnr_ssim_partial(a, b, mask, acc, n, c, h, w, mul, add, (hipStream_t)stream);
+}
+
 int crfp_psnr_partial_f32(const float* a, const float* b, double* acc, int n, int c, int h, int w, void* stream) {
     if (!a || !b || !acc || n < 1 || c < 1 || h < 1 || w < 1) { set_error("psnr_partial: bad argument"); return CRFP_E_BADARG; }
     return launch_psnr_partial(a, b, acc, n, c, h, w, (hipStream_t)stream);

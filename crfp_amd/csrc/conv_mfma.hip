@@ -139,12 +139,15 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
 // 15 k cycles per workgroup (38 % of a 32->32 conv's workgroup lifetime, measured with s_memtime stamps).
 // Bias quads and the residual are loaded up front so that the stores leave back to back.
 //
-// VBIAS: bias through per-lane vector loads (single epilogue per workgroup).  Inside a loop over cout tiles a vector
+// VBIAS = 2: the caller initialised the accumulators with the bias (loads issued at kernel start: no L2 round trip here);
+// VBIAS = 1: bias through per-lane vector loads (single epilogue per workgroup).  Inside a loop over cout tiles a vector
 // load would force s_waitcnt vmcnt(0), i.e. drain every store of the previous tile's epilogue (vmcnt is in-order and
-// counts stores on CDNA4: 12k cycles per tile measured); those callers pass VBIAS=false (wave-uniform scalar loads,
+// counts stores on CDNA4: 12k cycles per tile measured); those callers pass VBIAS=0 (wave-uniform scalar loads,
 // selected per lane half) and preload the flow vectors of the lane's PT pixels (flpre, ST_OFFMASK).
 struct EpiCtx {
     int H, W, cout, ncq, act, store, n_off_quads, dstH, dstW, lr;
+    bool single;    // exactly one destination, starting at quad 0 and taking all of them
+    long long* dbg; // diagnostic stamps (null in production)
     float slope, post;
     const float4* bp;
     const float* rp;
@@ -160,7 +163,7 @@ __device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
     e.ncq = (conv_packed_rows(a.cout, a.store, a.ps_r) + 3) >> 2;
     e.n_off_quads = a.n_off_quads; e.dstH = a.dstH; e.dstW = a.dstW;
     e.lr = a.ps_r == 4 ? 2 : 1;                           // ST_PS: r in {2, 4} (checked by the launcher)
-    // NONE / RELU / LRELU(0.1) as max(v,0) + slope*min(v,0): exact (one term is 0), branch-free
+    // NONE / RELU / LRELU(0.1) as max(v, slope*v) with slope 1 / 0 / 0.1: exact, branch-free, 2 VALU ops
     e.slope = a.act == CRFP_ACT_RELU ? 0.0f : (a.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
     e.post = a.post_scale;
     e.bp = reinterpret_cast<const float4*>(a.bpk);
@@ -175,10 +178,12 @@ __device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
         e.dq0[d] = on ? a.dst[d].q0 : 0;
         e.dq1[d] = on ? a.dst[d].q1 : 0;
     }
+    e.single = a.ndst == 1 && a.dst[0].q0 == 0 && a.dst[0].q1 >= e.ncq;
+    e.dbg = a.stamps;
     return e;
 }
 
-template <int CT, int PT, int RPW, int STORE, bool VBIAS, bool SLOWACT>
+template <int CT, int PT, int RPW, int STORE, int VBIAS, bool SLOWACT>
 __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[CT][PT], int T0, int tx0, int ty0,
                                                 int wave, int j, int h, const float2* flpre) {
     const int H = e.H, W = e.W;
@@ -188,7 +193,9 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int cq0 = (T0 + ct) * 8 + 2 * g;          // wave-uniform
-            if (VBIAS) {
+            if (VBIAS == 2) {
+                bb[ct][g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else if (VBIAS == 1) {
                 bb[ct][g] = e.bp[cq0 + h];
             } else {
                 const float4 b0 = e.bp[cq0], b1 = e.bp[cq0 + 1];
@@ -196,8 +203,14 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
             }
         }
 
+#ifdef CRFP_EPI_DBG
+    long long d0 = __builtin_amdgcn_s_memtime(), d1 = 0;
+#endif
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
+#ifdef CRFP_EPI_DBG
+        if (pt == 1) d1 = __builtin_amdgcn_s_memtime();
+#endif
         const int y = ty0 + wave * RPW + (pt >> 1), x = tx0 + (pt & 1) * 32 + j;
         if (y >= H || x >= W) continue;
         float2 fl = make_float2(0.0f, 0.0f);
@@ -236,25 +249,34 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                     for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], e.act) * e.post;
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = (fmaxf(v[c], 0.0f) + e.slope * fminf(v[c], 0.0f)) * e.post;
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], e.slope * v[c]) * e.post;   // slope in {1, 0, 0.1}: none / relu / lrelu
                 }
-                if (STORE != ST_PS) {  // zero the padding components of a ragged last quad
+                if (STORE != ST_PS && (e.cout & 3)) {  // zero the padding components of a ragged last quad (wave-uniform test)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (4 * cq + c >= e.cout) v[c] = 0.0f;
                 }
                 if (e.rp) { v[0] += rr[ct][g].x; v[1] += rr[ct][g].y; v[2] += rr[ct][g].z; v[3] += rr[ct][g].w; }
+                // store addresses = per-lane pixel offset (one 32-bit multiply per pixel tile) + wave-uniform 64-bit
+                // part per quad: the per-lane 64-bit multiplies of the first version were most of the epilogue's 6 k cycles
                 if (STORE == ST_Q4 || STORE == ST_OFFMASK) {
+                    if (e.single) {   // one destination that takes every quad (wave-uniform)
+                        const int cq0u = (T0 + ct) * 8 + 2 * g;
+                        *reinterpret_cast<float4*>(e.dp[0] + (long long)cq0u * e.dplane[0] + h * e.dplane[0] + (y * e.dpitch[0] + x) * 4) =
+                            make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
 #pragma unroll
-                    for (int d = 0; d < CRFP_MAX_DST; ++d)
-                        if (cq >= e.dq0[d] && cq < e.dq1[d])
-                            *reinterpret_cast<float4*>(e.dp[d] + (cq - e.dq0[d]) * e.dplane[d] + ((long long)y * e.dpitch[d] + x) * 4) =
-                                make_float4(v[0], v[1], v[2], v[3]);
+                        for (int d = 0; d < CRFP_MAX_DST; ++d)
+                            if (cq >= e.dq0[d] && cq < e.dq1[d])
+                                *reinterpret_cast<float4*>(e.dp[d] + (cq - e.dq0[d]) * e.dplane[d] + (y * e.dpitch[d] + x) * 4) =
+                                    make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 } else if (STORE == ST_PS) {
-                    const int lr = e.lr;
-                    const int Q = cq >> (2 * lr), sidx = cq & ((1 << (2 * lr)) - 1), i = sidx >> lr, jj = sidx & ((1 << lr) - 1);
-                    *reinterpret_cast<float4*>(e.dp[0] + (((long long)Q * e.dstH + (y << lr) + i) * e.dstW + (x << lr) + jj) * 4) =
-                        make_float4(v[0], v[1], v[2], v[3]);
+                    // cq0 is even and r >= 2: both lane halves share (Q, i) and differ by jj = +h
+                    const int lr = e.lr, cq0u = (T0 + ct) * 8 + 2 * g;
+                    const int Q = cq0u >> (2 * lr), sidx = cq0u & ((1 << (2 * lr)) - 1), i = sidx >> lr, jj = sidx & ((1 << lr) - 1);
+                    *reinterpret_cast<float4*>(e.dp[0] + ((long long)Q * e.dstH + i) * e.dstW * 4 + jj * 4 +
+                                               (((y << lr) * e.dstW + (x << lr)) + h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {  // ST_NCHW
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -264,10 +286,16 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                 }
             }
     }
+#ifdef CRFP_EPI_DBG
+    if (e.dbg && threadIdx.x == 0) {
+        long long* o = e.dbg + (16384 + (long long)blockIdx.x) * 8;
+        o[0] = d0; o[1] = d1; o[2] = __builtin_amdgcn_s_memtime(); o[3] = 1;
+    }
+#endif
 }
 
 // e: epi_ctx() made once per workgroup (outside any loop over cout tiles)
-template <int CT, int PT, int RPW, bool VBIAS = true>
+template <int CT, int PT, int RPW, int VBIAS = 1>
 __device__ __forceinline__ void conv_epilogue(const EpiCtx& e, f32x16 (&acc)[CT][PT], int T0, int tx0, int ty0,
                                               int wave, int j, int h, const float2* flpre = nullptr) {
     const bool slow = e.act == CRFP_ACT_TANH || e.act == CRFP_ACT_SIGMOID;   // API only; the engine never uses them here
@@ -574,6 +602,20 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[ct][pt][e] = 0.0f; acl[ct][pt][e] = 0.0f; }
+    {   // accumulators start at the bias: its loads are the first of the kernel and long landed when the MFMAs begin
+        const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bq = bp[(T0 + ct) * 8 + 2 * g + h];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    acc[ct][pt][4 * g + 0] = bq.x; acc[ct][pt][4 * g + 1] = bq.y;
+                    acc[ct][pt][4 * g + 2] = bq.z; acc[ct][pt][4 * g + 3] = bq.w;
+                }
+            }
+    }
 
     const int nchunks = a.kq >> 2;
     const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(NP == 3 ? a.wsplit : a.wsplit16);
@@ -678,12 +720,17 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[ct][pt][e] += acl[ct][pt][e] * (1.0f / F16_RES_SCALE);
     }
+    long long te1 = 0, te2 = 0;
+    if (a.stamps) { asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[0][PT - 1][15])); te1 = __builtin_amdgcn_s_memtime(); }
     const EpiCtx ec = epi_ctx(a, n);
-    conv_epilogue<CT, PT, RPW>(ec, acc, T0, tx0, ty0, wave, j, h);
+    if (a.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(ec.dpitch[0]), "s"(ec.ncq), "s"(ec.slope)); te2 = __builtin_amdgcn_s_memtime(); }
+    conv_epilogue<CT, PT, RPW, 2>(ec, acc, T0, tx0, ty0, wave, j, h);
     if (a.stamps) {
         const long long ti = __builtin_amdgcn_s_memtime();      // epilogue issued (stores in flight)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
+            a.stamps[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 2] = te1;   // overwrites phase C (unused here)
+            a.stamps[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 3] = te2;   // overwrites phase D
             a.stamps[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ti;
             a.stamps[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memtime();
         }
@@ -1000,7 +1047,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_spli
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[0][pt][e] += acl[0][pt][e] * (1.0f / F16_RES_SCALE);
             }
-            conv_epilogue<1, PT, RPW, false>(ec, acc, ct, tx0, ty0, wave, j, h, flpre);
+            conv_epilogue<1, PT, RPW, 0>(ec, acc, ct, tx0, ty0, wave, j, h, flpre);
         }
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
     }
@@ -1211,14 +1258,14 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
             }
         }
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
-        if (IS && ch == nchunks - 1) conv_epilogue<1, 2, 1, false>(ec, acc, step / nchunks, tx0, ty0, wave, j, h, flpre);
+        if (IS && ch == nchunks - 1) conv_epilogue<1, 2, 1, 0>(ec, acc, step / nchunks, tx0, ty0, wave, j, h, flpre);
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t; }
     }
     if (a.stamps && tid == 0) {
         long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4;
         o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD;
     }
-    if (!IS) conv_epilogue<1, 2, 1, false>(ec, acc, T0, tx0, ty0, wave, j, h, flpre);
+    if (!IS) conv_epilogue<1, 2, 1, 0>(ec, acc, T0, tx0, ty0, wave, j, h, flpre);
 }
 
 // split weight pack: wsplit bf16 index =

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
     }
     const float4 bias = *reinterpret_cast<const float4*>(a.bpk);
     const int cout = a.cout, act = a.act;
-    // NONE / RELU / LRELU(0.1) as max(v,0) + slope*min(v,0) (exact); tanh / sigmoid take the slow branch
+    // NONE / RELU / LRELU(0.1) as max(v, slope*v) with slope 1 / 0 / 0.1 (exact); tanh / sigmoid take the slow branch
     const float slope = act == CRFP_ACT_RELU ? 0.0f : (act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
     const bool slow_act = act == CRFP_ACT_TANH || act == CRFP_ACT_SIGMOID;
     const float post = a.post_scale;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
                         for (int o = 0; o < 4; ++o) v[o] = n_act(acc[i][o], act) * post;
                     } else {
 #pragma unroll
-                        for (int o = 0; o < 4; ++o) v[o] = (fmaxf(acc[i][o], 0.0f) + slope * fminf(acc[i][o], 0.0f)) * post;
+                        for (int o = 0; o < 4; ++o) v[o] = fmaxf(acc[i][o], slope * acc[i][o]) * post;
                     }
 #pragma unroll
                     for (int o = 0; o < 4; ++o)

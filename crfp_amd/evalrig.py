@@ -6,7 +6,7 @@ every 50th batch skipped (:350-351), RGB PSNR on the tensors as they are and PSN
 ``24.966*c0 + 128.553*c1 + 65.481*c2 + 16`` (utils.py:328-330, BGR weights applied to RGB-ordered data,
 kept as is) after the data-dependent range rule of utils.py:244-250, arithmetic mean of per-frame
 values.  Clips are independent: clip c runs on rank c mod world; the only collective is the final
-sum of (sum_psnr, sum_psnr_y, n_frames).
+sum of (sum_psnr, sum_ssim, sum_psnr_y, sum_ssim_y, n_frames).
 """
 from __future__ import annotations
 
@@ -56,21 +56,42 @@ def frame_psnrs(sr: torch.Tensor, hr: torch.Tensor):
     return p, py
 
 
-def evaluate(clip_fn: Callable[[int], Sequence[float]], n_clips: int, rank: int = 0, world: int = 1, dist=None,
+def frame_metrics(sr: torch.Tensor, hr: torch.Tensor):
+    """(PSNR, SSIM, PSNR-Y, SSIM-Y) of one frame pair [1,3,H,W] exactly as eval_basicvsr logs them
+    (trainer.py:348-369): all-ones mask, RGB on the tensors as they are, Y through bgr2ycbcr(y_only) on the
+    RGB-ordered data; two passes of the fused HIP PSNR+SSIM kernel (crfp_amd/utils.py)."""
+    from . import utils as U
+    p, s = U.calc_psnr_and_ssim_cuda(sr, hr, None)
+    ys = U.bgr2ycbcr(sr.permute(0, 2, 3, 1), y_only=True)
+    yh = U.bgr2ycbcr(hr.permute(0, 2, 3, 1), y_only=True)
+    py, sy = U.calc_psnr_and_ssim_cuda(ys, yh, None)
+    return float(p), float(s), float(py), float(sy)
+
+
+def evaluate(clip_fn: Callable[[int], Sequence[Sequence[float]]], n_clips: int, rank: int = 0, world: int = 1, dist=None,
              device: Optional[torch.device] = None):
-    """Run `clip_fn(clip_index) -> [(psnr, psnr_y) per counted frame]` on this rank's shard and reduce.
-    Returns dict(psnr, psnr_y, frames)."""
-    sums = torch.zeros(3, dtype=torch.float64)
+    """Run `clip_fn(clip_index) -> [per counted frame: (psnr, psnr_y) or (psnr, ssim, psnr_y, ssim_y)]` on this rank's
+    shard and reduce with ONE all-reduce of [sum psnr, sum ssim, sum psnr_y, sum ssim_y, n].
+    Returns dict(psnr, psnr_y, frames[, ssim, ssim_y])."""
+    sums = torch.zeros(5, dtype=torch.float64)
+    have_ssim = False
     for c in shard_clips(n_clips, rank, world):
-        for p, py in clip_fn(c):
-            sums += torch.tensor([p, py, 1.0], dtype=torch.float64)
+        for m in clip_fn(c):
+            if len(m) == 2:
+                sums += torch.tensor([m[0], 0.0, m[1], 0.0, 1.0], dtype=torch.float64)
+            else:
+                have_ssim = True
+                sums += torch.tensor([m[0], m[1], m[2], m[3], 1.0], dtype=torch.float64)
     if dist is not None and world > 1:
         buf = sums.to(device) if device is not None else sums
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         sums = buf.cpu()
-    n = float(sums[2])
-    return {"psnr": float(sums[0]) / n if n else float("nan"), "psnr_y": float(sums[1]) / n if n else float("nan"),
-            "frames": int(n)}
+    n = float(sums[4])
+    nan = float("nan")
+    out = {"psnr": float(sums[0]) / n if n else nan, "psnr_y": float(sums[2]) / n if n else nan, "frames": int(n)}
+    if have_ssim:
+        out.update(ssim=float(sums[1]) / n if n else nan, ssim_y=float(sums[3]) / n if n else nan)
+    return out
 
 
 def counted_frames(i_batch: int, n_frames: int) -> Iterable[int]:
@@ -78,11 +99,12 @@ def counted_frames(i_batch: int, n_frames: int) -> Iterable[int]:
     return (i for i in range(n_frames) if not (i == 0 and i_batch % 50 == 0))
 
 
-def eval_clip(model, batch: dict, i_batch: int):
+def eval_clip(model, batch: dict, i_batch: int, with_ssim: bool = True):
     """One eval batch through the model (trainer.py:307-369): batch has LR, HR, Ref, Ref_sp on device."""
     with torch.no_grad():
         sr = model(lrs=batch["LR"], fvs=batch["Ref"], mks=batch["Ref_sp"])
     B, N, C, H, W = sr.shape
     sr = sr.view(B * N, C, H, W)
     hr = batch["HR"].view(B * N, -1, H, W)
-    return [frame_psnrs(sr[i:i + 1], hr[i:i + 1]) for i in counted_frames(i_batch, N)]
+    fn = frame_metrics if with_ssim else frame_psnrs
+    return [fn(sr[i:i + 1], hr[i:i + 1]) for i in counted_frames(i_batch, N)]

@@ -82,6 +82,14 @@ int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, 
  * utils.py:328-330), c==3 only.  acc is 2 doubles (device), zeroed by the caller. */
 int crfp_psnr_partial_f32(const float* a, const float* b, double* acc, int n, int c, int h, int w, void* stream);
 
+/* Masked PSNR + SSIM raw sums in one pass: replaces utils.calc_psnr_and_ssim_cuda -> psnr_cuda / ssim_cuda / _ssim
+ * (utils.py:166-185,187-240,242-254; callers trainer.py:349-369, test_video.py:357-369).  a, b: [n,c,h,w] fp32; mask:
+ * [n,1,h,w] bytes (0 / non-0) or NULL (= all ones); x' = x*mul + add is the reference's range conversion (1/255, 0 when
+ * max-min > 2; 0.5, 0.5 when > 1; else 1, 0).  acc (3 doubles, zeroed by the caller) receives
+ * acc[0] += sum m (a'-b')^2 (all channels), acc[1] += sum m SSIM_map (all channels), acc[2] += sum m (per pixel). */
+int crfp_psnr_ssim_partial_f32(const float* a, const float* b, const unsigned char* mask, double* acc, int n, int c, int h, int w,
+                               float mul, float add, void* stream);
+
 /* ---- CRFP_DSV engine (mid_channels=32, hr_dcn=True, offset_prop=True; y_only selectable).
  * Parameters arrive as CRFP_DSV_NUM_PARAMS device pointers in the order of the reference's
  * state_dict (weight then bias of each conv, list in crfp_dsv_param_name). */

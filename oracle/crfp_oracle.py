@@ -346,6 +346,37 @@ def range_normalise(sr: Tensor, hr: Tensor):
     return sr, hr
 
 
+def _gaussian_window(channel: int, window_size: int = 11, sigma: float = 1.5) -> Tensor:
+    """utils.gaussian / create_window (utils.py:187-195)."""
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, window_size, window_size).contiguous()
+
+
+def ssim(img1: Tensor, img2: Tensor, mask: Tensor) -> float:
+    """utils.ssim_cuda -> ssim -> _ssim, size_average branch (utils.py:197-240): masked mean of the SSIM map."""
+    channel = img1.shape[1]
+    window = _gaussian_window(channel).type_as(img1)
+    pad = 5
+    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
+    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    C = ssim_map.shape[1]
+    return float((ssim_map * mask).sum() / (mask.float().sum() * C))
+
+
+def calc_psnr_and_ssim(sr: Tensor, hr: Tensor, mask: Tensor):
+    """utils.calc_psnr_and_ssim_cuda (utils.py:242-254)."""
+    a, b = range_normalise(sr, hr)
+    return psnr(a, b, mask), ssim(a, b, mask)
+
+
 def psnr_rgb_and_y(sr: Tensor, hr: Tensor):
     """The two PSNR figures Trainer.eval_basicvsr logs per frame (trainer.py:348-369), mask = ones."""
     ones = torch.ones((sr.shape[0], 1, sr.shape[2], sr.shape[3]))

@@ -172,6 +172,19 @@ def main():
                                                ref_utils.bgr2ycbcr(T(hr).permute(0, 2, 3, 1), y_only=True), ones)
     out.update(metric_sr=sr, metric_hr=hr, metric_psnr=np.float64(float(p)), metric_ssim=np.float64(float(s)),
                metric_psnr_y=np.float64(float(py)), metric_ssim_y=np.float64(float(sy)))
+    # region masks as test_video.py:340-369 passes them (fovea box, dilated ring), and the [0,255] range branch
+    box = torch.zeros(1, 1, 32, 48); box[:, :, 6:22, 10:30] = 1
+    ring = box.clone()
+    for _ in range(3):
+        ring = torch.clamp(torch.nn.functional.conv2d(ring, torch.ones(1, 1, 3, 3), padding=1), 0, 1)
+    ring = torch.logical_and(torch.logical_not(box.bool()), ring.bool())
+    pb, sb = ref_utils.calc_psnr_and_ssim_cuda(T(sr), T(hr), box)
+    pr, sr_ = ref_utils.calc_psnr_and_ssim_cuda(T(sr), T(hr), ring)
+    p255, s255 = ref_utils.calc_psnr_and_ssim_cuda(T(sr) * 255.0, T(hr) * 255.0, box)
+    out.update(metric_box=box.numpy().astype(np.uint8), metric_ring=ring.numpy().astype(np.uint8),
+               metric_psnr_box=np.float64(float(pb)), metric_ssim_box=np.float64(float(sb)),
+               metric_psnr_ring=np.float64(float(pr)), metric_ssim_ring=np.float64(float(sr_)),
+               metric_psnr_box255=np.float64(float(p255)), metric_ssim_box255=np.float64(float(s255)))
     np.savez_compressed(os.path.join(HERE, "ops_small.npz"), **out)
     print("ops_small.npz:", len(out), "arrays")
 

@@ -337,3 +337,49 @@ def test_concurrent_clips_on_two_streams_are_bit_exact():
         torch.cuda.synchronize()
         for k in range(2):
             assert maxdiff(outs[k], refs[k]) == 0.0
+
+
+def test_masked_psnr_ssim_golden_and_oracle(ops_golden, orc):
+    """crfp_amd.utils.calc_psnr_and_ssim_cuda (one HIP pass) vs the reference's values (golden) and vs the oracle on a
+    ragged size with a random mask and the [0,255] / [-1,1] range branches (utils.py:242-254)."""
+    from crfp_amd import utils as U
+    g, d = ops_golden, dev()
+    sr, hr = T(g["metric_sr"]).to(d), T(g["metric_hr"]).to(d)
+    ones = torch.ones(1, 1, *sr.shape[2:], device=d)
+    for mask, tag in ((ones, ""), (T(g["metric_box"]).to(d), "_box"), (T(g["metric_ring"]).to(d), "_ring")):
+        p, s = U.calc_psnr_and_ssim_cuda(sr, hr, mask)
+        assert abs(float(p) - float(g["metric_psnr" + tag])) < 1e-4      # dB
+        assert abs(float(s) - float(g["metric_ssim" + tag])) < 2e-6
+    p, s = U.calc_psnr_and_ssim_cuda(sr * 255.0, hr * 255.0, T(g["metric_box"]).to(d))
+    assert abs(float(p) - float(g["metric_psnr_box255"])) < 1e-4 and abs(float(s) - float(g["metric_ssim_box255"])) < 2e-6
+    ys, yh = U.bgr2ycbcr(sr.permute(0, 2, 3, 1), y_only=True), U.bgr2ycbcr(hr.permute(0, 2, 3, 1), y_only=True)
+    py, sy = U.calc_psnr_and_ssim_cuda(ys, yh, ones)
+    assert abs(float(py) - float(g["metric_psnr_y"])) < 1e-4 and abs(float(sy) - float(g["metric_ssim_y"])) < 2e-6
+    # ragged tiles, 2 images, random mask, all three range branches
+    rs = np.random.RandomState(5)
+    a = rs.uniform(0, 1, (2, 3, 70, 150)).astype(np.float32)
+    b = np.clip(a + rs.normal(0, 0.05, a.shape), 0, 1).astype(np.float32)
+    m = (rs.uniform(0, 1, (2, 1, 70, 150)) > 0.6)
+    for scale, shift in ((1.0, 0.0), (255.0, 0.0), (2.0, -1.0)):
+        A, B = T(a) * scale + shift, T(b) * scale + shift
+        pr, sr_ = orc.calc_psnr_and_ssim(A, B, T(m).float())
+        p, s = U.calc_psnr_and_ssim_cuda(A.to(d), B.to(d), T(m).to(d))
+        assert abs(float(p) - pr) < 1e-4 and abs(float(s) - sr_) < 2e-6
+    # identical images: the reference's mse == 0 special case
+    p, s = U.calc_psnr_and_ssim_cuda(sr, sr, ones)
+    assert abs(float(p) - orc.psnr(sr.cpu(), sr.cpu(), ones.cpu())) < 1e-4 and abs(float(s) - 1.0) < 1e-6
+
+
+def test_evalrig_frame_metrics_vs_oracle(orc):
+    """The four per-frame figures Trainer.eval_basicvsr logs (trainer.py:348-369), HIP vs oracle."""
+    from crfp_amd import evalrig
+    rs = np.random.RandomState(9)
+    hr = rs.uniform(0, 1, (1, 3, 96, 160)).astype(np.float32)
+    sr = (hr + rs.normal(0, 0.02, hr.shape)).astype(np.float32)
+    p, s, py, sy = evalrig.frame_metrics(T(sr).to(dev()), T(hr).to(dev()))
+    ones = torch.ones(1, 1, 96, 160)
+    pr, sr_ = orc.calc_psnr_and_ssim(T(sr), T(hr), ones)
+    pyr, syr = orc.calc_psnr_and_ssim(orc.to_y(T(sr).permute(0, 2, 3, 1)), orc.to_y(T(hr).permute(0, 2, 3, 1)), ones)
+    assert abs(p - pr) < 1e-4 and abs(s - sr_) < 2e-6 and abs(py - pyr) < 1e-4 and abs(sy - syr) < 2e-6
+    p2, py2 = evalrig.frame_psnrs(T(sr).to(dev()), T(hr).to(dev()))
+    assert abs(p2 - p) < 1e-4 and abs(py2 - py) < 1e-4

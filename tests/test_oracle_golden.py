@@ -136,3 +136,20 @@ def test_streaming_variant_with_regional_mask():
             so.clear_states()
         outs.append(so(T(lrs[:, i:i + 1]), T(fvs[:, i:i + 1]), T(mks[:, i:i + 1]), T(g["fgs"][:, i:i + 1])))
     close(torch.cat(outs, dim=1), g["out"], 2e-5)
+
+
+def test_masked_psnr_ssim_against_reference(ops_golden):
+    """utils.calc_psnr_and_ssim_cuda with the ones / fovea-box / dilated-ring masks of trainer.py:348 and
+    test_video.py:340-369, and its [0,255] range branch."""
+    g = ops_golden
+    sr, hr = T(g["metric_sr"]), T(g["metric_hr"])
+    ones = torch.ones(1, 1, *sr.shape[2:])
+    for mask, tag in ((ones, ""), (T(g["metric_box"]).float(), "_box"), (T(g["metric_ring"]).float(), "_ring")):
+        p, s = orc.calc_psnr_and_ssim(sr, hr, mask)
+        assert abs(p - float(g["metric_psnr" + tag])) < 1e-4
+        assert abs(s - float(g["metric_ssim" + tag])) < 1e-6
+    p, s = orc.calc_psnr_and_ssim(sr * 255.0, hr * 255.0, T(g["metric_box"]).float())
+    assert abs(p - float(g["metric_psnr_box255"])) < 1e-4 and abs(s - float(g["metric_ssim_box255"])) < 1e-6
+    ys, yh = orc.to_y(sr.permute(0, 2, 3, 1)), orc.to_y(hr.permute(0, 2, 3, 1))
+    py, sy = orc.calc_psnr_and_ssim(ys, yh, ones)
+    assert abs(py - float(g["metric_psnr_y"])) < 1e-4 and abs(sy - float(g["metric_ssim_y"])) < 1e-6

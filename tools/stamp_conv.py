@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 site = sys.argv[1] if len(sys.argv) > 1 else "conv_mfma:res.main0"
 dev = torch.device("cuda:0")
-buf = torch.zeros(32768 * 4, dtype=torch.int64, device=dev)
+buf = torch.zeros(65536 * 4, dtype=torch.int64, device=dev)
 os.environ["CRFP_STAMP_PTR"] = str(buf.data_ptr()); os.environ["CRFP_STAMP_NAME"] = site
 from crfp_amd import synth
 from crfp_amd.model import CRFP
@@ -26,9 +26,15 @@ if len(b8):
     ent, mm, end = b8[:, 4] - t0, b8[:, 5] - t0, b8[:, 6] - t0
     print(f"  entry->first stamp(t0) n/a; entry->main loop end mean {(mm - ent).mean():.0f}; epilogue+store drain mean {(end - mm).mean():.0f}; WG lifetime mean {(end - ent).mean():.0f}")
     iss = b8[:, 7] - t0
+    e1, e2 = b8[:, 2] - t0, b8[:, 3] - t0
+    print(f"  (epilogue split: MFMA drain + f16 combine {(e1 - mm).mean():.0f}; epi_ctx scalar loads {(e2 - e1).mean():.0f}; act + address + store issue {(iss - e2).mean():.0f})")
     print(f"  epilogue issue (bias, act, store issue) mean {(iss - mm).mean():.0f}; store drain (s_waitcnt vmcnt(0)) mean {(end - iss).mean():.0f}")
 lb = buf.view(-1, 4)[16384:].cpu().double(); lnz = lb[(lb.sum(1) > 0)]
 if len(lnz):
     print(" loader wave: blocks", len(lnz))
     for i, nm in enumerate(["issue loads", "split + write tile", "X..Y (weight image write)", "wait at X"]):
         print(f"  {nm:45s} mean {lnz[:, i].mean():10.0f}  max {lnz[:, i].max():10.0f}")
+
+dbg = buf.view(-1, 8)[16384:16384 + 1024].cpu().double(); dbg = dbg[dbg[:, 3] > 0]
+if len(dbg):
+    print(f"  epilogue body (CRFP_EPI_DBG build): pixel tile 0 {(dbg[:,1]-dbg[:,0]).mean():.0f} cycles, pixel tile 1 + exit {(dbg[:,2]-dbg[:,1]).mean():.0f}")
