@@ -383,3 +383,41 @@ def test_evalrig_frame_metrics_vs_oracle(orc):
     assert abs(p - pr) < 1e-4 and abs(s - sr_) < 2e-6 and abs(py - pyr) < 1e-4 and abs(sy - syr) < 2e-6
     p2, py2 = evalrig.frame_psnrs(T(sr).to(dev()), T(hr).to(dev()))
     assert abs(p2 - p) < 1e-4 and abs(py2 - py) < 1e-4
+
+
+def test_gaze_video_rig_vs_oracle(orc):
+    """crfp_amd.gaze.run_gaze_video (streaming model + region metrics on the GPU, regional-DCN mask on) against the
+    same loop driven through the oracle's StreamOracle and oracle metrics (test_video.py:303-379)."""
+    from crfp_amd import gaze, synth
+    from crfp_amd.model import CRFP
+    sd = synth.make_state_dict(7)
+    P = orc.load_numpy_state(sd)
+    h, w, N, fv = 16, 24, 5, 32
+    lrs, fvs, _ = synth.make_clip(21, 1, N, h, w, fv_size=fv)
+    lr = T(lrs[0])
+    rs = np.random.RandomState(4)
+    gt = torch.clamp(F.interpolate(lr, scale_factor=8, mode="bilinear", align_corners=False) +
+                     T(rs.normal(0, 0.02, (N, 3, 8 * h, 8 * w)).astype(np.float32)), 0, 1)
+    m = CRFP.MRCF_simple_v18(device=dev(), mid_channels=32)
+    m.load_state_dict({k: T(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.to(dev()).eval()
+    res = gaze.run_gaze_video(m, lr.to(dev()), gt.to(dev()), sigma=6.0, fv_size=fv, seed=11, fv_start=1,
+                              regional_dcn=True, rg=96)
+
+    class OracleModel:
+        def __init__(self):
+            self.o = orc.StreamOracle(P)
+
+        def clear_states(self):
+            self.o.clear_states()
+
+        def __call__(self, lrs, fvs, mks, fgs):
+            return self.o(lrs, fvs, mks.float(), fgs.float())
+
+    ref = gaze.run_gaze_video(OracleModel(), lr, gt, sigma=6.0, fv_size=fv, seed=11, fv_start=1, regional_dcn=True, rg=96,
+                              metric_fn=lambda a, b, mk: orc.calc_psnr_and_ssim(a, b, mk.float()))
+    assert res["trajectory"] == ref["trajectory"] and res["frames"] == N
+    for r in ("whole", "fovea", "outskirt", "past"):
+        assert abs(res[f"psnr_{r}"] - ref[f"psnr_{r}"]) < 2e-3, r          # dB
+        assert abs(res[f"ssim_{r}"] - ref[f"ssim_{r}"]) < 2e-5, r
+    assert len(res["per_frame"]["past"]) == N - 1

@@ -165,3 +165,39 @@ def test_device_code_has_no_packed_fp32_ops():
     n_mfma, _ = check_isa.count(_lib.LIB_PATH, r"v_mfma_f32_32x32x16_bf16")
     assert total > 10000 and n_mfma > 0
     assert n_pk == 0, f"{n_pk} packed-FP32 VALU instructions in {_lib.LIB_PATH}"
+
+
+def test_gaze_rig_masks_and_trajectory():
+    """crfp_amd.gaze vs a literal restatement of test_video.py:303-379 (iterated 3x3 dilation, mask algebra, history)."""
+    from crfp_amd import gaze
+    import torch.nn.functional as F
+    H, W, fv, N, sigma = 72, 96, 16, 6, 9.0
+    xs, ys = gaze.gaze_trajectory(N, H, W, sigma, np.random.RandomState(3))
+    rs = np.random.RandomState(3)
+    assert np.array_equal(xs, sigma * rs.randn(N) + W / 2) and np.array_equal(ys, sigma * rs.randn(N) + H / 2)
+    assert gaze.window_origin(W / 2 + 0.7, H / 2 - 0.2, fv, H, W) == (int(H / 2 - 0.2) - fv // 2, int(W / 2 + 0.7) - fv // 2)
+    assert gaze.window_origin(-5.0, 1e6, fv, H, W) == (H - fv, 0)                 # clipped instead of wrapping
+    assert gaze.regional_box(10, 20, 16, 40, 40, H, W) == (0, 38, 8, 48)
+    kern = torch.ones(1, 1, 3, 3)
+    masks = gaze.RegionMasks(H, W, fv, torch.device("cpu"), fv_start=1)
+    hist = []
+    past_ref = None
+    for n in range(N):
+        cy, cx = gaze.window_origin(xs[n], ys[n], fv, H, W)
+        m = masks.frame(n, cy, cx)
+        mk = torch.zeros(1, 1, H, W)
+        if n >= 1:
+            mk[:, :, cy:cy + fv, cx:cx + fv] = 1
+        mk_fv = mk.clone(); mk_fv[:, :, cy:cy + fv, cx:cx + fv] = 1
+        mk_out = mk_fv.clone()
+        for _ in range(10):
+            mk_out = torch.clamp(F.conv2d(mk_out, kern, padding=(1, 1)), 0, 1)
+        mk_out = torch.logical_and(torch.logical_not(mk), mk_out)
+        assert torch.equal(m["mk"], mk.bool()) and torch.equal(m["fovea"], mk_fv.bool()) and torch.equal(m["outskirt"], mk_out)
+        assert (m["past"] is None and past_ref is None) or torch.equal(m["past"], past_ref)
+        hist.append(mk_out)
+        if len(hist) > 3:
+            hist.pop(0)
+        past_ref = torch.sum(torch.cat(hist, dim=1), dim=1, keepdim=True).clip(0, 1).bool()
+        assert bool(m["fg"].all())
+    assert int(m["outskirt"].sum()) > 0 and not bool((m["outskirt"] & m["mk"]).any())
