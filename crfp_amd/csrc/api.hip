@@ -123,6 +123,62 @@ int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, 
     return launch_upsample_nchw(x, out, n, c, h, w, oh, ow, scale_h, scale_w, mul, (hipStream_t)stream);
 }
 
+int crfp_avgpool2_f32(const float* x, float* out, int n, int c, int h, int w, void* stream) {
+    if (!x || !out || n < 1 || c < 1 || h < 2 || w < 2) { set_error("avgpool2: bad argument"); return CRFP_E_BADARG; }
+    return launch_avgpool2_nchw(x, out, n, c, h, w, (hipStream_t)stream);
+}
+
+// fused a-15: conv_tttf on [state | x_hr], fovea blend, LeakyReLU -> new state; conv_last + bilinear x8 base -> frame
+size_t crfp_fovea_head_workspace_bytes(int n, int h, int w) {
+    const int H = 8 * h, W = 8 * w;
+    return 4 * q4_bytes(n, 4, H, W) + align_up((size_t)n * 3 * H * W * sizeof(float), 256) + 2 * align_up((9 * 2 * 16 + 4) * sizeof(float), 256);
+}
+
+int crfp_fovea_head_f32(const float* state, const float* x_hr, const unsigned char* mask, const float* lr, const float* w_tttf,
+                        const float* b_tttf, const float* w_last, const float* b_last, float* new_state, float* out, int n,
+                        int h, int w, int y_only, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!state || !x_hr || !mask || !lr || !w_tttf || !b_tttf || !w_last || !b_last || !new_state || !out || n < 1 || h < 1 || w < 1) {
+        set_error("fovea_head: bad argument");
+        return CRFP_E_BADARG;
+    }
+    if (!workspace || workspace_bytes < crfp_fovea_head_workspace_bytes(n, h, w)) { set_error("fovea_head: workspace too small"); return CRFP_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int H = 8 * h, W = 8 * w;
+    char* p = (char*)workspace;
+    float* sq = (float*)p; p += q4_bytes(n, 4, H, W);
+    float* xq = (float*)p; p += q4_bytes(n, 4, H, W);
+    float* nq = (float*)p; p += q4_bytes(n, 4, H, W);
+    float* bq = (float*)p; p += q4_bytes(n, 4, H, W);
+    float* up = (float*)p; p += align_up((size_t)n * 3 * H * W * sizeof(float), 256);
+    float* pk_t = (float*)p; p += align_up((9 * 2 * 16 + 4) * sizeof(float), 256);
+    float* pk_l = (float*)p;
+    const long long qs = (long long)H * W * 4;
+    auto plan = [&](int nsrc, int cin, int cout, int epi) {
+        NarrowArgs a;
+        memset(&a, 0, sizeof(a));
+        for (int i = 0; i < nsrc; ++i) { a.src[i].kind = SRC_Q4; a.src[i].nch = 4; a.src[i].nq = 1; a.src[i].cbase = 4 * i; a.src[i].bstride = qs; }
+        a.nsrc = nsrc; a.kq = nsrc; a.cin_total = cin; a.cout = cout; a.act = CRFP_ACT_NONE; a.epi = epi; a.y_only = y_only;
+        a.post_scale = 1.0f; a.N = n; a.H = H; a.W = W;
+        return a;
+    };
+    NarrowArgs t = plan(2, 8, 4, NE_BLEND), l = plan(1, 4, y_only ? 1 : 3, NE_LAST);
+    int rc = launch_nchw_to_q4(state, sq, n, 4, H, W, 0, s);
+    if (!rc) rc = launch_nchw_to_q4(x_hr, xq, n, 4, H, W, 0, s);
+    if (!rc) rc = launch_upsample_nchw(lr, up, n, 3, h, w, H, W, 0.125f, 0.125f, 1.0f, s);   // nn.Upsample(x8, bilinear, align_corners=False)
+    if (!rc) rc = launch_nchw_to_q4(up, bq, n, 3, H, W, 0, s);
+    if (!rc) rc = launch_narrow_pack(t, w_tttf, b_tttf, nullptr, nullptr, 0, pk_t, pk_t + 9 * 2 * 16, s);
+    if (!rc) rc = launch_narrow_pack(l, w_last, b_last, nullptr, nullptr, 0, pk_l, pk_l + 9 * 1 * 16, s);
+    if (rc) return rc;
+    t.src[0].p = sq; t.src[1].p = xq; t.wpk = pk_t; t.bpk = pk_t + 9 * 2 * 16; t.dst = nq; t.dst_bstride = qs;
+    t.mask = mask; t.mask_bstride = (long long)H * W;
+    rc = launch_narrow(t, "conv_narrow:tttf_blend", s);
+    l.src[0].p = nq; l.wpk = pk_l; l.bpk = pk_l + 9 * 1 * 16; l.dst = out; l.dst_bstride = (long long)(y_only ? 1 : 3) * H * W;
+    l.base = bq; l.base_bstride = qs;
+    if (!rc) rc = launch_narrow(l, "conv_narrow:last_plus_base", s);
+    if (!rc) rc = launch_q4_to_nchw(nq, new_state, n, 4, H, W, 0, s);
+    return rc;
+}
+
 int crfp_psnr_ssim_partial_f32(const float* a, const float* b, const unsigned char* mask, double* acc, int n, int c, int h, int w,
                                float mul, float add, void* stream) {
     if (!a || !b || !acc || n < 1 || c < 1 || h < 1 || w < 1) { set_error("psnr_ssim_partial: bad argument"); return CRFP_E_BADARG; }

@@ -219,6 +219,7 @@ int launch_upsample_nchw(const float* x, float* out, int N, int C, int H, int W,
                          float mul, hipStream_t s);
 int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long ob, int N, int H, int W, int r,
                   hipStream_t s);
+int launch_avgpool2_nchw(const float* x, float* out, int N, int C, int H, int W, hipStream_t s);
 int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W,
                        hipStream_t s);
 int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s);

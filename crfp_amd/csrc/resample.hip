@@ -300,6 +300,28 @@ int launch_scale_q4(const float* src, int src_pad, float* dst, int nq, int H, in
     return 0;
 }
 
+// nn.AvgPool2d(2, 2) on NCHW planes (floor mode: a trailing odd row / column is dropped) -- FNet's pooling (model/CRFP.py:755)
+__global__ void avgpool2_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int OH, int OW) {
+    const long long plane = blockIdx.y;
+    const float* px = x + plane * H * W;
+    float* po = out + plane * OH * OW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < OH * OW; i += gridDim.x * blockDim.x) {
+        const int oy = i / OW, ox = i - oy * OW;
+        const float* p = px + (long long)(2 * oy) * W + 2 * ox;
+        po[i] = ((p[0] + p[1]) + (p[W] + p[W + 1])) * 0.25f;
+    }
+}
+
+int launch_avgpool2_nchw(const float* x, float* out, int N, int C, int H, int W, hipStream_t s) {
+    const int OH = H / 2, OW = W / 2;
+    ProfScope prof("avgpool2_nchw", s, (double)N * C * ((double)H * W + (double)OH * OW) * 4.0, 0);
+    int blocks = (OH * OW + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    avgpool2_nchw_kernel<<<dim3(blocks, N * C), 256, 0, s>>>(x, out, H, W, OH, OW);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
 // acc[0] += sum (a-b)^2 ; acc[1] += sum (Y(a)-Y(b))^2 with Y = 24.966*c0 + 128.553*c1 + 65.481*c2 + 16
 __global__ void psnr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ acc,
                                     int C, long long HW) {

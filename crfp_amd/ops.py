@@ -113,3 +113,32 @@ def sq_err_sums(a, b):
     _lib.check(_lib.lib().crfp_psnr_partial_f32(a.data_ptr(), b.data_ptr(), acc.data_ptr(), n, c, h, w, _stream()),
                "crfp_psnr_partial_f32")
     return acc
+
+
+def avgpool2(x):
+    """nn.AvgPool2d(2, 2) (floor mode) on an NCHW tensor."""
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().crfp_avgpool2_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "crfp_avgpool2_f32")
+    return out
+
+
+def fovea_head(state, x_hr, mask, lr, w_tttf, b_tttf, w_last, b_last, y_only=False):
+    """Fused fovea fusion + output head (model/CRFP.py:1672-1684) -> (new_state [n,4,8h,8w], out [n,3|1,8h,8w])."""
+    state, x_hr, lr = _dev(state, "state"), _dev(x_hr, "x_hr"), _dev(lr, "lr")
+    w_tttf, b_tttf, w_last, b_last = (_dev(t, "weights") for t in (w_tttf, b_tttf, w_last, b_last))
+    n, _, h, w = lr.shape
+    H, W = 8 * h, 8 * w
+    if tuple(state.shape) != (n, 4, H, W) or tuple(x_hr.shape) != (n, 4, H, W):
+        raise ValueError("state / x_hr must be [n,4,8h,8w]")
+    m8 = (mask != 0 if mask.dtype != torch.bool else mask).to(state.device).expand(n, 1, H, W).contiguous().view(torch.uint8)
+    L = _lib.lib()
+    ws = torch.empty(L.crfp_fovea_head_workspace_bytes(n, h, w), dtype=torch.uint8, device=state.device)
+    new_state = torch.empty_like(state)
+    out = torch.empty((n, 1 if y_only else 3, H, W), dtype=torch.float32, device=state.device)
+    _lib.check(L.crfp_fovea_head_f32(state.data_ptr(), x_hr.data_ptr(), m8.data_ptr(), lr.data_ptr(), w_tttf.data_ptr(),
+                                     b_tttf.data_ptr(), w_last.data_ptr(), b_last.data_ptr(), new_state.data_ptr(),
+                                     out.data_ptr(), n, h, w, int(bool(y_only)), ws.data_ptr(), ws.numel(), _stream()),
+               "crfp_fovea_head_f32")
+    return new_state, out

@@ -82,6 +82,19 @@ int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, 
  * utils.py:328-330), c==3 only.  acc is 2 doubles (device), zeroed by the caller. */
 int crfp_psnr_partial_f32(const float* a, const float* b, double* acc, int n, int c, int h, int w, void* stream);
 
+/* nn.AvgPool2d(2, 2), floor mode (FNet, model/CRFP.py:755): x [n,c,h,w] -> out [n,c,h/2,w/2]. */
+int crfp_avgpool2_f32(const float* x, float* out, int n, int c, int h, int w, void* stream);
+
+/* Fovea fusion + output head of one frame, fused (model/CRFP.py:1672-1684):
+ *   f' = conv_tttf(cat(state, x_hr)); new_state = LeakyReLU_0.1(mask ? f' : state); out = conv_last(new_state) + bilinear_x8(lr)
+ *   (y_only: + bilinear_x8(0.299 R + 0.587 G + 0.114 B), one channel).
+ * state, x_hr, new_state: [n,4,8h,8w]; mask: [n,1,8h,8w] bytes; lr: [n,3,h,w]; out: [n,3|1,8h,8w];
+ * w_tttf [4,8,3,3], b_tttf [4], w_last [3|1,4,3,3], b_last [3|1] in the reference's OIHW order. */
+size_t crfp_fovea_head_workspace_bytes(int n, int h, int w);
+int crfp_fovea_head_f32(const float* state, const float* x_hr, const unsigned char* mask, const float* lr, const float* w_tttf,
+                        const float* b_tttf, const float* w_last, const float* b_last, float* new_state, float* out, int n,
+                        int h, int w, int y_only, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Masked PSNR + SSIM raw sums in one pass: replaces utils.calc_psnr_and_ssim_cuda -> psnr_cuda / ssim_cuda / _ssim
  * (utils.py:166-185,187-240,242-254; callers trainer.py:349-369, test_video.py:357-369).  a, b: [n,c,h,w] fp32; mask:
  * [n,1,h,w] bytes (0 / non-0) or NULL (= all ones); x' = x*mul + add is the reference's range conversion (1/255, 0 when

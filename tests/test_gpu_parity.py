@@ -421,3 +421,32 @@ def test_gaze_video_rig_vs_oracle(orc):
         assert abs(res[f"psnr_{r}"] - ref[f"psnr_{r}"]) < 2e-3, r          # dB
         assert abs(res[f"ssim_{r}"] - ref[f"ssim_{r}"]) < 2e-5, r
     assert len(res["per_frame"]["past"]) == N - 1
+
+
+def test_avgpool2_and_fovea_head_ops():
+    """C-ABI ops of SURVEY section 8b: crfp_avgpool2_f32 (odd sizes: floor mode) and the fused fovea head
+    crfp_fovea_head_f32 (model/CRFP.py:1672-1684) against plain ATen on the CPU."""
+    from crfp_amd import ops
+    rs = np.random.RandomState(17)
+    x = T(rs.normal(0, 1, (2, 5, 45, 81)).astype(np.float32))
+    assert maxdiff(ops.avgpool2(x.to(dev())), F.avg_pool2d(x, 2, 2)) < 1e-6
+    n, h, w = 2, 9, 13
+    H, W = 8 * h, 8 * w
+    state = T(rs.normal(0, 0.5, (n, 4, H, W)).astype(np.float32))
+    x_hr = T(rs.normal(0, 0.5, (n, 4, H, W)).astype(np.float32))
+    mask = T(rs.uniform(0, 1, (n, 1, H, W)) > 0.7)
+    lr = T(rs.uniform(0, 1, (n, 3, h, w)).astype(np.float32))
+    wt, bt = T(rs.normal(0, 0.2, (4, 8, 3, 3)).astype(np.float32)), T(rs.normal(0, 0.1, (4,)).astype(np.float32))
+    for y_only in (False, True):
+        co = 1 if y_only else 3
+        wl, bl = T(rs.normal(0, 0.2, (co, 4, 3, 3)).astype(np.float32)), T(rs.normal(0, 0.1, (co,)).astype(np.float32))
+        f2 = F.conv2d(torch.cat((state, x_hr), 1), wt, bt, padding=1)
+        mk = mask.float()
+        ns_ref = F.leaky_relu(mk * f2 + (1 - mk) * state, 0.1)
+        base = F.interpolate(lr, scale_factor=8, mode="bilinear", align_corners=False)
+        if y_only:
+            base = 0.299 * base[:, 0:1] + 0.587 * base[:, 1:2] + 0.114 * base[:, 2:3]
+        out_ref = F.conv2d(ns_ref, wl, bl, padding=1) + base
+        d = dev()
+        ns, out = ops.fovea_head(state.to(d), x_hr.to(d), mask.to(d), lr.to(d), wt.to(d), bt.to(d), wl.to(d), bl.to(d), y_only)
+        assert maxdiff(ns, ns_ref) < 2e-5 and maxdiff(out, out_ref) < 2e-5
