@@ -108,3 +108,69 @@ def eval_clip(model, batch: dict, i_batch: int, with_ssim: bool = True):
     hr = batch["HR"].view(B * N, -1, H, W)
     fn = frame_metrics if with_ssim else frame_psnrs
     return [fn(sr[i:i + 1], hr[i:i + 1]) for i in counted_frames(i_batch, N)]
+
+
+def load_checkpoint(model, model_path: str):
+    """Trainer.load (trainer.py:185-199): keep the checkpoint entries whose key (after 'basic_' -> 'basic_module.')
+    exists in the model, overlay them on the model's own state and load strictly."""
+    sd = model.state_dict()
+    saved = {k.replace("basic_", "basic_module."): v for k, v in torch.load(model_path, map_location="cpu").items()
+             if k.replace("basic_", "basic_module.") in sd}
+    sd.update(saved)
+    model.load_state_dict(sd, strict=True)
+    return sorted(saved)
+
+
+def eval_reds(model, args, rank: int = 0, world: int = 1, dist=None, device=None, with_ssim: bool = True, log=None):
+    """Trainer.eval_basicvsr over dataset.reds.EvalSet (trainer.py:295-413): batch size 1, items sharded round-robin over
+    ranks (each item is an independent clip window), per-frame metrics, one final all-reduce."""
+    from .dataset import reds
+    ds = reds.EvalSet(args)
+    dev = device if device is not None else next(model.parameters()).device
+
+    def clip_fn(i_batch):
+        item = ds[i_batch]
+        batch = {k: (v.unsqueeze(0).to(dev) if torch.is_tensor(v) else v) for k, v in item.items()}   # DataLoader(batch_size=1)
+        m = eval_clip(model, batch, i_batch, with_ssim)
+        if log is not None:
+            log(i_batch, m)
+        return m
+
+    return evaluate(clip_fn, len(ds), rank, world, dist, dev)
+
+
+def main(argv=None):
+    """`python -m crfp_amd.evalrig --dataset_dir <REDS>/val_sharp-style-root [--model_path ckpt.pt]`; under torchrun every
+    rank takes its shard (RCCL all-reduce of the five sums at the end)."""
+    import argparse
+    import json
+    import os
+
+    from .model import CRFP
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--dataset_dir", required=True)
+    ap.add_argument("--model_path", default=None)
+    ap.add_argument("--scale", type=int, default=8)
+    ap.add_argument("--N_frames", type=int, default=7)
+    ap.add_argument("--GT_size", type=int, default=256)
+    ap.add_argument("--FV_size", type=int, default=96)
+    ap.add_argument("--y_only", type=int, default=0)
+    a = ap.parse_args(argv)
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    model = CRFP.CRFP_DSV(device=dev, mid_channels=32, y_only=bool(a.y_only), hr_dcn=True, offset_prop=True).to(dev).eval()
+    if a.model_path:
+        load_checkpoint(model, a.model_path)
+    res = eval_reds(model, a, rank, world, dist, dev)
+    if rank == 0:
+        print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

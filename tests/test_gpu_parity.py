@@ -450,3 +450,48 @@ def test_avgpool2_and_fovea_head_ops():
         d = dev()
         ns, out = ops.fovea_head(state.to(d), x_hr.to(d), mask.to(d), lr.to(d), wt.to(d), bt.to(d), wl.to(d), bl.to(d), y_only)
         assert maxdiff(ns, ns_ref) < 2e-5 and maxdiff(out, out_ref) < 2e-5
+
+
+def test_eval_reds_end_to_end_vs_oracle(orc, tmp_path):
+    """dataset.reds.EvalSet -> model -> per-frame PSNR/SSIM/-Y -> means (Trainer.eval_basicvsr, trainer.py:295-413) on a
+    synthetic REDS-shaped PNG tree: HIP path vs the oracle driven through the same harness code."""
+    import types
+    import PIL.Image
+    from crfp_amd import evalrig, synth
+    from crfp_amd.dataset import reds
+    from crfp_amd.model import CRFP
+    rs = np.random.RandomState(77)
+    gt_root = str(tmp_path / "REDS_sharp")
+    lr_root = gt_root.replace("_sharp", "_sharp_BI_x8")
+    for clip in reds.REDS4:
+        base = rs.uniform(0, 255, (4, 8 * 16 + 8, 8 * 24 + 8, 3))
+        for i in range(4):
+            g = base[i % 2, i:i + 128, i:i + 192].astype(np.uint8)
+            for root, img in ((gt_root, g), (lr_root, np.array(PIL.Image.fromarray(g).resize((24, 16), PIL.Image.BICUBIC)))):
+                d = os.path.join(root, "val/val/val_sharp", clip)
+                os.makedirs(d, exist_ok=True)
+                PIL.Image.fromarray(img).save(os.path.join(d, f"{i:08d}.png"))
+    args = types.SimpleNamespace(dataset_dir=gt_root, scale=8, N_frames=3, GT_size=128, FV_size=32)
+    sd = synth.make_state_dict(7)
+    m = _model(sd)
+    res = evalrig.eval_reds(m, args, device=dev())
+    P = orc.load_numpy_state(sd)
+
+    def oracle_frames(i_batch):
+        item = reds.EvalSet(args)[i_batch]
+        sr = orc.crfp_dsv_forward(P, item["LR"][None], item["Ref"][None], item["Ref_sp"][None].float())[0]
+        out = []
+        ones = torch.ones(1, 1, *sr.shape[2:])
+        for i in evalrig.counted_frames(i_batch, sr.shape[0]):
+            a, b = sr[i:i + 1], item["HR"][i:i + 1]
+            p, s = orc.calc_psnr_and_ssim(a, b, ones)
+            py, sy = orc.calc_psnr_and_ssim(orc.to_y(a.permute(0, 2, 3, 1)), orc.to_y(b.permute(0, 2, 3, 1)), ones)
+            out.append((p, s, py, sy))
+        return out
+
+    ref = evalrig.evaluate(oracle_frames, len(reds.EvalSet(args)))
+    assert res["frames"] == ref["frames"] == 8 * 3 - 1      # frame 0 of batch 0 is skipped (trainer.py:350-351)
+    for k in ("psnr", "psnr_y"):
+        assert abs(res[k] - ref[k]) < 2e-3, k
+    for k in ("ssim", "ssim_y"):
+        assert abs(res[k] - ref[k]) < 2e-5, k
