@@ -184,6 +184,17 @@ class FNet(nn.Module):
         return ops.upsample_bilinear(o, size=(h, w))
 
 
+class SPyNet(nn.Module):
+    """Placeholder for the reference's SPyNet (model/CRFP.py:554-741).  CRFP_DSV never executes it -- its ``spynet``
+    attribute is an FNet (:1406) -- so there is no HIP path for the 7x7 pyramid convs; constructing it says so instead
+    of silently falling back to PyTorch."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("SPyNet is dormant on the CRFP_DSV inference path (the flow network is FNet); "
+                                  "crfp_amd provides no kernels for it")
+
+
 class CRFP_DSV(nn.Module):
     """Drop-in for the reference's CRFP_DSV (model/CRFP.py:1387-1706).  ``spynet_pretrained`` may be
     None (the reference would crash: it torch.load()s it unconditionally, :1407) -- weights then come
