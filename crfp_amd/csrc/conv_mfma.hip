@@ -737,28 +737,33 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
     }
 }
 
-// ---------------------------------------------------------------- software-pipelined persistent variant
+// ---------------------------------------------------------------- software-pipelined persistent variant (f16x3)
 // One 512-thread workgroup per CU (two waves per SIMD) walks a strided list of 8x64 output tiles; wave = one output
-// row (two 32-pixel MFMA column tiles).  The work is a stream of items (tile, K-chunk).  LDS holds the halo tile
-// images of TWO items (2 x 63 KB) and the weight fragments of one (27 KB); the registers hold two more items in raw
-// fp32 form.  While the MFMAs of item s run out of tile buffer s&1 the same waves
+// row (two 32-pixel MFMA column tiles).  The work is a stream of items (tile, K-chunk).  LDS holds TWO items (halo tile
+// images 2 x 42 KB + weight fragments 2 x 18 KB); the registers hold two more in raw fp32 form.  While the MFMAs of
+// item s run out of LDS buffer s&1 the same waves
 //   * issue the global loads of item s+2 (a full item of latency budget; measured wait at use: 16 cycles),
-//   * split item s+1 (loaded during item s-1) into its three bf16 images and write them to tile buffer (s+1)&1,
+//   * split item s+1 (loaded during item s-1) into its two fp16 images and write them + its weights to buffer (s+1)&1,
 // slice by slice between the taps: the MFMA is asynchronous (32 cycles per 32x32x16), so VALU/LDS instructions
 // issued between two of them ride in its shadow.  The code between two barriers is branch-free (every thread
 // writes both of its halo slots; surplus threads hit a dummy slot), otherwise the scheduler cannot interleave.
-// Why 8 waves and 8 rows: with 4x64 tiles and one wave per SIMD (first version) the tap stream took 6.9 k cycles per
-// item against 3.5 k of MFMA -- LDS operand traffic (0.75 ds_read_b128 per MFMA, 93 % of the LDS pipe) and in-order
-// issue behind a full LDS queue; a second wave per SIMD covers those stalls.
-// The single-buffered kernel above serialises load wait, split, MFMA and epilogue inside a workgroup and relies on
-// a second workgroup per CU to fill the gaps: 45 % MFMA-busy at best (s_memtime stamps).
+// One barrier per item; accumulators start at the bias; the epilogue runs when a tile's last chunk is done.
+// History: the first version (bf16x6, 4 waves) needed 6.9 k cycles per item against 3.5 k of MFMA -- LDS operand traffic
+// (0.75 ds_read_b128 per MFMA = 93 % of the LDS pipe) and in-order issue behind a full LDS queue with one wave per
+// SIMD; 8 waves fixed the issue stalls but bf16x6 stayed LDS-bound (7.9 k per item).  f16x3 moves 2/3 of the bytes.
+// Barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release fence + s_barrier, and the release
+// makes hipcc wait for vmcnt(0): every wave then sits out the write-acknowledge latency of its epilogue stores (2.5-3.3 k
+// cycles per item measured) although nobody in the workgroup reads them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int PIPE_NW = 8, PIPE_NT = 64 * PIPE_NW;
-constexpr int PIPE_NEL = (PIPE_NW + 2) * LW;            // 660 halo pixels
-constexpr int PIPE_NWS = (27 * 64 + PIPE_NT - 1) / PIPE_NT;   // 4 weight vectors per thread
+constexpr int PIPE_NEL = (PIPE_NW + 2) * LW;                   // 660 halo pixels
+constexpr int PIPE_WPC = 9 * 2 * 64;                           // weight vectors per (cout tile, chunk), f16x3
+constexpr int PIPE_NWS = (PIPE_WPC + PIPE_NT - 1) / PIPE_NT;   // 3 weight vectors per thread
 
 struct PipeRegs {
     f32x4 q[4][2];        // [K-quad of the chunk][halo element of this thread]
-    bf16x8 w[PIPE_NWS];   // this thread's share of the chunk's 27 KB weight fragment image
+    bf16x8 w[PIPE_NWS];   // this thread's share of the chunk's 18 KB weight fragment image
     int m[4];             // component masks of the 4 quads (wave-uniform)
     bool ok[2];           // halo element inside the image
 };
@@ -786,53 +791,45 @@ __device__ __forceinline__ void pipe_issue(PipeRegs& R, const ConvArgs& a, const
     }
 #pragma unroll
     for (int k = 0; k < PIPE_NWS; ++k)
-        R.w[k] = wp[((long long)(T0 * nchunks + ch) * 27) * 64 + min(tid + PIPE_NT * k, 1727)];
+        R.w[k] = wp[(long long)(T0 * nchunks + ch) * PIPE_WPC + min(tid + PIPE_NT * k, PIPE_WPC - 1)];
 }
 
-// unit U in 0..3: halo element U>>1, quad pair U&1 -> three bf16x8 images.  Slot PIPE_NEL is a dummy.
+// unit U in 0..3: halo element U>>1, quad pair U&1 -> two fp16x8 images.  Slot PIPE_NEL is a dummy.
 template <int U>
 __device__ __forceinline__ void pipe_split_unit(const PipeRegs& R, bf16x8 (*tl)[2][PIPE_NEL + 1], int tid) {
     constexpr int t = U >> 1, pr = U & 1;
     const int idx = min(tid + PIPE_NT * t, PIPE_NEL);
-    bf16x8 p0, p1, p2;
-    split_bf16x8(mask_quad(R.q[2 * pr][t], R.ok[t] ? R.m[2 * pr] : 0), mask_quad(R.q[2 * pr + 1][t], R.ok[t] ? R.m[2 * pr + 1] : 0),
-                 p0, p1, p2);
-    tl[0][pr][idx] = p0; tl[1][pr][idx] = p1; tl[2][pr][idx] = p2;
+    bf16x8 p0, p1;
+    split_f16x8(mask_quad(R.q[2 * pr][t], R.ok[t] ? R.m[2 * pr] : 0), mask_quad(R.q[2 * pr + 1][t], R.ok[t] ? R.m[2 * pr + 1] : 0),
+                p0, p1);
+    tl[0][pr][idx] = p0; tl[1][pr][idx] = p1;
 }
 
-struct PipeOps { bf16x8 w[3], b[2][3]; };
+template <int K>
+__device__ __forceinline__ void pipe_put_weight(const PipeRegs& R, bf16x8* wl, int tid) {
+    wl[min(tid + PIPE_NT * K, PIPE_WPC)] = R.w[K];   // slot PIPE_WPC is a dummy
+}
 
-__device__ __forceinline__ void pipe_read_ops(PipeOps& o, const bf16x8* wl, const bf16x8 (*tl)[2][PIPE_NEL + 1], int tap,
-                                              int wave, int lane) {
+__device__ __forceinline__ void pipe_tap(f32x16 (&acc)[1][2], f32x16 (&acl)[1][2], const bf16x8* wl,
+                                         const bf16x8 (*tl)[2][PIPE_NEL + 1], int tap, int wave, int lane) {
     const int j = lane & 31, h = lane >> 5;
     const int ky = tap / 3, kx = tap - 3 * ky;
+    bf16x8 wa[2];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) o.w[p] = wl[(tap * 3 + p) * 64 + lane];
+    for (int p = 0; p < 2; ++p) wa[p] = wl[(tap * 2 + p) * 64 + lane];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int pix = (wave + ky) * LW + pt * 32 + j + kx;
+        bf16x8 bq[2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) o.b[pt][p] = tl[p][h][pix];
-    }
-}
-
-__device__ __forceinline__ void pipe_mfma(f32x16 (&acc)[1][2], const PipeOps& o) {
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        f32x16 c = acc[0][pt];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[1], o.b[pt][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[0], o.b[pt][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[2], o.b[pt][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[0], o.b[pt][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[1], o.b[pt][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[0], o.b[pt][0], c, 0, 0, 0);
-        acc[0][pt] = c;
+        for (int p = 0; p < 2; ++p) bq[p] = tl[p][h][pix];
+        split_mfma<2>(acc[0][pt], acl[0][pt], wa, bq);
     }
 }
 
 __global__ __launch_bounds__(PIPE_NT, 1) void conv3x3_split_pipe_kernel(const ConvArgs a) {
-    __shared__ bf16x8 tile[2][3][2][PIPE_NEL + 1];   // [buffer][split part][quad pair][halo pixel (+1 dummy)]  127 KB
-    __shared__ bf16x8 wlds[27 * 64 + 1];             // [(tap, part)][lane] (+1 dummy)                            27 KB
+    __shared__ bf16x8 tile[2][2][2][PIPE_NEL + 1];   // [buffer][split part][quad pair][halo pixel (+1 dummy)]  84.6 KB
+    __shared__ bf16x8 wlds[2][PIPE_WPC + 1];         // [buffer][(tap, part)][lane] (+1 dummy)                   36.9 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW, ntiles = tiles_x * ((a.H + PIPE_NW - 1) / PIPE_NW);
@@ -840,8 +837,11 @@ __global__ __launch_bounds__(PIPE_NT, 1) void conv3x3_split_pipe_kernel(const Co
     const int nchunks = a.kq >> 2;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nitems = my_tiles * nchunks;
-    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit);
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit16);
     const EpiCtx ec = epi_ctx(a, n);
+    float4 bq4[4];   // this lane's bias quads: the accumulators of every tile start there
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq4[g] = reinterpret_cast<const float4*>(a.bpk)[T0 * 8 + 2 * g + h];
 
     // issue cursor (items are issued two ahead of the one being multiplied)
     int ik = 0, ich = 0;
@@ -854,21 +854,24 @@ __global__ __launch_bounds__(PIPE_NT, 1) void conv3x3_split_pipe_kernel(const Co
         }                                                                                                 \
         if (++ich == nchunks) { ich = 0; ++ik; }                                                          \
     }
-#define CRFP_PIPE_PUT_WEIGHTS(R)                                                                          \
-    _Pragma("unroll") for (int k = 0; k < PIPE_NWS; ++k) wlds[min(tid + PIPE_NT * k, 1728)] = R.w[k];
+#define CRFP_PIPE_ACC_INIT                                                                                \
+    _Pragma("unroll") for (int pt = 0; pt < 2; ++pt)                                                      \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
+            acc[0][pt][4 * g + 0] = bq4[g].x; acc[0][pt][4 * g + 1] = bq4[g].y;                           \
+            acc[0][pt][4 * g + 2] = bq4[g].z; acc[0][pt][4 * g + 3] = bq4[g].w;                           \
+            acl[0][pt][4 * g + 0] = 0.0f; acl[0][pt][4 * g + 1] = 0.0f;                                   \
+            acl[0][pt][4 * g + 2] = 0.0f; acl[0][pt][4 * g + 3] = 0.0f;                                   \
+        }
     CRFP_PIPE_ISSUE(RA)
     CRFP_PIPE_ISSUE(RB)
-    // item 0 -> tile buffer 0 + the weight buffer
+    // item 0 -> buffer 0
     pipe_split_unit<0>(RA, tile[0], tid); pipe_split_unit<1>(RA, tile[0], tid);
     pipe_split_unit<2>(RA, tile[0], tid); pipe_split_unit<3>(RA, tile[0], tid);
-    CRFP_PIPE_PUT_WEIGHTS(RA)
+    pipe_put_weight<0>(RA, wlds[0], tid); pipe_put_weight<1>(RA, wlds[0], tid); pipe_put_weight<2>(RA, wlds[0], tid);
     __syncthreads();
 
-    f32x16 acc[1][2];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][pt][e] = 0.0f;
+    f32x16 acc[1][2], acl[1][2];
+    CRFP_PIPE_ACC_INIT
     int mk = 0, mch = 0;   // item being multiplied
 
 #ifdef CRFP_PIPE_STAMPS
@@ -877,39 +880,39 @@ __global__ __launch_bounds__(PIPE_NT, 1) void conv3x3_split_pipe_kernel(const Co
 #else
 #define CRFP_PST(ACC)
 #endif
-    // one item: MFMAs out of tile buffer BUF (+ the weight buffer); RNEXT (item s+1, landed) is split into tile
-    // buffer BUF^1 between the taps and its weights replace the weight buffer between the two barriers at the end;
-    // RFREE (consumed by the previous item) receives the loads of item s+2 first of all
+    // one item: MFMAs out of LDS buffer BUF; RNEXT (item s+1, landed) is split / copied into buffer BUF^1 between the
+    // taps; RFREE (consumed by the previous item) receives the loads of item s+2 first of all
 #define CRFP_PIPE_ITEM(BUF, RNEXT, RFREE)                                                                 \
     {                                                                                                     \
         CRFP_PST(st_bar)                                                                                  \
         CRFP_PIPE_ISSUE(RFREE)                                                                            \
-        PipeOps o;                                                                                        \
-        pipe_read_ops(o, wlds, tile[BUF], 0, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 0, wave, lane);                                          \
         pipe_split_unit<0>(RNEXT, tile[(BUF) ^ 1], tid);                                                  \
-        pipe_read_ops(o, wlds, tile[BUF], 1, wave, lane); pipe_mfma(acc, o);                              \
-        pipe_read_ops(o, wlds, tile[BUF], 2, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 1, wave, lane);                                          \
+        pipe_put_weight<0>(RNEXT, wlds[(BUF) ^ 1], tid);                                                  \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 2, wave, lane);                                          \
         pipe_split_unit<1>(RNEXT, tile[(BUF) ^ 1], tid);                                                  \
-        pipe_read_ops(o, wlds, tile[BUF], 3, wave, lane); pipe_mfma(acc, o);                              \
-        pipe_read_ops(o, wlds, tile[BUF], 4, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 3, wave, lane);                                          \
+        pipe_put_weight<1>(RNEXT, wlds[(BUF) ^ 1], tid);                                                  \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 4, wave, lane);                                          \
         pipe_split_unit<2>(RNEXT, tile[(BUF) ^ 1], tid);                                                  \
-        pipe_read_ops(o, wlds, tile[BUF], 5, wave, lane); pipe_mfma(acc, o);                              \
-        pipe_read_ops(o, wlds, tile[BUF], 6, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 5, wave, lane);                                          \
+        pipe_put_weight<2>(RNEXT, wlds[(BUF) ^ 1], tid);                                                  \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 6, wave, lane);                                          \
         pipe_split_unit<3>(RNEXT, tile[(BUF) ^ 1], tid);                                                  \
-        pipe_read_ops(o, wlds, tile[BUF], 7, wave, lane); pipe_mfma(acc, o);                              \
-        pipe_read_ops(o, wlds, tile[BUF], 8, wave, lane); pipe_mfma(acc, o);                              \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 7, wave, lane);                                          \
+        pipe_tap(acc, acl, wlds[BUF], tile[BUF], 8, wave, lane);                                          \
         CRFP_PST(st_taps)                                                                                 \
         if (++mch == nchunks) {                                                                           \
             const int t_ = blockIdx.x + mk * gridDim.x, ty_ = t_ / tiles_x, tx_ = t_ - ty_ * tiles_x;     \
-            conv_epilogue<1, 2, 1>(ec, acc, T0, tx_ * TW, ty_ * PIPE_NW, wave, j, h);                     \
             _Pragma("unroll") for (int pt = 0; pt < 2; ++pt)                                              \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[0][pt][e] = 0.0f;                      \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[0][pt][e] += acl[0][pt][e] * (1.0f / F16_RES_SCALE); \
+            conv_epilogue<1, 2, 1, 2>(ec, acc, T0, tx_ * TW, ty_ * PIPE_NW, wave, j, h);                  \
+            CRFP_PIPE_ACC_INIT                                                                            \
             mch = 0; ++mk;                                                                                \
         }                                                                                                 \
         CRFP_PST(st_epi)                                                                                  \
-        __syncthreads();               /* every wave is done with the weight buffer and tile[BUF] */     \
-        CRFP_PIPE_PUT_WEIGHTS(RNEXT)                                                                      \
-        __syncthreads();                                                                                  \
+        lds_barrier();     /* buffer BUF^1 complete, every wave done with buffer BUF */                  \
     }
 
     for (int s = 0; s < nitems; s += 2) {
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(PIPE_NT, 1) void conv3x3_split_pipe_kernel(const Co
     }
 #undef CRFP_PIPE_ITEM
 #undef CRFP_PIPE_ISSUE
-#undef CRFP_PIPE_PUT_WEIGHTS
+#undef CRFP_PIPE_ACC_INIT
 #ifdef CRFP_PIPE_STAMPS
     if (a.stamps && tid == 0) {
         long long* o = a.stamps + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8;

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
         }
         if (t_next >= ntiles) break;
         t_cur = t_next;
-        __syncthreads();   // every wave is done reading the tile before it is overwritten
+        // every wave is done reading the tile before it is overwritten.  LDS-only barrier: __syncthreads() would also
+        // wait (vmcnt(0)) for the write acknowledgement of the stores above, which nobody in the workgroup reads
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #undef CRFP_NARROW_LOAD
 }
