@@ -204,8 +204,9 @@ int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s);
 int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
                         int N, int nq, int H, int W, int border, int src_pad, hipStream_t s);
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
-                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
-int launch_dcn_g8_pack(const float* w_oihw, float* wpk, hipStream_t s);  // [36][2][32][4]
+                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16 = false);
+int launch_dcn_g8_pack(const float* w_oihw, float* wpk, hipStream_t s, bool f16 = false);  // fp32 [36][2][32][4] or split-fp16 image
+bool dcn_g8_use_f16();   // engine: split-fp16 DCN GEMM unless CRFP_DCN_MODE=f32
 int launch_dcn3(const float* x, long long xb, const float* offmask3, long long omb, const float* w_oihw,
                 const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
 int launch_dcn_generic(const float* x, const float* offset, const float* mask, const float* w, const float* b,

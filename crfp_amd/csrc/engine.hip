@@ -543,7 +543,7 @@ struct Runner {
                 mfma(it_lvl(l, L_OM), 1, H2, W2, {{f, 0}}, {{F(L.offmask), 0, 0, 54}}, 0, 0, nullptr, 0, flow2, 0);
                 const Item& dw = M.items[it_lvl(l, L_DCNW)];
                 RUN(launch_dcn_g8(F(L.prev2), 0, F(L.offmask), 0, packed + dw.off_w, packed + dw.off_b, F(L.aligned), 0,
-                                  1, H2, W2, s));
+                                  1, H2, W2, s, dcn_g8_use_f16()));
                 if (fg && l > 0) {  // model/CRFP_test.py:2361,2375: resblock input * fg (x0.25) for levels 1, 2
                     RUN(launch_scale_q4(prop, 0, F(L.sc_prop), 6, H2, W2, F(L.fg2), nullptr, s));
                     RUN(launch_scale_q4(cw, 0, F(L.sc_cw), 2, H2, W2, F(L.fg2), nullptr, s));
@@ -636,7 +636,7 @@ int crfp_dsv_pack_weights(const float* const* params, int y_only, void* packed, 
                 break;
             case T_NARROW: rc = launch_narrow_pack(it.nw, w, b, w2, b2, split, pk + it.off_w, pk + it.off_b, s); break;
             case T_DCN8:
-                rc = launch_dcn_g8_pack(w, pk + it.off_w, s);
+                rc = launch_dcn_g8_pack(w, pk + it.off_w, s, dcn_g8_use_f16());
                 if (!rc && hipMemcpyAsync(pk + it.off_b, b, 32 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
                 break;
             default:

@@ -7,6 +7,8 @@
 // flow) hit consecutive 16-B elements: the four corner loads of a wave cover two nearly contiguous
 // 1-KiB row segments that the CU's L1 serves 3 times out of 4; HBM sees each input line once.
 #include "crfp_common.h"
+#include <cstdlib>
+#include <cstring>
 
 #include <cstdlib>
 
@@ -191,7 +193,12 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast
 
 // x is P4 (see above).  VALU budget per sampling position: position (2), clamp (4), floor/frac (6),
 // modulated bilinear weights (6), byte offset (4), 16 FMAs for the 4-channel sample.
-template <int NW, int NP, int MINW>
+// F16: the 32x32 GEMM runs on the fp16 MFMA with the exact two-term split of conv_mfma.hip (sample = s0 + 2^-11 s1, weights
+// pre-split; hi / lo accumulators): a pair of sampling positions (2 x 4 channels per lane half) is one K = 16 step = 3 MFMAs of
+// 32 cycles instead of 8 fp32 MFMAs of 64.  The C-ABI op keeps the fp32 MFMA (F16 = false).
+typedef _Float16 dcn_f16x8 __attribute__((ext_vector_type(8)));
+
+template <int NW, int NP, int MINW, bool F16>
 __global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __restrict__ x, long long xb,
                                                         const float* __restrict__ offmask, long long omb,
                                                         const float* __restrict__ wpk, const float* __restrict__ bias,
@@ -214,9 +221,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __re
     const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
     const int hbase = 4 * h * plane_b + guard;
 
-    f32x16 acc;
+    f32x16 acc, acl;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acl[e] = 0.0f; }
+    static_assert(!F16 || NP == 2, "the f16 path consumes sampling positions in pairs");
 
     // software pipeline: the (dy,dx) pairs and masks of iteration v+1 are in flight while the 16 corner
     // loads of iteration v (4 sampling positions x 4 corners, issued back to back) are consumed
@@ -257,21 +265,45 @@ __global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __re
                 q10[pi] = bload(rx, vo, pitch);
                 q11[pi] = bload(rx, vo, pitch + 16);
             }
+            f32x4 vals[NP];
 #pragma unroll
             for (int pi = 0; pi < NP; ++pi) {
                 f32x4 val = q00[pi] * w00[pi];
                 val = __builtin_elementwise_fma(q01[pi], f32x4{w01[pi], w01[pi], w01[pi], w01[pi]}, val);
                 val = __builtin_elementwise_fma(q10[pi], f32x4{w10[pi], w10[pi], w10[pi], w10[pi]}, val);
                 val = __builtin_elementwise_fma(q11[pi], f32x4{w11[pi], w11[pi], w11[pi], w11[pi]}, val);
-                const f32x4 wa = wl[(4 * v + hb + pi) * 64 + lane];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, val.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, val.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, val.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, val.w, acc, 0, 0, 0);
+                vals[pi] = val;
+                if (!F16) {
+                    const f32x4 wa = wl[(4 * v + hb + pi) * 64 + lane];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, val.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, val.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, val.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, val.w, acc, 0, 0, 0);
+                }
+            }
+            if (F16) {   // positions (4v+hb, 4v+hb+1) = pair u: lane half h supplies their 2 x 4 channels as k = 8h .. 8h+7
+                const float xs[8] = {vals[0].x, vals[0].y, vals[0].z, vals[0].w, vals[NP - 1].x, vals[NP - 1].y, vals[NP - 1].z, vals[NP - 1].w};
+                dcn_f16x8 b0, b1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const _Float16 hh = (_Float16)xs[i];
+                    b0[i] = hh;
+                    b1[i] = (_Float16)((xs[i] - (float)hh) * 2048.0f);
+                }
+                const int u = (4 * v + hb) >> 1;
+                const dcn_f16x8 w0 = __builtin_bit_cast(dcn_f16x8, wl[(2 * u) * 64 + lane]);
+                const dcn_f16x8 w1 = __builtin_bit_cast(dcn_f16x8, wl[(2 * u + 1) * 64 + lane]);
+                acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, acl, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, acc, 0, 0, 0);
+                acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, acl, 0, 0, 0);
             }
         }
     }
     if (!valid) return;
+    if (F16) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
+    }
     float* o = out + (long long)n * ob + ((long long)py * W + px) * 4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -291,23 +323,50 @@ __global__ void dcn_g8_pack_kernel(const float* __restrict__ w, float* __restric
     wpk[idx] = w[(row * 32 + ci) * 9 + tap];
 }
 
-int launch_dcn_g8_pack(const float* w, float* wpk, hipStream_t s) {
-    dcn_g8_pack_kernel<<<(36 * 2 * 32 * 4 + 255) / 256, 256, 0, s>>>(w, wpk);
+// f16 image, same 36 864 bytes: wpk16[((u*2 + part)*64 + lane)*8 + i], lane = half*32 + row, i < 4: position 2u, else 2u+1
+__global__ void dcn_g8_pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 18 * 64 * 8) return;
+    const int i = idx & 7, lane = (idx >> 3) & 63, u = idx >> 9;
+    const int row = lane & 31, half = lane >> 5;
+    const int p36 = 2 * u + (i >> 2), ch = i & 3;
+    const int ci = 4 * (4 * half + p36 / 9) + ch, tap = p36 % 9;
+    const float val = w[(row * 32 + ci) * 9 + tap];
+    const _Float16 p0 = (_Float16)val;
+    const _Float16 p1 = (_Float16)((val - (float)p0) * 2048.0f);
+    wpk[((u * 2 + 0) * 64 + lane) * 8 + i] = __builtin_bit_cast(unsigned short, p0);
+    wpk[((u * 2 + 1) * 64 + lane) * 8 + i] = __builtin_bit_cast(unsigned short, p1);
+}
+
+bool dcn_g8_use_f16() {
+    static const bool f16 = !(getenv("CRFP_DCN_MODE") && !strcmp(getenv("CRFP_DCN_MODE"), "f32"));
+    return f16;
+}
+
+// f16 = true: the engine's split-fp16 image; false: the fp32 image of the per-op C-ABI
+int launch_dcn_g8_pack(const float* w, float* wpk, hipStream_t s, bool f16) {
+    if (f16) dcn_g8_pack16_kernel<<<(18 * 64 * 8 + 255) / 256, 256, 0, s>>>(w, (unsigned short*)wpk);
+    else dcn_g8_pack_kernel<<<(36 * 2 * 32 * 4 + 255) / 256, 256, 0, s>>>(w, wpk);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
-                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s) {
+                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16) {
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * (32 + 144 + 72 + 32) * 4.0 + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
     static const int variant = getenv("CRFP_DCN_VARIANT") ? atoi(getenv("CRFP_DCN_VARIANT")) : 3;  // tuning knob (A/B: 3 fastest)
+    if (f16) {
+        dcn_g8_kernel<4, 2, 4, true><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
     switch (variant) {
-        case 1: dcn_g8_kernel<8, 2, 6><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
-        case 2: dcn_g8_kernel<8, 4, 4><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
-        case 3: dcn_g8_kernel<4, 2, 4><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
-        case 4: dcn_g8_kernel<8, 1, 8><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
-        default: dcn_g8_kernel<4, 4, 3><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        case 1: dcn_g8_kernel<8, 2, 6, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        case 2: dcn_g8_kernel<8, 4, 4, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        case 3: dcn_g8_kernel<4, 2, 4, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        case 4: dcn_g8_kernel<8, 1, 8, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        default: dcn_g8_kernel<4, 4, 3, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
     }
     CRFP_CHECK_LAUNCH();
     return 0;
