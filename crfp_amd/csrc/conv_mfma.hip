@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
-    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int btile = xcd_band_tile(blockIdx.x, gridDim.x);   // XCD x works on a contiguous band of tiles
+    const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = blockIdx.y * CT;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
@@ -576,7 +577,8 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
-    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int btile = xcd_band_tile(blockIdx.x, gridDim.x);   // XCD x works on a contiguous band of tiles
+    const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = blockIdx.y * CT;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
@@ -952,7 +954,8 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_spli
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
-    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    const int btile = xcd_band_tile(blockIdx.x, gridDim.x);   // XCD x works on a contiguous band of tiles
+    const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
     const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(NP == 3 ? a.wsplit : a.wsplit16);

@@ -102,7 +102,15 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
             }                                                                                             \
     }
 
-    int t_cur = blockIdx.x;
+    // XCD-aware walk: the workgroups of XCD x (= blockIdx.x % 8) share the contiguous tile band of that XCD
+    // (same-box A/B: -1..-5 % for the Q4 -> Q4 stencils, +6 % for the NCHW-plane head, which keeps the strided walk)
+    constexpr bool BAND = EPI != NE_LAST;
+    const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+    const int band0 = BAND ? xcd * xq + min(xcd, xr) : 0;
+    const int band1 = BAND ? band0 + xq + (xcd < xr ? 1 : 0) : ntiles;
+    const int t_step = BAND ? ((int)gridDim.x - xcd + 7) >> 3 : (int)gridDim.x;   // workgroups on this XCD
+    int t_cur = BAND ? band0 + (blockIdx.x >> 3) : (int)blockIdx.x;
+    if (t_cur >= band1) return;
     CRFP_NARROW_LOAD(t_cur)
     for (;;) {
 #pragma unroll
@@ -113,8 +121,8 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
                 if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = r[k][t];
             }
         __syncthreads();
-        const int t_next = t_cur + gridDim.x;
-        if (t_next < ntiles) CRFP_NARROW_LOAD(t_next)     // flies during the FMAs and stores below
+        const int t_next = t_cur + t_step;
+        if (t_next < band1) CRFP_NARROW_LOAD(t_next)     // flies during the FMAs and stores below
 
         float acc[4][4];
 #pragma unroll
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
                 }
             }
         }
-        if (t_next >= ntiles) break;
+        if (t_next >= band1) break;
         t_cur = t_next;
         // every wave is done reading the tile before it is overwritten.  LDS-only barrier: __syncthreads() would also
         // wait (vmcnt(0)) for the write acknowledgement of the stores above, which nobody in the workgroup reads

@@ -166,6 +166,19 @@ struct NarrowArgs {
     long long* stamps;  // diagnostic builds (-DCRFP_NARROW_STAMPS) only
 };
 
+// ------------------------------------------------------------------ XCD-aware tile order
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  With the natural order two
+// neighbouring tiles (which share halo rows / gathered lines) always sit on different XCDs and both fetch the shared lines
+// from HBM.  This maps linear workgroup id b of `total` to a tile id such that XCD x walks the contiguous band
+// [x*q + min(x,r), ...) of the tile list (q = total/8, r = total%8): a bijection on [0, total).
+__device__ __forceinline__ int xcd_band_tile(int b, int total) {
+#ifdef CRFP_NO_XCD_BAND
+    return b;   // A/B builds only
+#endif
+    const int q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    return x * q + min(x, r) + i;
+}
+
 // ------------------------------------------------------------------ profiling + errors
 void set_error(const char* fmt, ...);
 struct ProfScope {

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 36 * 64; i += 64 * NW) wl[i] = reinterpret_cast<const f32x4*>(wpk)[i];
     const int j = lane & 31, h = lane >> 5;
+    // (XCD-banded tile order measured here: traffic 316 -> 268 MB but +1.8 % time; the gathers keep the natural order)
     const int px = blockIdx.x * 32 + j, py = blockIdx.y * NW + wave;
     const int n = blockIdx.z;
     const bool valid = px < W && py < H;
