@@ -341,9 +341,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
-    const int btile = xcd_band_tile(blockIdx.x, gridDim.x);   // XCD x works on a contiguous band of tiles
+    // 1-D grid over (tile, cout-tile group) with the groups of a tile adjacent, dealt to the XCDs in contiguous bands:
+    // neighbouring tiles share their halo lines and the cout-tile groups of one tile re-read the same input in one L2
+    const int ngrp = a.ctiles / CT;
+    const int bwork = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int btile = bwork / ngrp;
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
-    const int T0 = blockIdx.y * CT;
+    const int T0 = (bwork - btile * ngrp) * CT;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
 
@@ -577,9 +581,13 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
-    const int btile = xcd_band_tile(blockIdx.x, gridDim.x);   // XCD x works on a contiguous band of tiles
+    // 1-D grid over (tile, cout-tile group) with the groups of a tile adjacent, dealt to the XCDs in contiguous bands:
+    // neighbouring tiles share their halo lines and the cout-tile groups of one tile re-read the same input in one L2
+    const int ngrp = a.ctiles / CT;
+    const int bwork = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int btile = bwork / ngrp;
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
-    const int T0 = blockIdx.y * CT;
+    const int T0 = (bwork - btile * ngrp) * CT;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
 
@@ -1474,24 +1482,24 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         conv3x3_split_pipe_kernel<<<grid, PIPE_NT, 0, s>>>(a);
     } else if (split) {
         if (ct2) {
-            dim3 grid(tiles, a.ctiles / 2, a.N);
+            dim3 grid(tiles * (a.ctiles / 2), 1, a.N);
             if (use_f16) conv3x3_split_kernel<2, 1, 2><<<grid, 256, 0, s>>>(am);
             else conv3x3_split_kernel<2, 1, 3><<<grid, 256, 0, s>>>(am);
         } else if (split_rpw == 1) {
-            dim3 grid(tiles, a.ctiles, a.N);
+            dim3 grid(tiles * a.ctiles, 1, a.N);
             static const int dyn_lds = getenv("CRFP_SPLIT_DYNLDS") ? atoi(getenv("CRFP_SPLIT_DYNLDS")) : 0;  // occupancy experiment
             if (use_f16) conv3x3_split_kernel<1, 1, 2><<<grid, 256, dyn_lds, s>>>(am);
             else conv3x3_split_kernel<1, 1, 3><<<grid, 256, 0, s>>>(am);
         } else {
-            dim3 grid(tiles, a.ctiles, a.N);
+            dim3 grid(tiles * a.ctiles, 1, a.N);
             if (use_f16) conv3x3_split_kernel<1, 2, 2><<<grid, 256, 0, s>>>(am);
             else conv3x3_split_kernel<1, 2, 3><<<grid, 256, 0, s>>>(am);
         }
     } else if (ct2) {
-        dim3 grid(tiles, a.ctiles / 2, a.N);
+        dim3 grid(tiles * (a.ctiles / 2), 1, a.N);
         conv3x3_mfma_kernel<2, 1><<<grid, 256, 0, s>>>(a);
     } else {
-        dim3 grid(tiles, a.ctiles, a.N);
+        dim3 grid(tiles * a.ctiles, 1, a.N);
         conv3x3_mfma_kernel<1, 2><<<grid, 256, 0, s>>>(a);
     }
     CRFP_CHECK_LAUNCH();
