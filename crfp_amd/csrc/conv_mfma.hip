@@ -28,6 +28,9 @@ constexpr int TW = 64, LW = TW + 2;
 #ifndef CRFP_TAP_UNROLL
 #define CRFP_TAP_UNROLL 3
 #endif
+#ifndef CRFP_SPLIT_TAP_UNROLL
+#define CRFP_SPLIT_TAP_UNROLL 9   // default split kernel: full unroll measured +1.4 % frames/s over 3 (168 VGPRs, still 3 waves/SIMD)
+#endif
 
 __device__ __forceinline__ float4 load_src_quad(const ConvSrc& s, int n, int kql, int gy, int gx, int H, int W) {
     const float* base = s.p + (long long)n * s.bstride;
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
         if (ch + 1 < nchunks) CRFP_SPLIT_ISSUE(ch + 1)
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }  // diagnostic: issue booked under D
-#pragma unroll CRFP_TAP_UNROLL
+#pragma unroll CRFP_SPLIT_TAP_UNROLL
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
             bf16x8 wa[CT][NP];
