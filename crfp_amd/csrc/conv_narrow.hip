@@ -40,6 +40,9 @@ __device__ __forceinline__ float n_act(float v, int act) {
 // in LDS too (broadcast reads).  The loads of tile t+1 are issued right after tile t reached LDS, so they fly during
 // the FMAs and stores of tile t: the one-tile-per-workgroup version spent 7.7-12 k cycles per tile waiting for its
 // loads and 4 k in an epilogue that re-read its arguments (s_memtime stamps), i.e. HBM idled while it computed.
+#ifndef CRFP_NARROW_KY_UNROLL
+#define CRFP_NARROW_KY_UNROLL 1
+#endif
 constexpr int NTW = 64, NTH = 16, NLW = NTW + 2, NLH = NTH + 2;
 constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per quad
 
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
         // 18 halo reads of a quad and blows past 200 VGPRs (or spills at a lower cap).
 #pragma unroll 1
         for (int k = 0; k < KQ; ++k) {
-#pragma unroll 1
+#pragma unroll (CRFP_NARROW_KY_UNROLL)
             for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
