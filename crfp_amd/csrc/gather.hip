@@ -315,6 +315,139 @@ __global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------- dcn_g8, software-pipelined (engine path, f16x3)
+// Same mapping as dcn_g8_kernel (wave = 32 pixels of a row, lane half = 4 deformable groups, 36 sampling positions per
+// lane, consumed in 18 pairs), but the 8 corner loads of pair b+1 are issued BEFORE pair b is interpolated, split and
+// multiplied, and the (dy,dx)/mask quads run two iterations ahead.  In the straight version every pair waited for its own
+// gathers, and its VALU (~33 us of instruction issue), gather (~32 us of L1 bandwidth: 1.06 GB of 16-B corner reads) and
+// offset traffic (199 MB of HBM) added up instead of overlapping (96 us).
+struct DcnPair {
+    f32x4 q[2][4];   // [position][corner]
+    float w[2][4];   // modulated bilinear weights
+};
+
+struct DcnOff { f32x4 m4, oa, ob; };   // masks of 4 positions, (dy,dx) of positions (0,1) and (2,3)
+
+__device__ __forceinline__ void dcn_issue_pair(DcnPair& P, __amdgpu_buffer_rsrc_t rx, const DcnOff& O, int hb, int v, float fy0,
+                                               float fx0, float fH, float fW, int PW, int pitch, int plane_b, int hbase) {
+    const float dyv[4] = {O.oa.x, O.oa.z, O.ob.x, O.ob.z};
+    const float dxv[4] = {O.oa.y, O.oa.w, O.ob.y, O.ob.w};
+    const float mmv[4] = {O.m4.x, O.m4.y, O.m4.z, O.m4.w};
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int pp = hb + pi;
+        const int p36 = 4 * v + pp, gi = p36 / 9, tap = p36 - 9 * gi, ky = tap / 3, kx = tap - 3 * ky;
+        // (float)(cy-1) + (float)ky is exact, so this equals the reference's (float)(y - pad + ky) + dy
+        float sy = (fy0 + (float)ky) + dyv[pp];
+        float sx = (fx0 + (float)kx) + dxv[pp];
+        sy = fminf(fmaxf(sy, -1.0f), fH);
+        sx = fminf(fmaxf(sx, -1.0f), fW);
+        const float fy = floorf(sy), fx = floorf(sx);
+        const float ly = sy - fy, lx = sx - fx;
+        const float a = (1.0f - ly) * mmv[pp], b = ly * mmv[pp], hx = 1.0f - lx;
+        P.w[pi][0] = a * hx; P.w[pi][1] = a * lx; P.w[pi][2] = b * hx; P.w[pi][3] = b * lx;
+        const int vo = ((int)fy * PW + (int)fx) * 16 + hbase + gi * plane_b;
+        P.q[pi][0] = bload(rx, vo, 0);
+        P.q[pi][1] = bload(rx, vo, 16);
+        P.q[pi][2] = bload(rx, vo, pitch);
+        P.q[pi][3] = bload(rx, vo, pitch + 16);
+    }
+}
+
+__device__ __forceinline__ void dcn_consume_pair(const DcnPair& P, f32x16& acc, f32x16& acl, const f32x4* wl, int u, int lane) {
+    float xs[8];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        f32x4 val = P.q[pi][0] * P.w[pi][0];
+        val = __builtin_elementwise_fma(P.q[pi][1], f32x4{P.w[pi][1], P.w[pi][1], P.w[pi][1], P.w[pi][1]}, val);
+        val = __builtin_elementwise_fma(P.q[pi][2], f32x4{P.w[pi][2], P.w[pi][2], P.w[pi][2], P.w[pi][2]}, val);
+        val = __builtin_elementwise_fma(P.q[pi][3], f32x4{P.w[pi][3], P.w[pi][3], P.w[pi][3], P.w[pi][3]}, val);
+        xs[4 * pi + 0] = val.x; xs[4 * pi + 1] = val.y; xs[4 * pi + 2] = val.z; xs[4 * pi + 3] = val.w;
+    }
+    dcn_f16x8 b0, b1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 hh = (_Float16)xs[i];
+        b0[i] = hh;
+        b1[i] = (_Float16)((xs[i] - (float)hh) * 2048.0f);
+    }
+    const dcn_f16x8 w0 = __builtin_bit_cast(dcn_f16x8, wl[(2 * u) * 64 + lane]);
+    const dcn_f16x8 w1 = __builtin_bit_cast(dcn_f16x8, wl[(2 * u + 1) * 64 + lane]);
+    acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, acl, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, acc, 0, 0, 0);
+    acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, acl, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __restrict__ x, long long xb,
+                                                             const float* __restrict__ offmask, long long omb,
+                                                             const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                             float* __restrict__ out, long long ob, int H, int W) {
+    __shared__ f32x4 wl[36 * 64];   // split-fp16 weight image (36 KB), shared by the 4 waves
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 36 * 64; i += 256) wl[i] = reinterpret_cast<const f32x4*>(wpk)[i];
+    const int j = lane & 31, h = lane >> 5;
+    const int px = blockIdx.x * 32 + j, py = blockIdx.y * 4 + wave;
+    const int n = blockIdx.z;
+    const bool valid = px < W && py < H;
+    const int cx = min(px, W - 1), cy = min(py, H - 1);
+    const long long plane = (long long)H * W * 4;
+    const float* om = offmask + (long long)n * omb + ((long long)cy * W + cx) * 4;
+    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
+    const int guard = pitch + 16;  // zeroed guard in front of plane 0 (see flow_warp_p4_kernel)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + (long long)n * xb) - (guard >> 2), 0, 8 * plane_b + guard, 0x00020000);
+    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
+    const int hbase = 4 * h * plane_b + guard;
+
+    f32x16 acc, acl;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acl[e] = 0.0f; }
+
+#define CRFP_DCN_LOAD_OFF(O, V)                                                                           \
+    {                                                                                                     \
+        const int v_ = min((V), 8);   /* the two look-ahead loads past the end are clamped (unused) */     \
+        O.m4 = ldg4(om + (36 + 9 * h + v_) * plane);                                                      \
+        O.oa = ldg4(om + (18 * h + 2 * v_) * plane);                                                      \
+        O.ob = ldg4(om + (18 * h + 2 * v_ + 1) * plane);                                                  \
+    }
+#define CRFP_DCN_ISSUE(P, O, HB, V) dcn_issue_pair(P, rx, O, HB, V, fy0, fx0, fH, fW, PW, pitch, plane_b, hbase);
+    DcnOff O0, O1, O2;
+    DcnPair QA, QB;
+    CRFP_DCN_LOAD_OFF(O0, 0)
+    CRFP_DCN_LOAD_OFF(O1, 1)
+    __syncthreads();
+    CRFP_DCN_ISSUE(QA, O0, 0, 0)
+    // iteration v: OC = offsets(v) (in registers), ON = offsets(v+1) (landing), OF receives offsets(v+2)
+#define CRFP_DCN_ITER(V, OC, ON, OF)                                                                      \
+    {                                                                                                     \
+        CRFP_DCN_LOAD_OFF(OF, (V) + 2)                                                                    \
+        CRFP_DCN_ISSUE(QB, OC, 2, V)                                                                      \
+        dcn_consume_pair(QA, acc, acl, wl, 2 * (V), lane);                                                \
+        if ((V) < 8) CRFP_DCN_ISSUE(QA, ON, 0, (V) + 1)                                                   \
+        dcn_consume_pair(QB, acc, acl, wl, 2 * (V) + 1, lane);                                            \
+    }
+#pragma unroll 1
+    for (int v3 = 0; v3 < 9; v3 += 3) {
+        CRFP_DCN_ITER(v3, O0, O1, O2)
+        CRFP_DCN_ITER(v3 + 1, O1, O2, O0)
+        CRFP_DCN_ITER(v3 + 2, O2, O0, O1)
+    }
+#undef CRFP_DCN_ITER
+#undef CRFP_DCN_ISSUE
+#undef CRFP_DCN_LOAD_OFF
+    if (!valid) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
+    float* o = out + (long long)n * ob + ((long long)py * W + px) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cq = 2 * g + h;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * cq);
+        *reinterpret_cast<float4*>(o + cq * plane) =
+            make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+    }
+}
+
 // wpk[((p36*2 + half)*32 + row)*4 + i] = W[row][4*(4*half + p36/9) + i][p36 % 9]
 __global__ void dcn_g8_pack_kernel(const float* __restrict__ w, float* __restrict__ wpk) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,6 +490,14 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * (32 + 144 + 72 + 32) * 4.0 + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
     static const int variant = getenv("CRFP_DCN_VARIANT") ? atoi(getenv("CRFP_DCN_VARIANT")) : 3;  // tuning knob (A/B: 3 fastest)
+    // measured 91.9 vs 91.6 us: issuing the next pair's gathers early does not help, the kernel is bound by the L1 line rate
+    // of the 16-B corner gathers (1.06 GB through the TA per launch), not by latency -> opt-in experiment
+    static const bool pipe = getenv("CRFP_DCN_PIPE") && atoi(getenv("CRFP_DCN_PIPE")) == 1;
+    if (f16 && pipe) {
+        dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
     if (f16) {
         dcn_g8_kernel<4, 2, 4, true><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
         CRFP_CHECK_LAUNCH();
