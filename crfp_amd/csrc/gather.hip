@@ -422,9 +422,13 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
     {                                                                                                     \
         CRFP_DCN_LOAD_OFF(OF, (V) + 2)                                                                    \
         CRFP_DCN_ISSUE(QB, OC, 2, V)                                                                      \
+        __builtin_amdgcn_sched_barrier(0);   /* keep the gathers ahead of the math: hipcc otherwise sinks them */ \
         dcn_consume_pair(QA, acc, acl, wl, 2 * (V), lane);                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
         if ((V) < 8) CRFP_DCN_ISSUE(QA, ON, 0, (V) + 1)                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
         dcn_consume_pair(QB, acc, acl, wl, 2 * (V) + 1, lane);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
     }
 #pragma unroll 1
     for (int v3 = 0; v3 < 9; v3 += 3) {
@@ -490,9 +494,9 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * (32 + 144 + 72 + 32) * 4.0 + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
     static const int variant = getenv("CRFP_DCN_VARIANT") ? atoi(getenv("CRFP_DCN_VARIANT")) : 3;  // tuning knob (A/B: 3 fastest)
-    // measured 91.9 vs 91.6 us: issuing the next pair's gathers early does not help, the kernel is bound by the L1 line rate
-    // of the 16-B corner gathers (1.06 GB through the TA per launch), not by latency -> opt-in experiment
-    static const bool pipe = getenv("CRFP_DCN_PIPE") && atoi(getenv("CRFP_DCN_PIPE")) == 1;
+    // measured 89.1 vs 91.7 us (and no gain at all until sched_barrier pinned the gathers ahead of the math): the kernel is
+    // mostly bound by the L1 line rate of the 16-B corner gathers (1.06 GB through the TA per launch) and VALU issue
+    static const bool pipe = !(getenv("CRFP_DCN_PIPE") && atoi(getenv("CRFP_DCN_PIPE")) == 0);
     if (f16 && pipe) {
         dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
         CRFP_CHECK_LAUNCH();
