@@ -84,28 +84,36 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
     const bool y_only = a.y_only != 0;
 
     f32x4 r[KQ][NST];
-    // issue every load of a tile before anything consumes them (independent loads in flight together)
+    bool okr[NST];   // halo element of the tile held in r[] lies inside the image
+    // Every load of a tile is issued before anything consumes it, UNCONDITIONALLY at clamped coordinates: a predicated
+    // load (`if (inside) r = load`) makes hipcc wait for each load right behind its issue (the select that merges the
+    // zero needs the data) -- the first version's ISA read `G V(0) G V(0) ...`, five full memory latencies per quad.
+    // Outside-image elements are zeroed when the registers are written to LDS.
 #define CRFP_NARROW_LOAD(T)                                                                               \
     {                                                                                                     \
         const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * NTW, y0_ = ty_ * NTH;                \
-        _Pragma("unroll") for (int k = 0; k < KQ; ++k)                                                    \
-            _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                             \
-                const int idx = tid + 256 * t;                                                            \
-                const int rr = idx / NLW, c = idx - rr * NLW;                                             \
-                const int gy = y0_ + rr - 1, gx = x0_ + c - 1;                                            \
-                r[k][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};                                                  \
-                if (idx < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W) {                          \
-                    if (qflow[k]) {                                                                       \
-                        const float2 f = *reinterpret_cast<const float2*>(qbase[k] + ((long long)gy * W + gx) * 2); \
-                        r[k][t] = f32x4{f.x, f.y, 0.0f, 0.0f};                                            \
-                    } else {                                                                              \
-                        r[k][t] = *reinterpret_cast<const f32x4*>(qbase[k] + ((long long)gy * qpitch[k] + gx) * 4); \
-                    }                                                                                     \
+        int cgy[NST], cgx[NST];                                                                           \
+        _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                                 \
+            const int idx = min(tid + 256 * t, NLH * NLW - 1);                                            \
+            const int rr = idx / NLW, c = idx - rr * NLW;                                                 \
+            const int gy = y0_ + rr - 1, gx = x0_ + c - 1;                                                \
+            okr[t] = tid + 256 * t < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W;                 \
+            cgy[t] = min(max(gy, 0), H - 1);                                                              \
+            cgx[t] = min(max(gx, 0), W - 1);                                                              \
+        }                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < KQ; ++k) {                                                  \
+            if (qflow[k]) {   /* wave-uniform */                                                          \
+                _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                         \
+                    const float2 f = *reinterpret_cast<const float2*>(qbase[k] + ((long long)cgy[t] * W + cgx[t]) * 2); \
+                    r[k][t] = f32x4{f.x, f.y, 0.0f, 0.0f};                                                \
                 }                                                                                         \
+            } else {                                                                                      \
+                _Pragma("unroll") for (int t = 0; t < NST; ++t)                                           \
+                    r[k][t] = *reinterpret_cast<const f32x4*>(qbase[k] + ((long long)cgy[t] * qpitch[k] + cgx[t]) * 4); \
             }                                                                                             \
+        }                                                                                                 \
     }
 
-    // XCD-aware walk: the workgroups of XCD x (= blockIdx.x % 8) share the contiguous tile band of that XCD
     // (same-box A/B: -1..-5 % for the Q4 -> Q4 stencils, +6 % for the NCHW-plane head, which keeps the strided walk)
     constexpr bool BAND = EPI != NE_LAST;
     const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
 #pragma unroll
             for (int t = 0; t < NST; ++t) {
                 const int idx = tid + 256 * t;
-                if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = r[k][t];
+                if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = okr[t] ? r[k][t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
         __syncthreads();
         const int t_next = t_cur + t_step;
