@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int c = 0; c < 4; ++c) nb[r][c] = bload(rx, vo, r * pitch + c * 16);
+        __builtin_amdgcn_sched_barrier(0);   // all 16 gathers in flight together (hipcc otherwise issues and waits row by row)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
