@@ -385,8 +385,12 @@ struct SideStream {
         return ev[i];
     }
 };
+// one per (host thread, device): streams and events belong to the device that was current when they were created
 static SideStream& side_stream() {
-    static thread_local SideStream ss;
+    static thread_local SideStream per_dev[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    SideStream& ss = per_dev[dev];
     if (!ss.s && ss.ok && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
     return ss;
 }
