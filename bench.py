@@ -189,7 +189,7 @@ def main():
             note = {"f32": "fp32 MFMA",
                     "bf16x6": "algorithmic fp32 flops; executed as 6 bf16 MFMA products per MAC (split-bf16), so peak = 2.5 PF / 6"}.get(
                         mode, "algorithmic fp32 flops; executed as 3 fp16 MFMA products per MAC (split-fp16, fp32-grade), so peak = "
-                              "2.5 PF dense fp16 / 3; the kernel is LDS-bandwidth bound (1.0 ds_read_b128 per MFMA), not MFMA bound")
+                              "2.5 PF dense fp16 / 3; PMC: MFMA pipe ~28 % busy (profiles/*_mfma_lds_util.txt), the rest is operand traffic through LDS (1.0 ds_read_b128 per MFMA), load wait, split and the tile-granularity tail")
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["TFLOPs"],
                                   "peak": peak, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / peak,
                                   "traffic": pmc_traffic(dom["kernel"]), "avg_launch_us": dom["avg_us"],
