@@ -35,9 +35,15 @@ __global__ __launch_bounds__(256, 4) void victim(unsigned* errs, unsigned* where
             for (int kx = 0; kx < 3; ++kx) {
                 const float4* wq = &wl[(ky * 3 + kx) * 4];
                 const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
+                float4 uu[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) uu[i] = tile[4 * ty + ky + i][tx + kx];
+#ifdef FULLWAIT
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS return complete before the first packed FMA
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 u = tile[4 * ty + ky + i][tx + kx];
+                    const float4 u = uu[i];
                     acc[i][0] = fmaf(w3.x, u.w, fmaf(w2.x, u.z, fmaf(w1.x, u.y, fmaf(w0.x, u.x, acc[i][0]))));
                     acc[i][1] = fmaf(w3.y, u.w, fmaf(w2.y, u.z, fmaf(w1.y, u.y, fmaf(w0.y, u.x, acc[i][1]))));
                     acc[i][2] = fmaf(w3.z, u.w, fmaf(w2.z, u.z, fmaf(w1.z, u.y, fmaf(w0.z, u.x, acc[i][2]))));
