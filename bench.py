@@ -54,7 +54,7 @@ def kernel_family(name: str) -> str:
 ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_mfma_kernel"), "conv3x3_narrow": ("conv3x3_narrow_kernel",),
                  "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel",),
                  "flow_warp_q4_c4": ("flow_warp_p4_kernel",), "flow_warp_q4_c32": ("flow_warp_p4_kernel",),
-                 "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "hr_prep_up8_blend": ("hr_prep_kernel",)}
+                 "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "flow_warp_q4_c32+c24": ("flow_warp_p4_dual_kernel",), "hr_prep_up8_blend": ("hr_prep_kernel",)}
 
 
 def pmc_traffic(family: str):

@@ -214,6 +214,8 @@ int launch_narrow_pack(const NarrowArgs& a, const float* w_oihw, const float* bi
 int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s);
 // gather.hip
 // src_pad = 1: x is P4 (padded planes, zero pads): validity logic replaced by clamping + hardware range check
+int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* flow, float* outa, float* outb, int H, int W,
+                                 hipStream_t s);
 int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
                         int N, int nq, int H, int W, int border, int src_pad, hipStream_t s);
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,

@@ -528,9 +528,8 @@ struct Runner {
             float* flow2 = F(L.flow2[par]);
             float* flow8 = F(L.flow8[par]);
             mfma(IT_DOWN, 1, H2, W2, {{F(L.state_hr), 0, 1}}, {{F(L.prev2), 0, 0, 8, 1}});
-            RUN(launch_flow_warp_q4(F(L.prev2), 0, flow2, 0, F(L.prev2w), 0, 1, 8, H2, W2, 0, 1, s));
+            RUN(launch_flow_warp_p4_dual_8_6(F(L.prev2), carry, flow2, F(L.prev2w), F(L.carryw), H2, W2, s));
             RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, 1, s));
-            RUN(launch_flow_warp_q4(carry, 0, flow2, 0, F(L.carryw), 0, 1, 6, H2, W2, 0, 1, s));
             const float* offprev = nullptr;
             if (fg) RUN(launch_fg_prep(fg, F(L.fg2), H8, W8, s));
             for (int l = 0; l < 3; ++l) {

@@ -120,6 +120,73 @@ __global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restri
     }
 }
 
+// Two P4 tensors warped by the same flow field in one launch (the engine warps prev2 [8 quads] and the carried features
+// [6 quads] with flow2 every frame: model/CRFP.py:1570-1582): the flow read and the coordinate arithmetic are shared, and
+// the corner gathers go out in batches of up to 4 quads (16 loads in flight) instead of one quad at a time -- the
+// runtime-nq loop above waits for every quad's four loads before it issues the next four.
+template <int NQ>
+__device__ __forceinline__ void warp_quads(__amdgpu_buffer_rsrc_t r, int voff, int pitch, int plane_b, float w00, float w01,
+                                           float w10, float w11, float* os, long long oplane) {
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += 4) {
+        constexpr int B = 4;
+        f32x4 a[B], b[B], c[B], d[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i)
+            if (q0 + i < NQ) {
+                const int vo = voff + (q0 + i) * plane_b;
+                a[i] = bload(r, vo, 0); b[i] = bload(r, vo, 16); c[i] = bload(r, vo, pitch); d[i] = bload(r, vo, pitch + 16);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < B; ++i)
+            if (q0 + i < NQ) *reinterpret_cast<f32x4*>(os + (q0 + i) * oplane) = a[i] * w00 + b[i] * w01 + c[i] * w10 + d[i] * w11;
+    }
+}
+
+template <int NQA, int NQB>
+__global__ __launch_bounds__(256) void flow_warp_p4_dual_kernel(const float* __restrict__ xa, const float* __restrict__ xb_,
+                                                                const float* __restrict__ flow, float* __restrict__ outa,
+                                                                float* __restrict__ outb, int H, int W) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    const long long pix = (long long)py * W + px;
+    const float2 f = *reinterpret_cast<const float2*>(flow + pix * 2);
+    const float dw = (float)(W - 1 > 1 ? W - 1 : 1), dh = (float)(H - 1 > 1 ? H - 1 : 1);
+    const float gx = 2.0f * ((float)px + f.x) / dw - 1.0f;
+    const float gy = 2.0f * ((float)py + f.y) / dh - 1.0f;
+    float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f);
+    float iy = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+    ix = fminf(fmaxf(ix, -1.0f), (float)W);
+    iy = fminf(fmaxf(iy, -1.0f), (float)H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float lx = ix - fx, ly = iy - fy, hx = 1.0f - lx, hy = 1.0f - ly;
+    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
+    const int guard = pitch + 16;   // see flow_warp_p4_kernel
+    const int voff = ((int)fy * PW + (int)fx) * 16 + guard;
+    const long long oplane = (long long)H * W * 4;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xa) - (guard >> 2), 0,
+                                                                        NQA * plane_b + guard, 0x00020000);
+    warp_quads<NQA>(ra, voff, pitch, plane_b, w00, w01, w10, w11, outa + pix * 4, oplane);
+    if (NQB > 0) {
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb_) - (guard >> 2), 0,
+                                                                            NQB * plane_b + guard, 0x00020000);
+        warp_quads<NQB>(rb, voff, pitch, plane_b, w00, w01, w10, w11, outb + pix * 4, oplane);
+    }
+}
+
+// prev2 (8 quads) + carry (6 quads) by flow2, one launch; zeros padding, P4 sources
+int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* flow, float* outa, float* outb, int H, int W,
+                                 hipStream_t s) {
+    const double px = (double)H * W;
+    ProfScope prof("flow_warp_q4_c32+c24", s, px * (2.0 * 14 * 4 + 2) * 4.0, px * 14 * 4 * 7.0);
+    flow_warp_p4_dual_kernel<8, 6><<<dim3((W + 63) / 64, (H + 3) / 4, 1), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
                         int N, int nq, int H, int W, int border, int src_pad, hipStream_t s) {
     const double px = (double)N * H * W;
