@@ -63,7 +63,6 @@ __device__ __forceinline__ float4 load_src_quad(const ConvSrc& s, int n, int kql
 // tanh / sigmoid on the hardware exp2 + rcp (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of the libm
 // versions (~30 VALU instructions each): the 216-channel offset/mask epilogue is transcendental-bound
 // otherwise.  |error| < 3e-7 absolute on both, i.e. < 3e-6 px on the +-10 px DCN offsets.
-__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
 __device__ __forceinline__ float fast_tanh(float v) {
     const float e = __expf(-2.0f * fabsf(v));          // in (0, 1]: no overflow
     const float t = (1.0f - e) * __frcp_rn(1.0f + e);
@@ -239,10 +238,10 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                               acc[ct][pt][4 * g + 2] + b.z, acc[ct][pt][4 * g + 3] + b.w};
                 if (STORE == ST_OFFMASK) {
                     if (cq < e.n_off_quads) {  // (dy,dx) pairs: 10*tanh(.) + flow flipped to (y,x)
-                        v[0] = 10.0f * fast_tanh(v[0]) + fl.y;
-                        v[1] = 10.0f * fast_tanh(v[1]) + fl.x;
-                        v[2] = 10.0f * fast_tanh(v[2]) + fl.y;
-                        v[3] = 10.0f * fast_tanh(v[3]) + fl.x;
+                        v[0] = tanh10_plus(v[0], 10.0f + fl.y);
+                        v[1] = tanh10_plus(v[1], 10.0f + fl.x);
+                        v[2] = tanh10_plus(v[2], 10.0f + fl.y);
+                        v[3] = tanh10_plus(v[3], 10.0f + fl.x);
                     } else {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) v[c] = fast_sigmoid(v[c]);

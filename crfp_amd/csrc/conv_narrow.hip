@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
                 } else {  // NE_OFFMASK3
                     const float2 f = *reinterpret_cast<const float2*>(flowp + pix * 2);
                     *reinterpret_cast<float4*>(dst + dpix * 4) =
-                        make_float4(10.0f * tanhf(acc[i][0]) + f.y, 10.0f * tanhf(acc[i][1]) + f.x,
-                                    1.0f / (1.0f + expf(-acc[i][2])), 0.0f);
+                        make_float4(tanh10_plus(acc[i][0], 10.0f + f.y), tanh10_plus(acc[i][1], 10.0f + f.x),
+                                    fast_sigmoid(acc[i][2]), 0.0f);   // libm tanhf/expf were the whole 42 us of this conv
                 }
             }
         }

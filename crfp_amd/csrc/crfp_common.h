@@ -166,6 +166,15 @@ struct NarrowArgs {
     long long* stamps;  // diagnostic builds (-DCRFP_NARROW_STAMPS) only
 };
 
+// Activations of the offset/mask heads (DCN modules, model/CRFP.py:338-340): hardware exp2/rcp, ~1 ulp each.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+// 10*tanh(v) + f as (10 + f) - 20 / (1 + e^(2v)), c10f = 10 + f: mul, exp, add, rcp, fma.  e^(2v) = inf / 0 at the ends
+// gives f + 10 / f - 10 exactly; absolute error ~2e-6 px.
+__device__ __forceinline__ float tanh10_plus(float v, float c10f) {
+    const float r = __frcp_rn(1.0f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f));
+    return __builtin_fmaf(r, -20.0f, c10f);
+}
+
 // ------------------------------------------------------------------ XCD-aware tile order
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  With the natural order two
 // neighbouring tiles (which share halo rows / gathered lines) always sit on different XCDs and both fetch the shared lines
