@@ -43,15 +43,27 @@ __device__ __forceinline__ float n_act(float v, int act) {
 #ifndef CRFP_NARROW_KY_UNROLL
 #define CRFP_NARROW_KY_UNROLL 1
 #endif
+#ifndef CRFP_NARROW_MFMA
+#define CRFP_NARROW_MFMA 1
+#endif
 constexpr int NTW = 64, NTH = 16, NLW = NTW + 2, NLH = NTH + 2;
 constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per quad
 
 template <int KQ, int EPI>
 __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_narrow_kernel(const NarrowArgs a) {
     __shared__ float4 tile[KQ][NLH][NLW];
-    __shared__ float4 wl[9 * KQ * 4];  // weights as [tap][kq][cin comp] -> float4 over cout (broadcast reads)
+    __shared__ float4 wl[9 * KQ * 4];  // FMA form: [tap][kq][cin comp] -> float4 over cout (broadcast reads)
+                                       // MFMA form: [tap][kq][cout] -> float4 over cin comp (lane reads row cout = lane & 3)
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    if (tid < 9 * KQ * 4) wl[tid] = reinterpret_cast<const float4*>(a.wpk)[tid];
+    if (tid < 9 * KQ * 4) {
+        const float4 wv = reinterpret_cast<const float4*>(a.wpk)[tid];   // packed: (tap, kq, cin comp) -> 4 couts
+        if (CRFP_NARROW_MFMA) {
+            float* wf = reinterpret_cast<float*>(wl) + (tid >> 2) * 16 + (tid & 3);
+            wf[0] = wv.x; wf[4] = wv.y; wf[8] = wv.z; wf[12] = wv.w;
+        } else {
+            wl[tid] = wv;
+        }
+    }
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + NTW - 1) / NTW, ntiles = tiles_x * ((H + NTH - 1) / NTH);
@@ -135,9 +147,9 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
         const int t_next = t_cur + t_step;
         if (t_next < band1) CRFP_NARROW_LOAD(t_next)     // flies during the FMAs and stores below
 
-        float acc[4][4];
+        f32x4 acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i][0] = bias.x; acc[i][1] = bias.y; acc[i][2] = bias.z; acc[i][3] = bias.w; }
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{bias.x, bias.y, bias.z, bias.w};
         // (k, ky) loops are deliberately NOT unrolled: hipcc otherwise hoists all 36 weight reads and
         // 18 halo reads of a quad and blows past 200 VGPRs (or spills at a lower cap).
 #pragma unroll 1
@@ -147,6 +159,25 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const float4* wq = &wl[((ky * 3 + kx) * KQ + k) * 4];
+                    if (CRFP_NARROW_MFMA) {
+                        // v_mfma_f32_4x4x1_16b_f32: 16 blocks of (4 couts x 1) x (1 x 4 pixels); lane l supplies A row l & 3
+                        // (its cout's weight) and B column l & 3 (its own pixel's value) of block l >> 2 and receives the 4
+                        // couts of its own pixel in the 4 result registers -- one 8-cycle MFMA where the FMA form issues four
+                        // 4-cycle v_fma_f32 (packed FP32 would do the same but is off, see Makefile).  fp32 in, fp32 out.
+                        const float4 wv = wq[tx & 3];
+                        f32x4 u[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) u[i] = reinterpret_cast<const f32x4&>(tile[k][4 * ty + ky + i][tx + kx]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, u[i].x, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, u[i].y, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, u[i].z, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, u[i].w, acc[i], 0, 0, 0);
+                        continue;
+                    }
                     const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
