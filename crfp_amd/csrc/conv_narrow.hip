@@ -41,7 +41,13 @@ __device__ __forceinline__ float n_act(float v, int act) {
 // the FMAs and stores of tile t: the one-tile-per-workgroup version spent 7.7-12 k cycles per tile waiting for its
 // loads and 4 k in an epilogue that re-read its arguments (s_memtime stamps), i.e. HBM idled while it computed.
 #ifndef CRFP_NARROW_KY_UNROLL
-#define CRFP_NARROW_KY_UNROLL 1
+#define CRFP_NARROW_KY_UNROLL 3
+#endif
+#ifndef CRFP_NARROW_OCC1
+#define CRFP_NARROW_OCC1 4   // workgroups per CU (launch bound and persistent grid) for KQ = 1
+#endif
+#ifndef CRFP_NARROW_OCC2
+#define CRFP_NARROW_OCC2 3   // ... for KQ = 2 (KQ = 3: 2, LDS-bound)
 #endif
 #ifndef CRFP_NARROW_MFMA
 #define CRFP_NARROW_MFMA 1
@@ -50,7 +56,7 @@ constexpr int NTW = 64, NTH = 16, NLW = NTW + 2, NLH = NTH + 2;
 constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per quad
 
 template <int KQ, int EPI>
-__global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_narrow_kernel(const NarrowArgs a) {
+__global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_NARROW_OCC2 : 2)) void conv3x3_narrow_kernel(const NarrowArgs a) {
     __shared__ float4 tile[KQ][NLH][NLW];
     __shared__ float4 wl[9 * KQ * 4];  // FMA form: [tap][kq][cin comp] -> float4 over cout (broadcast reads)
                                        // MFMA form: [tap][kq][cout] -> float4 over cin comp (lane reads row cout = lane & 3)
@@ -150,8 +156,9 @@ __global__ __launch_bounds__(256, KQ == 1 ? 4 : (KQ == 2 ? 3 : 2)) void conv3x3_
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{bias.x, bias.y, bias.z, bias.w};
-        // (k, ky) loops are deliberately NOT unrolled: hipcc otherwise hoists all 36 weight reads and
-        // 18 halo reads of a quad and blows past 200 VGPRs (or spills at a lower cap).
+        // The k loop is deliberately NOT unrolled (hipcc otherwise hoists every quad's reads).  ky is: with the MFMA form
+        // a quad needs 18 halo + 9 weight ds_read_b128 (27 instead of 45 when the rows shared by the ky are re-read) and
+        // stays at 108 / 128 / 149 VGPRs for KQ = 1 / 2 / 3 (+0.7 % clip); the FMA form spilled when ky was unrolled.
 #pragma unroll 1
         for (int k = 0; k < KQ; ++k) {
 #pragma unroll (CRFP_NARROW_KY_UNROLL)
@@ -306,7 +313,7 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     // persistent: a few workgroups per CU walk the tiles (ceil-balanced shares)
     const int ntl = ((a.W + NTW - 1) / NTW) * ((a.H + NTH - 1) / NTH);
     static const int per_cu_env = getenv("CRFP_NARROW_WGS_PER_CU") ? atoi(getenv("CRFP_NARROW_WGS_PER_CU")) : 0;   // tuning knob
-    const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? 4 : (a.kq == 2 ? 3 : 2));
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? CRFP_NARROW_OCC1 : (a.kq == 2 ? CRFP_NARROW_OCC2 : 2));
     const int share = (ntl + 256 * per_cu - 1) / (256 * per_cu);
     dim3 grid((ntl + share - 1) / share, 1, a.N);
 #define CRFP_NARROW_LAUNCH(KQ_)                                                                    \
