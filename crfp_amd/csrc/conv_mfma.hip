@@ -132,6 +132,24 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
     }
 }
 
+// The f16x3 split of 4 values (same arithmetic as split_f16x8_fast further down, which a consuming conv would apply):
+// hi[] = fp16(x) pairs, lo[] = fp16((x - fp16(x)) * 2^11) pairs.
+__device__ __forceinline__ void split_f16x4(const float (&x)[4], unsigned (&hi)[2], unsigned (&lo)[2]) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    float negone = -1.0f;
+    asm("" : "+v"(negone));   // opaque: keeps fma(x0, -1, x) a v_fma_mix_f32
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const h2_t a = __builtin_convertvector(f2_t{x[2 * i], x[2 * i + 1]}, h2_t);
+        const float r0 = __builtin_fmaf((float)a[0], negone, x[2 * i]);
+        const float r1 = __builtin_fmaf((float)a[1], negone, x[2 * i + 1]);
+        const h2_t b = __builtin_convertvector(f2_t{r0 * 2048.0f, r1 * 2048.0f}, h2_t);
+        hi[i] = __builtin_bit_cast(unsigned, a);
+        lo[i] = __builtin_bit_cast(unsigned, b);
+    }
+}
+
 // Epilogue shared by the fp32-MFMA and the split-bf16-MFMA main loops (identical C/D lane map):
 // bias, activation, scale, residual, layout-aware store.
 //
@@ -154,6 +172,8 @@ struct EpiCtx {
     const float4* bp;
     const float* rp;
     const float* flp;
+    float* s3p;          // SRC_S3 image of the output (null: none)
+    int s3_ngroups;      // cout / 8
     float* dp[CRFP_MAX_DST];
     long long dplane[CRFP_MAX_DST];
     int dpitch[CRFP_MAX_DST], dq0[CRFP_MAX_DST], dq1[CRFP_MAX_DST];
@@ -171,6 +191,8 @@ __device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
     e.bp = reinterpret_cast<const float4*>(a.bpk);
     e.rp = a.resid ? a.resid + (long long)n * a.resid_bstride : nullptr;
     e.flp = a.flow + (long long)n * a.flow_bstride;
+    e.s3p = a.s3_dst ? a.s3_dst + (long long)n * a.s3_bstride : nullptr;
+    e.s3_ngroups = a.cout >> 3;
 #pragma unroll
     for (int d = 0; d < CRFP_MAX_DST; ++d) {
         const bool on = d < a.ndst;
@@ -261,6 +283,14 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                 if (e.rp) { v[0] += rr[ct][g].x; v[1] += rr[ct][g].y; v[2] += rr[ct][g].z; v[3] += rr[ct][g].w; }
                 // store addresses = per-lane pixel offset (one 32-bit multiply per pixel tile) + wave-uniform 64-bit
                 // part per quad: the per-lane 64-bit multiplies of the first version were most of the epilogue's 6 k cycles
+                if (STORE == ST_Q4 && e.s3p) {   // SRC_S3 image: this lane's 4 channels are half h of the 8-channel element
+                    unsigned hi2[2], lo2[2];
+                    split_f16x4(v, hi2, lo2);
+                    const int grp = (T0 + ct) * 4 + g;
+                    float* sp = e.s3p + (((long long)grp * H + y) * W + x) * 4 + h * 2;
+                    *reinterpret_cast<uint2*>(sp) = make_uint2(hi2[0], hi2[1]);
+                    *reinterpret_cast<uint2*>(sp + (long long)e.s3_ngroups * H * W * 4) = make_uint2(lo2[0], lo2[1]);
+                }
                 if (STORE == ST_Q4 || STORE == ST_OFFMASK) {
                     if (e.single) {   // one destination that takes every quad (wave-uniform)
                         const int cq0u = (T0 + ct) * 8 + 2 * g;
@@ -699,7 +729,19 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t;   // diagnostic: load-landing wait booked under C
         }
-        if (NP == 2 && (m0 & m1 & m2 & m3) == 15) {   // wave-uniform: every chunk but a ragged last one
+        if (NP == 2 && (m0 & 16)) {   // SRC_S3 chunk (wave-uniform): the producer already split it -- copy, zero outside the image
+#pragma unroll
+            for (int t = 0; t < NIN; ++t) {
+                const int idx = tid + 256 * t;
+                if (idx < NEL) {
+                    const f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    tile[0][0][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq0[t] : z);        // (x0,  channels 0..7 of the chunk)
+                    tile[0][1][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq1[t] : z);        // (x0,  channels 8..15)
+                    tile[NP - 1][0][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq2[t] : z);   // (x1s, channels 0..7)
+                    tile[NP - 1][1][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq3[t] : z);   // (x1s, channels 8..15)
+                }
+            }
+        } else if (NP == 2 && (m0 & m1 & m2 & m3) == 15) {   // wave-uniform: every chunk but a ragged last one
 #pragma unroll
             for (int t = 0; t < NIN; ++t) {
                 const int idx = tid + 256 * t;
@@ -1434,6 +1476,20 @@ int launch_conv_pack(const ConvArgs& a, const float* w, const float* bias, const
     return 0;
 }
 
+// SRC_S3 sources / s3_dst are understood by conv3x3_split_kernel<1,1,2> (the default) only
+bool conv_s3_supported() {
+    static const bool ok = [] {
+        auto on = [](const char* k) { return getenv(k) && atoi(getenv(k)) != 0; };
+        if (getenv("CRFP_CONV_MODE") && strcmp(getenv("CRFP_CONV_MODE"), "f16x3")) return false;
+        if (on("CRFP_SPLIT_WS") || on("CRFP_SPLIT_IS") || on("CRFP_SPLIT_PIPE")) return false;
+        if (getenv("CRFP_SPLIT_RPW") && atoi(getenv("CRFP_SPLIT_RPW")) != 1) return false;
+        if (getenv("CRFP_SPLIT_CT") && atoi(getenv("CRFP_SPLIT_CT")) != 1) return false;
+        if (getenv("CRFP_CONV_S3") && atoi(getenv("CRFP_CONV_S3")) == 0) return false;   // A/B knob
+        return true;
+    }();
+    return ok;
+}
+
 int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     if (a.kq & 1 || a.kq < 2 || a.ctiles < 1 || a.nsrc < 1 || a.nsrc > CRFP_MAX_SRC) {
         set_error("conv_mfma %s: bad plan (kq=%d ctiles=%d nsrc=%d)", name, a.kq, a.ctiles, a.nsrc);
@@ -1452,6 +1508,12 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     bool nchw_src = false;
     for (int i = 0; i < a.nsrc; ++i) nchw_src |= a.src[i].kind == SRC_NCHW;
     const bool split = a.wsplit && use_split && (a.kq & 3) == 0 && !nchw_src && a.kq <= CRFP_MAX_KQ;
+    bool uses_s3 = a.s3_dst != nullptr;
+    for (int i = 0; i < a.nsrc; ++i) uses_s3 |= a.src[i].kind == SRC_S3;
+    if (uses_s3 && (!split || !conv_s3_supported() || (a.s3_dst && (a.store != ST_Q4 || (a.cout & 7))))) {
+        set_error("conv_mfma %s: SRC_S3 / s3_dst need the default f16x3 kernel, ST_Q4 and cout %% 8 == 0", name);
+        return CRFP_E_UNSUPPORTED;
+    }
     static const int split_ct = getenv("CRFP_SPLIT_CT") ? atoi(getenv("CRFP_SPLIT_CT")) : 1;  // tuning knob
     if (split && split_ct < 2) ct2 = false;  // <2,1> needs 93 KB of LDS (1 workgroup per CU): slower than 2 x <1,1>
     const int TH = (ct2 || (split && split_rpw == 1)) ? 4 : 8;
@@ -1483,6 +1545,15 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
                     d.base = sr.p + ((long long)(k >> 4) * (4 * a.H + sr.pad) * W4 + (ij >> 2) * W4 + (ij & 3)) * 4;
                 } else if (sr.kind == SRC_FLOW2) {
                     d.rs = 2 * a.W; d.cs = 2; d.mask = 3; d.base = sr.p;
+                } else if (sr.kind == SRC_S3) {
+                    // chunk-local quad qi -> 16-byte plane: qi 0/1 = x0 image, channels 0..7 / 8..15 of the chunk; qi 2/3 = x1s image
+                    if ((q & 3) != (k & 3) || (sr.nq & 3) || sr.pad) {
+                        set_error("conv_mfma %s: an SRC_S3 source must start on a 16-channel chunk, hold whole chunks and be unpadded", name);
+                        return CRFP_E_BADARG;
+                    }
+                    const int qi = k & 3, plane = (qi >> 1) * (sr.nq >> 1) + 2 * (k >> 2) + (qi & 1);
+                    d.rs = a.W * 4; d.cs = 4; d.mask = 16 | 15;
+                    d.base = sr.p + (long long)plane * a.H * d.rs;
                 } else {
                     d.rs = 0; d.cs = 0; d.mask = 0; d.base = a.wpk; d.bstride = 0;
                 }

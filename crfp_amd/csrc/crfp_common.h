@@ -24,7 +24,11 @@ enum SrcKind : int {
     SRC_NCHW = 1,    // NCHW planes (API tensors / LR frames), nch channels
     SRC_UNSHUF4 = 2, // Q4 tensor at 4x resolution read through pixel_unshuffle(4): nch = 16 * C_hi
     SRC_FLOW2 = 3,   // [H][W][2] (dx,dy) pairs -> quad (dx,dy,0,0)
-    SRC_ZERO = 4     // padding quad(s)
+    SRC_ZERO = 4,    // padding quad(s)
+    SRC_S3 = 5       // pre-split fp16 pair image written by a producing conv (ConvArgs::s3_dst): 2 x nch/8 planes of
+                     // [H][W] 16-byte elements = 8 channels of fp16; planes [0, nch/8) hold x0 = fp16(x), planes
+                     // [nch/8, nch/4) hold x1s = fp16((x - x0) * 2^11).  Same bytes per pixel as the fp32 Q4 tensor it
+                     // replaces; the consuming conv copies it to LDS instead of converting (nch % 16 == 0, chunk aligned)
 };
 
 enum StoreMode : int {
@@ -87,7 +91,11 @@ struct ConvArgs {
     int store, ps_r;
     int n_off_quads;
     int dstH, dstW;
+    float* s3_dst;      // ST_Q4 only: also (or, with ndst == 0, only) write the output as an SRC_S3 image (cout % 8 == 0)
+    long long s3_bstride;
 };
+
+bool conv_s3_supported();   // the selected conv kernels consume SRC_S3 sources (default f16x3 path only)
 
 // packed row (0..ctiles*32) -> reference output channel, or -1 (padding)
 __host__ __device__ inline int conv_row_to_cout(int row, int cout, int store, int ps_r) {
@@ -114,6 +122,7 @@ __host__ __device__ inline int conv_packed_rows(int cout, int store, int ps_r) {
 __host__ __device__ inline int conv_k_to_cin(int kind, int nch, int kql, int comp) {
     switch (kind) {
         case SRC_Q4:
+        case SRC_S3:
         case SRC_NCHW: {
             const int c = 4 * kql + comp;
             return c < nch ? c : -1;
@@ -133,6 +142,7 @@ __host__ __device__ inline int conv_k_to_cin(int kind, int nch, int kql, int com
 __host__ __device__ inline int src_quads(int kind, int nch) {
     switch (kind) {
         case SRC_Q4:
+        case SRC_S3:
         case SRC_NCHW: return (nch + 3) / 4;
         case SRC_UNSHUF4: return ((nch / 16 + 3) / 4) * 16;
         case SRC_FLOW2: return 1;

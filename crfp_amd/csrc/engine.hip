@@ -188,15 +188,19 @@ struct Model {
         add_mfma(IT_ENC_LR1, "conv_mfma:enc_lr1", CI_ENC_LR1, -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_LRELU01);
         add_mfma(IT_UPS, "conv_mfma:upsample_ps2", CI_UPS, -1, {{Q, 32}}, ST_PS, 2, CRFP_ACT_NONE);
         add_mfma(IT_DOWN, "conv_mfma:downsample_unshuf4", CI_DOWN, -1, {{SRC_UNSHUF4, 64}}, ST_Q4, 0, CRFP_ACT_NONE);
+        // The DCN offset feature of a level (dcn_block.2 / conv_fuse output, model/CRFP.py:331-336) only ever feeds convs
+        // (offset/mask head, next level's conv_fuse, dcn_3's pre-offset conv): it is stored as the producer-split SRC_S3
+        // image instead of fp32 Q4 (same bytes), so the 216-channel head no longer converts the same tile 7 times.
+        const int FS = conv_s3_supported() ? (int)SRC_S3 : (int)Q;
         for (int l = 0; l < 3; ++l) {
             if (l > 0)
-                add_mfma(it_lvl(l, L_FUSE), "conv_mfma:dcn.conv_fuse", ci_dcn(l, 0), -1, {{Q, 32}, {Q, 32}}, ST_Q4, 0,
+                add_mfma(it_lvl(l, L_FUSE), "conv_mfma:dcn.conv_fuse", ci_dcn(l, 0), -1, {{Q, 32}, {FS, 32}}, ST_Q4, 0,
                          CRFP_ACT_LRELU01);
             // dcn_block.0 input = [cur = prop(24) | carry(8)] | warped prev(32) | flow(2)   (:331,1586)
             add_mfma(it_lvl(l, L_DB0), "conv_mfma:dcn.block0", ci_dcn(l, 1), -1,
                      {{Q, 24}, {Q, 8}, {Q, 32}, {SRC_FLOW2, 2}}, ST_Q4, 0, CRFP_ACT_LRELU01);
             add_mfma(it_lvl(l, L_DB1), "conv_mfma:dcn.block2", ci_dcn(l, 2), -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_LRELU01);
-            add_mfma(it_lvl(l, L_OM), "conv_mfma:dcn.offset_mask", ci_dcn(l, 3), ci_dcn(l, 4), {{Q, 32}}, ST_OFFMASK, 0,
+            add_mfma(it_lvl(l, L_OM), "conv_mfma:dcn.offset_mask", ci_dcn(l, 3), ci_dcn(l, 4), {{FS, 32}}, ST_OFFMASK, 0,
                      CRFP_ACT_NONE);
             items[it_lvl(l, L_OM)].c.n_off_quads = 36;
             Item& dw = items[it_lvl(l, L_DCNW)];
@@ -214,7 +218,7 @@ struct Model {
             add_mfma(it_lvl(l, L_RB2), "conv_mfma:res.conv2_add", ci_rb(l, 2), -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_NONE);
         }
         add_mfma(IT_UPP, "conv_mfma:upsample_post_ps4", CI_UPP, -1, {{Q, 24}}, ST_PS, 4, CRFP_ACT_LRELU01);
-        add_mfma(IT_POFF, "conv_mfma:dcn3.preoffset_ps4", CI_D3_UPS, -1, {{Q, 32}}, ST_PS, 4, CRFP_ACT_NONE, 2.0f);
+        add_mfma(IT_POFF, "conv_mfma:dcn3.preoffset_ps4", CI_D3_UPS, -1, {{FS, 32}}, ST_PS, 4, CRFP_ACT_NONE, 2.0f);
         add_narrow(IT_EH0, "conv_narrow:enc_hr0", CI_ENC_HR0, -1, {{Q, 3}, {Q, 3}}, CRFP_ACT_LRELU01, NE_PLAIN);
         add_narrow(IT_EH1, "conv_narrow:enc_hr1", CI_ENC_HR1, -1, {{Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
         add_narrow(IT_D3B0, "conv_narrow:dcn3.block0", CI_D3_B0, -1, {{Q, 4}, {Q, 4}, {SRC_FLOW2, 2}}, CRFP_ACT_LRELU01,
@@ -409,8 +413,10 @@ struct Runner {
     struct SrcBind { const float* p; long long bs; int pad = 0; };
     struct DstBind { float* p; long long bs; int q0, q1; int pad = 0; };
 
+    // s3: the output goes (only, when dsts is empty) to an SRC_S3 image
     void mfma(int id, int N, int H, int W, std::vector<SrcBind> srcs, std::vector<DstBind> dsts, int dstH = 0, int dstW = 0,
-              const float* resid = nullptr, long long resid_bs = 0, const float* flow = nullptr, long long flow_bs = 0) {
+              const float* resid = nullptr, long long resid_bs = 0, const float* flow = nullptr, long long flow_bs = 0,
+              float* s3 = nullptr, long long s3_bs = 0) {
         if (rc) return;
         const Item& it = M.items[id];
         ConvArgs a = it.c;
@@ -422,6 +428,7 @@ struct Runner {
         }
         a.N = N; a.H = H; a.W = W; a.dstH = dstH; a.dstW = dstW;
         a.resid = resid; a.resid_bstride = resid_bs; a.flow = flow; a.flow_bstride = flow_bs;
+        a.s3_dst = s3; a.s3_bstride = s3_bs;
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
         a.wsplit = packed + it.off_s;
@@ -537,11 +544,14 @@ struct Runner {
                 mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
                      {{F(L.fa), 0, 0, 8}});
                 float* f = F(L.offfeat[l]);
+                const bool s3 = conv_s3_supported();   // f holds the SRC_S3 image (same size) instead of fp32 Q4
                 if (l == 0) {
-                    mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{f, 0, 0, 8}});
+                    if (s3) mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, 0);
+                    else mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{f, 0, 0, 8}});
                 } else {
                     mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{F(L.fb), 0, 0, 8}});
-                    mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {{f, 0, 0, 8}});
+                    if (s3) mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, 0);
+                    else mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {{f, 0, 0, 8}});
                 }
                 mfma(it_lvl(l, L_OM), 1, H2, W2, {{f, 0}}, {{F(L.offmask), 0, 0, 54}}, 0, 0, nullptr, 0, flow2, 0);
                 const Item& dw = M.items[it_lvl(l, L_DCNW)];
