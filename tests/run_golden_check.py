@@ -20,3 +20,5 @@ m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict
 m = m.to(dev).eval()
 out = m(lrs=torch.from_numpy(lrs).to(dev), fvs=torch.from_numpy(fvs).to(dev), mks=torch.from_numpy(mks).to(dev)).cpu().numpy()
 print("MAXDIFF %.6e" % float(np.abs(out - g["out"]).max()))
+import hashlib  # noqa: E402
+print("DIGEST " + hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest())

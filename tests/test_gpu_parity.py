@@ -268,7 +268,7 @@ def test_streaming_variant_golden():
 
 @pytest.mark.parametrize("env", [{"CRFP_CONV_MODE": "f32"}, {"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "0"},
                                  {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"}, {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SIDE_STREAM": "0"}, {"CRFP_SPLIT_PIPE": "1"}, {"CRFP_CONV_MODE": "bf16x6"},
-                                 {"CRFP_CONV_MODE": "bf16x6", "CRFP_SPLIT_IS": "0"}])
+                                 {"CRFP_CONV_MODE": "bf16x6", "CRFP_SPLIT_IS": "0"}, {"CRFP_CONV_S3": "0"}])
 def test_alternate_kernel_paths(env):
     """Every selectable conv main loop (fp32 MFMA, split-bf16 single-role / input-stationary /
     warp-specialised, 4- and 8-row tiles) must give the same clip within the parity tolerance."""
@@ -281,6 +281,23 @@ def test_alternate_kernel_paths(env):
     line = [l for l in out.stdout.splitlines() if l.startswith("MAXDIFF")]
     assert line, out.stderr[-2000:]
     assert float(line[0].split()[1]) < 2e-4
+
+
+def test_producer_split_is_bit_identical():
+    """SRC_S3 (the producing conv writes the fp16 pair image) must not change a single bit: the
+    producer applies the same split the consumer would."""
+    import subprocess
+    import sys
+    digests = []
+    for s3 in ("1", "0"):
+        e = dict(os.environ)
+        e["CRFP_CONV_S3"] = s3
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "run_golden_check.py")],
+                             capture_output=True, text=True, env=e, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")]
+        assert line, out.stderr[-2000:]
+        digests.append(line[0])
+    assert digests[0] == digests[1]
 
 
 def test_config_b_geometry_vs_oracle(orc):
