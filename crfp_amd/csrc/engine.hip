@@ -708,14 +708,15 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
     R.reset_state();
     R.encode_lr(t, lrs, lr_f);
     if (hipEventRecord(ev_xlr, main_s) != hipSuccess) return fail("record");
-    R.s = ss.s;
-    if (t > 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
     if (hipStreamWaitEvent(ss.s, ev_xlr, 0) != hipSuccess) return fail("wait");
     for (int i = 0; i < t && !R.rc; ++i) {
         hipEvent_t pre_done = ss.event(2 + 2 * i), main_done = ss.event(3 + 2 * i);
         if (!ss.ok) return fail("hipEventCreate");
         // side: pre-work of frame i into set i&1 (free once the recurrent part of frame i-2 is done)
         R.s = ss.s;
+        // FNet (all pairs, 0.7 ms) goes BEHIND frame 0's pre-work: frame 0 needs no flow, and with FNet first the caller's
+        // stream sat idle for FNet + pre(0) at the start of every clip.  It now runs beside frame 0's recurrent part.
+        if (i == 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
         if (i >= 2 && hipStreamWaitEvent(ss.s, ss.event(3 + 2 * (i - 2)), 0) != hipSuccess) return fail("wait");
         R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
                     i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq);
