@@ -508,13 +508,16 @@ struct Runner {
 
     // one iteration of the recurrent loop (reference model/CRFP.py:1555-1684)
     // state-independent part of a frame (reference model/CRFP.py:1538-1547,1560,1565-1566): buffer set `par`
+    // before_ups: event this stream waits for right before the upsample conv, the only consumer of x_lr here (clip
+    // schedule: the fovea blend and encoder_hr of frame 0 then run beside encoder_lr instead of behind it)
     void frame_pre(int par, bool first, const float* lr, const float* fv, const uint8_t* mk, const float* flow_lr_q4,
-                   const float* x_lr_i) {
+                   const float* x_lr_i, hipEvent_t before_ups = nullptr) {
         const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         const long long P8q = (long long)H8 * W8 * 4;
         RUN(launch_hr_prep(lr, fv, mk, F(L.xin8[par]), h, w, s));
         narrow(IT_EH0, H8, W8, {F(L.xin8[par]), F(L.xin8[par]) + P8q}, F(L.eh[par]));
         narrow(IT_EH1, H8, W8, {F(L.eh[par])}, F(L.x_hr[par]));
+        if (before_ups && !rc && hipStreamWaitEvent(s, before_ups, 0) != hipSuccess) { set_error("dsv: hipStreamWaitEvent failed"); rc = 1; }
         mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0[par]), 0, 0, 6}}, H2, W2);
         if (!first) {
             RUN(launch_upflow(flow_lr_q4, 0, F(L.flow2[par]), 0, 1, h, w, 2, s));
@@ -708,7 +711,6 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
     R.reset_state();
     R.encode_lr(t, lrs, lr_f);
     if (hipEventRecord(ev_xlr, main_s) != hipSuccess) return fail("record");
-    if (hipStreamWaitEvent(ss.s, ev_xlr, 0) != hipSuccess) return fail("wait");
     for (int i = 0; i < t && !R.rc; ++i) {
         hipEvent_t pre_done = ss.event(2 + 2 * i), main_done = ss.event(3 + 2 * i);
         if (!ss.ok) return fail("hipEventCreate");
@@ -719,7 +721,7 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
         if (i == 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
         if (i >= 2 && hipStreamWaitEvent(ss.s, ss.event(3 + 2 * (i - 2)), 0) != hipSuccess) return fail("wait");
         R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
-                    i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq);
+                    i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq, i == 0 ? ev_xlr : nullptr);
         if (hipEventRecord(pre_done, ss.s) != hipSuccess) return fail("record");
         // main: recurrent part of frame i
         R.s = main_s;
