@@ -337,6 +337,26 @@ def test_two_stream_schedule_is_bit_exact():
         assert maxdiff(out, ref) == 0.0
 
 
+@pytest.mark.parametrize("t", [1, 2, 3])
+def test_two_stream_schedule_short_clips(t):
+    """Clip lengths at which the side-stream schedule changes shape (no FNet at t=1, FNet behind frame 0's pre-work
+    from t=2, buffer-set reuse from t=3): same bits as the single-stream schedule."""
+    from crfp_amd import synth
+    m = _model(synth.make_state_dict(7))
+    lrs, fvs, mks = synth.make_clip(99 + t, 1, t, 36, 64, fv_size=96)
+    d = dev()
+    L, Fv, M = T(lrs).to(d), T(fvs).to(d), T(mks).to(d)
+    os.environ["CRFP_SIDE_STREAM"] = "0"
+    try:
+        ref = m(lrs=L, fvs=Fv, mks=M).clone()
+    finally:
+        os.environ.pop("CRFP_SIDE_STREAM")
+    for _ in range(3):
+        out = m(lrs=L, fvs=Fv, mks=M)
+        torch.cuda.synchronize()
+        assert maxdiff(out, ref) == 0.0
+
+
 def test_concurrent_clips_on_two_streams_are_bit_exact():
     """Two engines, two caller streams, clips in flight together == the same clips run one after the other."""
     from crfp_amd import synth
