@@ -286,10 +286,14 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                 if (STORE == ST_Q4 && e.s3p) {   // SRC_S3 image: this lane's 4 channels are half h of the 8-channel element
                     unsigned hi2[2], lo2[2];
                     split_f16x4(v, hi2, lo2);
-                    const int grp = (T0 + ct) * 4 + g;
-                    float* sp = e.s3p + (((long long)grp * H + y) * W + x) * 4 + h * 2;
-                    *reinterpret_cast<uint2*>(sp) = make_uint2(hi2[0], hi2[1]);
-                    *reinterpret_cast<uint2*>(sp + (long long)e.s3_ngroups * H * W * 4) = make_uint2(lo2[0], lo2[1]);
+                    // v_permlane32_swap: lanes 32-63 of the first operand trade places with lanes 0-31 of the second.  After
+                    // it the lower lane (h = 0) holds the x0 words of all 8 channels and the upper lane (same pixel, h = 1)
+                    // the x1s words: one 16-byte store per lane instead of two 8-byte ones.
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 r0 = __builtin_amdgcn_permlane32_swap(hi2[0], lo2[0], false, false);
+                    const u32x2 r1 = __builtin_amdgcn_permlane32_swap(hi2[1], lo2[1], false, false);
+                    const int plane = (T0 + ct) * 4 + g + h * e.s3_ngroups;
+                    *reinterpret_cast<uint4*>(e.s3p + (((long long)plane * H + y) * W + x) * 4) = make_uint4(r0.x, r1.x, r0.y, r1.y);
                 }
                 if (STORE == ST_Q4 || STORE == ST_OFFMASK) {
                     if (e.single) {   // one destination that takes every quad (wave-uniform)
