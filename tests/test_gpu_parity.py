@@ -283,6 +283,21 @@ def test_alternate_kernel_paths(env):
     assert float(line[0].split()[1]) < 2e-4
 
 
+@pytest.mark.parametrize("h,w,t,fv", [(18, 26, 3, 48), (33, 47, 3, 64), (17, 65, 3, 48), (64, 16, 2, 48), (21, 130, 2, 64)])
+def test_odd_geometries_vs_oracle(orc, h, w, t, fv):
+    """Sizes that are no multiple of any tile (4x64 conv tiles, 16x64 stencil tiles, 32-pixel DCN rows, FNet's three
+    poolings) against the CPU oracle."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    P = orc.load_numpy_state(sd)
+    lrs, fvs, mks = synth.make_clip(1000 + h * w, 1, t, h, w, fv_size=fv, sigma_t=10.0)
+    m = _model(sd)
+    d = dev()
+    out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    ref = orc.crfp_dsv_forward(P, T(lrs), T(fvs), T(mks))
+    assert maxdiff(out, ref) < 1e-4
+
+
 def test_producer_split_is_bit_identical():
     """SRC_S3 (the producing conv writes the fp16 pair image) must not change a single bit: the
     producer applies the same split the consumer would."""
