@@ -298,6 +298,24 @@ def test_odd_geometries_vs_oracle(orc, h, w, t, fv):
     assert maxdiff(out, ref) < 1e-4
 
 
+def test_batch_of_two_clips(orc):
+    """n = 2 (the reference's forward takes a batch; here the clips of a batch go through the C-ABI one by one)."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    P = orc.load_numpy_state(sd)
+    lrs, fvs, mks = synth.make_clip(31, 2, 3, 16, 24, fv_size=48)
+    m = _model(sd)
+    d = dev()
+    L, Fv, M = T(lrs).to(d), T(fvs).to(d), T(mks).to(d)
+    out = m(lrs=L, fvs=Fv, mks=M)
+    assert out.shape[0] == 2
+    for b in range(2):
+        one = m(lrs=L[b:b + 1], fvs=Fv[b:b + 1], mks=M[b:b + 1])
+        assert maxdiff(out[b:b + 1], one) == 0.0
+    ref = orc.crfp_dsv_forward(P, T(lrs), T(fvs), T(mks))
+    assert maxdiff(out, ref) < 1e-4
+
+
 def test_producer_split_is_bit_identical():
     """SRC_S3 (the producing conv writes the fp16 pair image) must not change a single bit: the
     producer applies the same split the consumer would."""
