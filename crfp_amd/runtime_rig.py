@@ -1,0 +1,76 @@
+"""Timing rig with the shape and the arithmetic of the reference's stand-alone speed test (test_runtime.py:81-99,
+128-129,142-186): 1 x 5 frames, LR 135 x 240 -> 1080 x 1920, a 96 x 96 fovea crop, 30 repetitions of which the first
+10 are warm-up, prints the output shape and seconds per frame = time / (repeat - warm_up + 1) / t exactly as the
+reference's last line does (its divisor counts one repetition too many; kept, so the printed number is comparable).
+
+What it is NOT: the reference's rig drives a benchmark-only wiring (model/CRFP_runtime.py:8364-8682 -- flow and alignment
+restricted to the top-left ``warp_size`` window, encoder_hr on the crop, other residual-block classes) through an import
+that does not exist in the reference repo (``model.MRCF_runtime``).  That wiring is not built here;
+this rig runs the shipped CRFP_DSV path over the WHOLE frame with the crop pasted at the top-left of the window, i.e. it
+does at least the work of the reference's variant.  ``warp_size`` is accepted and only used to place the crop.
+
+    python -m crfp_amd.runtime_rig [--repeat 30 --warm-up 10 --t 5 --hr 1080 1920 --fv 96 --warp 720 720]
+"""
+from __future__ import annotations
+
+import argparse
+
+import torch
+
+
+def build_inputs(lr: torch.Tensor, fv: torch.Tensor, warp_size):
+    """(lr [1,t,3,h,w], fv crop [1,t,3,fh,fw]) -> (lrs, fvs, mks) of CRFP_DSV.forward: the crop sits at the centre of the
+    top-left ``warp_size`` window of the 8x frame, mk = 1 there."""
+    n, t, _, h, w = lr.shape
+    fh, fw = fv.shape[-2:]
+    H, W = 8 * h, 8 * w
+    wy, wx = min(warp_size[0], H), min(warp_size[1], W)
+    y0, x0 = max((wy - fh) // 2, 0), max((wx - fw) // 2, 0)
+    fvs = torch.zeros(n, t, 3, H, W, device=lr.device, dtype=lr.dtype)
+    mks = torch.zeros(n, t, 1, H, W, device=lr.device, dtype=torch.bool)
+    fvs[..., y0:y0 + fh, x0:x0 + fw] = fv
+    mks[..., y0:y0 + fh, x0:x0 + fw] = True
+    return lr, fvs, mks
+
+
+def run(repeat_time=30, warm_up=10, t=5, hr=(1080, 1920), fv_size=96, warp_size=(720, 720), device="cuda:0", seed=7):
+    from . import synth
+    from .model import CRFP
+    dev = torch.device(device)
+    model = CRFP.CRFP_DSV(device=dev, mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(seed).items()}, strict=True)
+    model = model.to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lr = torch.rand(1, t, 3, hr[0] // 8, hr[1] // 8, generator=g).to(dev)
+    fv = torch.rand(1, t, 3, fv_size, fv_size, generator=g).to(dev)
+    lrs, fvs, mks = build_inputs(lr, fv, warp_size)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    infer_time, y = 0.0, None
+    with torch.no_grad():
+        for idx in range(repeat_time):
+            if idx < warm_up:
+                infer_time = 0.0
+            torch.cuda.synchronize()
+            start.record()
+            y = model(lrs=lrs, fvs=fvs, mks=mks)
+            end.record()
+            torch.cuda.synchronize()
+            infer_time += start.elapsed_time(end) / 1000
+    return y, infer_time / (repeat_time - warm_up + 1) / t
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--repeat", type=int, default=30)
+    ap.add_argument("--warm-up", type=int, default=10)
+    ap.add_argument("--t", type=int, default=5)
+    ap.add_argument("--hr", type=int, nargs=2, default=(1080, 1920))
+    ap.add_argument("--fv", type=int, default=96)
+    ap.add_argument("--warp", type=int, nargs=2, default=(720, 720))
+    a = ap.parse_args(argv)
+    y, s_per_frame = run(a.repeat, a.warm_up, a.t, tuple(a.hr), a.fv, tuple(a.warp))
+    print(y.shape, s_per_frame)   # test_runtime.py:186
+
+
+if __name__ == "__main__":
+    main()
