@@ -510,16 +510,19 @@ struct Runner {
     // state-independent part of a frame (reference model/CRFP.py:1538-1547,1560,1565-1566): buffer set `par`
     // before_ups: event this stream waits for right before the upsample conv, the only consumer of x_lr here (clip
     // schedule: the fovea blend and encoder_hr of frame 0 then run beside encoder_lr instead of behind it)
+    // parts: 1 = fovea blend + encoder_hr + upsample conv (need no flow), 2 = the two flow up-samplings (need FNet)
     void frame_pre(int par, bool first, const float* lr, const float* fv, const uint8_t* mk, const float* flow_lr_q4,
-                   const float* x_lr_i, hipEvent_t before_ups = nullptr) {
+                   const float* x_lr_i, hipEvent_t before_ups = nullptr, int parts = 3) {
         const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         const long long P8q = (long long)H8 * W8 * 4;
-        RUN(launch_hr_prep(lr, fv, mk, F(L.xin8[par]), h, w, s));
-        narrow(IT_EH0, H8, W8, {F(L.xin8[par]), F(L.xin8[par]) + P8q}, F(L.eh[par]));
-        narrow(IT_EH1, H8, W8, {F(L.eh[par])}, F(L.x_hr[par]));
-        if (before_ups && !rc && hipStreamWaitEvent(s, before_ups, 0) != hipSuccess) { set_error("dsv: hipStreamWaitEvent failed"); rc = 1; }
-        mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0[par]), 0, 0, 6}}, H2, W2);
-        if (!first) {
+        if (parts & 1) {
+            RUN(launch_hr_prep(lr, fv, mk, F(L.xin8[par]), h, w, s));
+            narrow(IT_EH0, H8, W8, {F(L.xin8[par]), F(L.xin8[par]) + P8q}, F(L.eh[par]));
+            narrow(IT_EH1, H8, W8, {F(L.eh[par])}, F(L.x_hr[par]));
+            if (before_ups && !rc && hipStreamWaitEvent(s, before_ups, 0) != hipSuccess) { set_error("dsv: hipStreamWaitEvent failed"); rc = 1; }
+            mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0[par]), 0, 0, 6}}, H2, W2);
+        }
+        if (!first && (parts & 2)) {
             RUN(launch_upflow(flow_lr_q4, 0, F(L.flow2[par]), 0, 1, h, w, 2, s));
             RUN(launch_upflow(flow_lr_q4, 0, F(L.flow8[par]), 0, 1, h, w, 8, s));
         }
@@ -740,11 +743,34 @@ int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const
     if (rc) return rc;
     if (!lr || !fv || !mk || !out || (!first && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
-    if (first) R.reset_state();
-    if (!first) R.fnet(1, lr, 0, lr_prev, 0);
+    const bool use_side = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);
+    SideStream& ss = side_stream();
+    hipStream_t main_s = (hipStream_t)stream;
+    if (first || !use_side || !ss.ok || prof_enabled()) {
+        if (first) R.reset_state();
+        if (!first) R.fnet(1, lr, 0, lr_prev, 0);
+        R.encode_lr(1, lr, 0);
+        R.frame_pre(0, first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr));
+        R.frame(0, first != 0, mk, out, fg);
+        return R.rc;
+    }
+    // two streams: FNet (one pair, small launch-latency-bound kernels, 0.45 ms) and the flow up-samplings stay on the
+    // caller's stream; encoder_lr, the fovea blend, encoder_hr and the upsample conv run beside them on the side stream.
+    // The caller's kernels are enqueued first (enqueue order across streams matters).
+    auto fail = [&](const char* what) { set_error("dsv_stream_frame: %s failed", what); return 1; };
+    hipEvent_t ev_start = ss.event(0), ev_side = ss.event(1);
+    if (!ss.ok) return fail("hipEventCreate");
+    if (hipEventRecord(ev_start, main_s) != hipSuccess) return fail("record");
+    R.fnet(1, lr, 0, lr_prev, 0);
+    R.frame_pre(0, false, lr, fv, mk, R.F(L.flow_lr), R.F(L.x_lr), nullptr, 2);
+    R.s = ss.s;
+    if (hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
     R.encode_lr(1, lr, 0);
-    R.frame_pre(0, first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr));
-    R.frame(0, first != 0, mk, out, fg);
+    R.frame_pre(0, false, lr, fv, mk, nullptr, R.F(L.x_lr), nullptr, 1);
+    if (hipEventRecord(ev_side, ss.s) != hipSuccess) return fail("record");
+    R.s = main_s;
+    if (hipStreamWaitEvent(main_s, ev_side, 0) != hipSuccess) return fail("join");
+    R.frame(0, false, mk, out, fg);
     return R.rc;
 }
 
