@@ -19,6 +19,13 @@ namespace crfp {
 //   g = x + flow_x;  gn = 2*g/max(W-1,1) - 1          (model/CRFP.py:118-121)
 //   ix = (gn + 1) * ((W-1)/2)                         (ATen CPU grid_sampler, align_corners=True)
 // zeros padding: each out-of-range corner contributes 0; border: ix clamped to [0, W-1].
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// flow vectors are read once per launch: non-temporal (the gathered planes keep the cache)
+__device__ __forceinline__ float2 ldnt2(const float* p) {
+    const f32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_t*>(p));
+    return make_float2(v.x, v.y);
+}
+
 template <int BORDER>
 __global__ __launch_bounds__(256) void flow_warp_q4_kernel(const float* __restrict__ x, long long xb,
                                                            const float* __restrict__ flow, long long fb,
@@ -29,7 +36,7 @@ __global__ __launch_bounds__(256) void flow_warp_q4_kernel(const float* __restri
     const int n = blockIdx.z;
     if (px >= W || py >= H) return;
     const long long pix = (long long)py * W + px;
-    const float2 f = *reinterpret_cast<const float2*>(flow + (long long)n * fb + pix * 2);
+    const float2 f = ldnt2(flow + (long long)n * fb + pix * 2);
     const float dw = (float)(W - 1 > 1 ? W - 1 : 1), dh = (float)(H - 1 > 1 ? H - 1 : 1);
     const float gx = 2.0f * ((float)px + f.x) / dw - 1.0f;
     const float gy = 2.0f * ((float)py + f.y) / dh - 1.0f;
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restri
     const int n = blockIdx.z;
     if (px >= W || py >= H) return;
     const long long pix = (long long)py * W + px;
-    const float2 f = *reinterpret_cast<const float2*>(flow + (long long)n * fb + pix * 2);
+    const float2 f = ldnt2(flow + (long long)n * fb + pix * 2);
     const float dw = (float)(W - 1 > 1 ? W - 1 : 1), dh = (float)(H - 1 > 1 ? H - 1 : 1);
     const float gx = 2.0f * ((float)px + f.x) / dw - 1.0f;
     const float gy = 2.0f * ((float)py + f.y) / dh - 1.0f;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void flow_warp_p4_dual_kernel(const float* __r
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
     const long long pix = (long long)py * W + px;
-    const float2 f = *reinterpret_cast<const float2*>(flow + pix * 2);
+    const float2 f = ldnt2(flow + pix * 2);
     const float dw = (float)(W - 1 > 1 ? W - 1 : 1), dh = (float)(H - 1 > 1 ? H - 1 : 1);
     const float gx = 2.0f * ((float)px + f.x) / dw - 1.0f;
     const float gy = 2.0f * ((float)py + f.y) / dh - 1.0f;
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
     const bool live = px < W && py < H;
     const int cpx = min(px, W - 1), cpy = min(py, H - 1);
     const long long pix = (long long)cpy * W + cpx;
-    const float4 om = *reinterpret_cast<const float4*>(offmask3 + (long long)n * omb + pix * 4);
+    const f32x4 om = ldg4(offmask3 + (long long)n * omb + pix * 4);   // read once: non-temporal
     const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
     const int guard = pitch + 16;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
