@@ -87,8 +87,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // check of a raw buffer load returns 0.  No per-corner validity logic and no 64-bit address math is
 // left on the VALU: one 32-bit byte offset per sample, the other three corners ride on the scalar
 // offset operand (+16, +pitch, +pitch+16).
+#ifndef CRFP_GATHER_AUX
+#define CRFP_GATHER_AUX 0   // cache-policy bits of the gather loads (gfx942+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CRFP_GATHER_AUX));
 }
 
 __global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restrict__ x, long long xb,
