@@ -1,6 +1,11 @@
-// 3x3 stride-1 pad-1 convolution as an implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32),
-// gfx950.  Replaces every "wide" nn.Conv2d(k=3) of the reference path (model/CRFP.py:303-317,
-// 449-450, 532, 172-176, 257-261, 747-795; model/LTE.py:40-42).
+// 3x3 stride-1 pad-1 convolution as an implicit GEMM on the MFMA, gfx950.  Replaces every "wide" nn.Conv2d(k=3) of
+// the reference path (model/CRFP.py:303-317, 449-450, 532, 172-176, 257-261, 747-795; model/LTE.py:40-42).
+//
+// File map: shared epilogue (conv_epilogue_t) | fp32-MFMA kernel conv3x3_mfma_kernel (v_mfma_f32_32x32x2_f32: the per-op
+// C-ABI and the few convs with NCHW / ragged-K sources) | the split-operand kernels on the 16-bit MFMA: the DEFAULT
+// conv3x3_split_kernel<1,1,2> (f16x3; bf16x6 as <.,.,3>), and the opt-in experiments (pipelined
+// persistent, input-stationary, warp-specialised) | weight packers | launch_conv_mfma.
+// The layout notes below are written for the fp32 kernel; the split kernels share orientation, lane map and epilogue.
 //
 // GEMM orientation:  D[cout][pixel] += A[cout][k] * B[k][pixel]
 //   A = weights (rows = 32 output channels of a cout tile), pre-packed so that the 64 lanes of a
