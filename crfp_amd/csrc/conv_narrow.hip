@@ -36,8 +36,9 @@ __device__ __forceinline__ float n_act(float v, int act) {
 
 // Workgroup = 256 threads walks a strided list of 64 x 16 output tiles (persistent).  Per tile the (16+2) x (64+2)
 // halo of every input quad goes global -> registers -> LDS (coalesced 16-B loads); thread (tx, ty) then produces the 4
-// vertically adjacent pixels (tx, 4*ty .. 4*ty+3): 18 ds_read_b128 per input quad feed 4 x 9 x 16 FMAs; the weights sit
-// in LDS too (broadcast reads).  The loads of tile t+1 are issued right after tile t reached LDS, so they fly during
+// vertically adjacent pixels (tx, 4*ty .. 4*ty+3): 18 halo + 9 weight ds_read_b128 per input quad feed 4 x 9 x 4 fp32
+// MFMAs (v_mfma_f32_4x4x1: the four couts of a pixel per instruction; CRFP_NARROW_MFMA=0 builds the v_fma_f32 form with
+// broadcast weight reads).  The loads of tile t+1 are issued right after tile t reached LDS, so they fly during
 // the FMAs and stores of tile t: the one-tile-per-workgroup version spent 7.7-12 k cycles per tile waiting for its
 // loads and 4 k in an epilogue that re-read its arguments (s_memtime stamps), i.e. HBM idled while it computed.
 #ifndef CRFP_NARROW_KY_UNROLL
