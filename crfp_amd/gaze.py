@@ -89,9 +89,10 @@ def run_gaze_video(model, lr: torch.Tensor, gt: torch.Tensor, sigma: float, fv_s
     """Stream `lr [N,3,h,w]` / `gt [N,3,8h,8w]` (device tensors, range [0,1]) through `model` (MRCF_simple_v18 interface:
     ``model(lrs=, fvs=, mks=, fgs=)`` one frame per call, ``clear_states()``) along a gaussian gaze trajectory and collect
     the rig's region metrics.  Returns per-region mean PSNR / SSIM, the trajectory and the outputs' checksum."""
+    regions_fn = None
     if metric_fn is None:
         from . import utils as U
-        metric_fn = U.calc_psnr_and_ssim_cuda
+        metric_fn, regions_fn = U.calc_psnr_and_ssim_cuda, U.calc_psnr_and_ssim_regions
     N, _, H, W = gt.shape
     xs, ys = gaze_trajectory(N, H, W, sigma, np.random.RandomState(seed))
     masks = RegionMasks(H, W, fv_size, gt.device, fv_start, regional_dcn, rg, rg)
@@ -109,11 +110,15 @@ def run_gaze_video(model, lr: torch.Tensor, gt: torch.Tensor, sigma: float, fv_s
             fv = g * m["mk"]
             sr = model(lrs=lr[n:n + 1].unsqueeze(0), fvs=fv.unsqueeze(0), mks=m["mk"].unsqueeze(0), fgs=m["fg"].unsqueeze(0))
             sr = sr.reshape(1, -1, H, W)
-            for r, mask in (("whole", ones), ("fovea", m["fovea"]), ("outskirt", m["outskirt"]), ("past", m["past"])):
-                if mask is None:
-                    continue   # frame 0 has no past ring
-                p, s = metric_fn(sr, g, mask)
-                acc[r].append((float(p), float(s)))
+            todo = [(r, mask) for r, mask in (("whole", ones), ("fovea", m["fovea"]), ("outskirt", m["outskirt"]),
+                                              ("past", m["past"])) if mask is not None]   # frame 0 has no past ring
+            if regions_fn is not None:   # one range probe and one host sync per frame
+                for (r, _), (p, s) in zip(todo, regions_fn(sr, g, [mask for _, mask in todo])):
+                    acc[r].append((float(p), float(s)))
+            else:
+                for r, mask in todo:
+                    p, s = metric_fn(sr, g, mask)
+                    acc[r].append((float(p), float(s)))
     out: Dict[str, object] = {"trajectory": traj, "frames": N}
     for r in regions:
         if acc[r]:

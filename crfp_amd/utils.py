@@ -72,6 +72,20 @@ def calc_psnr_and_ssim_cuda(sr, hr, mask, is_tensor=True, batch_avg=False):
     return torch.tensor(_psnr_from(se, ms, tuple(sr.shape))), torch.tensor(ss / (ms * sr.shape[1]))
 
 
+def calc_psnr_and_ssim_regions(sr, hr, masks):
+    """calc_psnr_and_ssim_cuda(sr, hr, m) for every mask m of one frame (the video rig's whole / fovea / outskirt / past
+    regions, test_video.py:360-370) with ONE range probe and ONE host synchronisation instead of one per region; same
+    kernel, same numbers.  Returns a list of (psnr, ssim) tensors."""
+    sr, hr = _dev(sr, "sr"), _dev(hr, "hr")
+    span = float(hr.max() - hr.min())
+    mul, add = (1.0 / 255.0, 0.0) if span > 2 else ((0.5, 0.5) if span > 1 else (1.0, 0.0))
+    sums = torch.stack([psnr_ssim_sums(sr, hr, m, mul, add).clone() for m in masks]).cpu()
+    out = []
+    for se, ss, ms in sums.tolist():
+        out.append((torch.tensor(_psnr_from(se, ms, tuple(sr.shape))), torch.tensor(ss / (ms * sr.shape[1]))))
+    return out
+
+
 def bgr2ycbcr(img, y_only=False):
     """utils.bgr2ycbcr on an [N,H,W,3] tensor (BGR weights applied to whatever channel order arrives, as the
     reference does, trainer.py:362-363)."""
