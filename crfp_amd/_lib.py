@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRFP_HIP_LIB") or os.path.join(_HERE, "libcrfp_hip.so")
 
 NUM_PARAMS = 118
+DSV_Y_ONLY, DSV_STRICT_F32 = 1, 2   # flags of crfp_dsv_forward_clip / crfp_dsv_stream_frame
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -23,6 +24,7 @@ class ProfRecord(C.Structure):
 SIGNATURES = {
     "crfp_version": (C.c_int, []),
     "crfp_last_error_string": (C.c_char_p, []),
+    "crfp_shutdown": (C.c_int, []),
     "crfp_flow_warp_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "crfp_flow_warp_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_dcnv2_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
@@ -40,6 +42,7 @@ SIGNATURES = {
     "crfp_dsv_packed_weight_bytes": (C.c_size_t, [C.c_int]),
     "crfp_dsv_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_dsv_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "crfp_dsv_status_offset": (C.c_size_t, [C.c_int] * 3),
     "crfp_dsv_forward_clip": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 +
                               [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_dsv_stream_frame": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 3 +

@@ -177,6 +177,7 @@ struct EpiCtx {
     const float4* bp;
     const float* rp;
     const float* flp;
+    unsigned* ovf;       // fp16-operand overflow word (null: not tracked)
     float* s3p;          // SRC_S3 image of the output (null: none)
     int s3_ngroups;      // cout / 8
     float* dp[CRFP_MAX_DST];
@@ -209,6 +210,7 @@ __device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
     }
     e.single = a.ndst == 1 && a.dst[0].q0 == 0 && a.dst[0].q1 >= e.ncq;
     e.dbg = a.stamps;
+    e.ovf = a.ovf;
     return e;
 }
 
@@ -235,6 +237,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
 #ifdef CRFP_EPI_DBG
     long long d0 = __builtin_amdgcn_s_memtime(), d1 = 0;
 #endif
+    float vmax = 0.0f;   // largest |value| this lane stores (fp16-operand range guard, see ConvArgs::ovf)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
 #ifdef CRFP_EPI_DBG
@@ -286,6 +289,8 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                         if (4 * cq + c >= e.cout) v[c] = 0.0f;
                 }
                 if (e.rp) { v[0] += rr[ct][g].x; v[1] += rr[ct][g].y; v[2] += rr[ct][g].z; v[3] += rr[ct][g].w; }
+                if (STORE != ST_OFFMASK && STORE != ST_NCHW)   // those outputs never feed an fp16 operand
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 // store addresses = per-lane pixel offset (one 32-bit multiply per pixel tile) + wave-uniform 64-bit
                 // part per quad: the per-lane 64-bit multiplies of the first version were most of the epilogue's 6 k cycles
                 if (STORE == ST_Q4 && e.s3p) {   // SRC_S3 image: this lane's 4 channels are half h of the 8-channel element
@@ -327,6 +332,9 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                 }
             }
     }
+    // a stored value that the next split-fp16 conv could not represent (>= 65504, inf): raise the sticky word; the output
+    // head then poisons the frame with NaN instead of returning plausible garbage
+    if (e.ovf && !(vmax < 65504.0f)) atomicOr(e.ovf, 1u);
 #ifdef CRFP_EPI_DBG
     if (e.dbg && threadIdx.x == 0) {
         long long* o = e.dbg + (16384 + (long long)blockIdx.x) * 8;
@@ -637,7 +645,9 @@ __device__ __forceinline__ void load_quad_batch_v(f32x4 (&r)[NIN], const ConvSrc
 
 template <int CT, int RPW, int NP>
 __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void conv3x3_split_kernel(const ConvArgs a) {
+#ifdef CRFP_LAB
     const long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
     constexpr int NEL = LH * LW;                 // halo pixels
     constexpr int NIN = (NEL + 255) / 256;       // halo pixels per thread; each carries the chunk's 4 quads
@@ -728,16 +738,20 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
         }                                                                                                 \
     }
 
+#ifdef CRFP_LAB
     long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
+#endif
     CRFP_SPLIT_ISSUE(0)
     for (int ch = 0; ch < nchunks; ++ch) {
         const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;  // component masks of the chunk now in registers
         __syncthreads();  // every wave finished reading the previous chunk
+#ifdef CRFP_LAB
         if (a.stamps) {
             long long t = __builtin_amdgcn_s_memtime(); tA += t - t0; t0 = t;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             t = __builtin_amdgcn_s_memtime(); tC += t - t0; t0 = t;   // diagnostic: load-landing wait booked under C
         }
+#endif
         if (NP == 2 && (m0 & 16)) {   // SRC_S3 chunk (wave-uniform): the producer already split it -- copy, zero outside the image
 #pragma unroll
             for (int t = 0; t < NIN; ++t) {
@@ -785,9 +799,13 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
             if (idx < CT * WPC) (&wlds[0][0])[idx] = rws[k];
         }
         __syncthreads();
+#ifdef CRFP_LAB
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
+#endif
         if (ch + 1 < nchunks) CRFP_SPLIT_ISSUE(ch + 1)
+#ifdef CRFP_LAB
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }  // diagnostic: issue booked under D
+#endif
 #pragma unroll CRFP_SPLIT_TAP_UNROLL
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
@@ -806,10 +824,13 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
                 for (int ct = 0; ct < CT; ++ct) split_mfma<NP>(acc[ct][pt], acl[ct][pt], wa[ct], bq);
             }
         }
+#ifdef CRFP_LAB
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }
+#endif
     }
 #undef CRFP_SPLIT_ISSUE
 #undef CRFP_QDESC
+#ifdef CRFP_LAB
     if (a.stamps) {
         const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t;
         if (tid == 0) {
@@ -817,6 +838,7 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
             o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD; o[4] = t_entry; o[5] = t;
         }
     }
+#endif
     if (NP == 2) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -825,11 +847,16 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[ct][pt][e] += acl[ct][pt][e] * (1.0f / F16_RES_SCALE);
     }
+#ifdef CRFP_LAB
     long long te1 = 0, te2 = 0;
     if (a.stamps) { asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[0][PT - 1][15])); te1 = __builtin_amdgcn_s_memtime(); }
+#endif
     const EpiCtx ec = epi_ctx(a, n);
+#ifdef CRFP_LAB
     if (a.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(ec.dpitch[0]), "s"(ec.ncq), "s"(ec.slope)); te2 = __builtin_amdgcn_s_memtime(); }
+#endif
     conv_epilogue<CT, PT, RPW, 2>(ec, acc, T0, tx0, ty0, wave, j, h);
+#ifdef CRFP_LAB
     if (a.stamps) {
         const long long ti = __builtin_amdgcn_s_memtime();      // epilogue issued (stores in flight)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -840,8 +867,10 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
             a.stamps[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memtime();
         }
     }
+#endif
 }
 
+#ifdef CRFP_LAB   // experiments that lose to conv3x3_split_kernel<1,1,2>: built only into the lab library (make lab)
 // ---------------------------------------------------------------- software-pipelined persistent variant (f16x3)
 // One 512-thread workgroup per CU (two waves per SIMD) walks a strided list of 8x64 output tiles; wave = one output
 // row (two 32-pixel MFMA column tiles).  The work is a stream of items (tile, K-chunk).  LDS holds TWO items (halo tile
@@ -1377,6 +1406,8 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
     if (!IS) conv_epilogue<1, 2, 1, 0>(ec, acc, T0, tx0, ty0, wave, j, h, flpre);
 }
 
+#endif  // CRFP_LAB
+
 // split weight pack: wsplit bf16 index =
 //   (((((T*nchunks + ch)*9 + tap)*3 + part)*64 + lane)*8 + jj),  lane = half*32 + row,
 //   K-quad = 4*ch + 2*half + (jj>>2), component = jj&3
@@ -1421,17 +1452,24 @@ __global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict
     }
 }
 
-// bf16 triple image followed by the fp16 pair image
+// product build: the fp16 pair image only; lab build: bf16 triple image followed by the fp16 pair image
+#ifdef CRFP_LAB
 size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * (3 + 2) * 64 * 16; }
 size_t conv_split16_offset_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 3 * 64 * 16; }
+#else
+size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 2 * 64 * 16; }
+size_t conv_split16_offset_bytes(const ConvArgs&) { return 0; }
+#endif
 
 int launch_conv_pack_split(const ConvArgs& a, const float* w, const float* w2, int cout_split, void* wsplit,
                            hipStream_t s) {
     if (a.kq & 3) { set_error("conv_pack_split: kq %d not a multiple of 4", a.kq); return CRFP_E_BADARG; }
     const long long total = (long long)a.ctiles * (a.kq >> 2) * 9 * 64 * 8;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+#ifdef CRFP_LAB
     conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout, (unsigned short*)wsplit, 3);
     CRFP_CHECK_LAUNCH();
+#endif
     conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout,
                                                   (unsigned short*)((char*)wsplit + conv_split16_offset_bytes(a)), 2);
     CRFP_CHECK_LAUNCH();
@@ -1485,15 +1523,31 @@ int launch_conv_pack(const ConvArgs& a, const float* w, const float* bias, const
     return 0;
 }
 
+// Precision of the engine's wide convolutions and of dcn_g8's GEMM.  Default: the split-fp16 scheme (fp32-grade, needs
+// |operand| < 65504, guarded by the overflow word, see ConvArgs::ovf).  Strict: plain fp32 MFMA everywhere -- selected per
+// call through ConvArgs::strict (CRFP_DSV_STRICT_F32 of the C-ABI) or for the whole process with CRFP_PRECISION=f32
+// (read once; CRFP_CONV_MODE=f32 / CRFP_DCN_MODE=f32 of round 1 still work).
+bool precision_env_strict(const char* legacy_knob) {
+    const char* p = getenv("CRFP_PRECISION");
+    if (p && !strcmp(p, "f32")) return true;
+    const char* l = getenv(legacy_knob);
+    return l && !strcmp(l, "f32");
+}
+
+#ifdef CRFP_LAB
+static const char* lab_conv_mode() { static const char* m = getenv("CRFP_CONV_MODE"); return m ? m : "f16x3"; }
+static int lab_knob(const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; }
+#endif
+
 // SRC_S3 sources / s3_dst are understood by conv3x3_split_kernel<1,1,2> (the default) only
 bool conv_s3_supported() {
     static const bool ok = [] {
-        auto on = [](const char* k) { return getenv(k) && atoi(getenv(k)) != 0; };
-        if (getenv("CRFP_CONV_MODE") && strcmp(getenv("CRFP_CONV_MODE"), "f16x3")) return false;
-        if (on("CRFP_SPLIT_WS") || on("CRFP_SPLIT_IS") || on("CRFP_SPLIT_PIPE")) return false;
-        if (getenv("CRFP_SPLIT_RPW") && atoi(getenv("CRFP_SPLIT_RPW")) != 1) return false;
-        if (getenv("CRFP_SPLIT_CT") && atoi(getenv("CRFP_SPLIT_CT")) != 1) return false;
-        if (getenv("CRFP_CONV_S3") && atoi(getenv("CRFP_CONV_S3")) == 0) return false;   // A/B knob
+        if (precision_env_strict("CRFP_CONV_MODE")) return false;
+#ifdef CRFP_LAB
+        if (strcmp(lab_conv_mode(), "f16x3")) return false;
+        if (lab_knob("CRFP_SPLIT_WS", 0) || lab_knob("CRFP_SPLIT_IS", 0) || lab_knob("CRFP_SPLIT_PIPE", 0)) return false;
+        if (lab_knob("CRFP_SPLIT_RPW", 1) != 1 || lab_knob("CRFP_SPLIT_CT", 1) != 1 || !lab_knob("CRFP_CONV_S3", 1)) return false;
+#endif
         return true;
     }();
     return ok;
@@ -1504,27 +1558,30 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         set_error("conv_mfma %s: bad plan (kq=%d ctiles=%d nsrc=%d)", name, a.kq, a.ctiles, a.nsrc);
         return CRFP_E_BADARG;
     }
-    if (a.store == ST_PS && (a.ps_r != 2 && a.ps_r != 4 || a.act == CRFP_ACT_TANH || a.act == CRFP_ACT_SIGMOID)) {
+    if (a.store == ST_PS && ((a.ps_r != 2 && a.ps_r != 4) || a.act == CRFP_ACT_TANH || a.act == CRFP_ACT_SIGMOID)) {
         set_error("conv_mfma %s: pixel-shuffle store supports r in {2, 4} with none/relu/lrelu (r=%d act=%d)", name, a.ps_r, a.act);
         return CRFP_E_UNSUPPORTED;
     }
-    static const int max_ct = getenv("CRFP_CONV_CT") ? atoi(getenv("CRFP_CONV_CT")) : 2;  // tuning knob
-    bool ct2 = a.ctiles % 2 == 0 && max_ct >= 2;
-    // CRFP_CONV_MODE: f16x3 (default) | bf16x6 | f32 -- all three are fp32-grade (see the scheme comments above)
-    static const bool use_split = !(getenv("CRFP_CONV_MODE") && !strcmp(getenv("CRFP_CONV_MODE"), "f32"));
-    static const bool use_f16 = !(getenv("CRFP_CONV_MODE") && !strcmp(getenv("CRFP_CONV_MODE"), "bf16x6"));
-    static const int split_rpw = getenv("CRFP_SPLIT_RPW") ? atoi(getenv("CRFP_SPLIT_RPW")) : 1;  // tuning knob
-    bool nchw_src = false;
-    for (int i = 0; i < a.nsrc; ++i) nchw_src |= a.src[i].kind == SRC_NCHW;
+    static const bool env_strict = precision_env_strict("CRFP_CONV_MODE");
+    const bool use_split = !(env_strict || a.strict);
+    bool ct2 = a.ctiles % 2 == 0;
+    bool nchw_src = false, s3_src = false;
+    for (int i = 0; i < a.nsrc; ++i) { nchw_src |= a.src[i].kind == SRC_NCHW; s3_src |= a.src[i].kind == SRC_S3; }
     const bool split = a.wsplit && use_split && (a.kq & 3) == 0 && !nchw_src && a.kq <= CRFP_MAX_KQ;
-    bool uses_s3 = a.s3_dst != nullptr;
-    for (int i = 0; i < a.nsrc; ++i) uses_s3 |= a.src[i].kind == SRC_S3;
+    const bool uses_s3 = a.s3_dst != nullptr || s3_src;
     if (uses_s3 && (!split || !conv_s3_supported() || (a.s3_dst && (a.store != ST_Q4 || (a.cout & 7))))) {
         set_error("conv_mfma %s: SRC_S3 / s3_dst need the default f16x3 kernel, ST_Q4 and cout %% 8 == 0", name);
         return CRFP_E_UNSUPPORTED;
     }
-    static const int split_ct = getenv("CRFP_SPLIT_CT") ? atoi(getenv("CRFP_SPLIT_CT")) : 1;  // tuning knob
-    if (split && split_ct < 2) ct2 = false;  // <2,1> needs 93 KB of LDS (1 workgroup per CU): slower than 2 x <1,1>
+    int split_rpw = 1;
+#ifdef CRFP_LAB
+    split_rpw = lab_knob("CRFP_SPLIT_RPW", 1);
+    const int split_ct = lab_knob("CRFP_SPLIT_CT", 1);
+    if (lab_knob("CRFP_CONV_CT", 2) < 2) ct2 = false;
+    if (split && split_ct < 2) ct2 = false;
+#else
+    if (split) ct2 = false;  // <2,1> needs 93 KB of LDS (1 workgroup per CU): slower than 2 x <1,1>
+#endif
     const int TH = (ct2 || (split && split_rpw == 1)) ? 4 : 8;
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     const double px = (double)a.N * a.H * a.W;
@@ -1532,12 +1589,16 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].kind == SRC_ZERO ? 0 : a.src[i].nch;
     ProfScope prof(name, s, px * (in_ch + a.cout) * 4.0 + (double)a.cout * in_ch * 9 * 4.0,
                    2.0 * px * a.cout * in_ch * 9.0);
+    ConvArgs& am = const_cast<ConvArgs&>(a);  // callers pass a private, mutable plan copy
+    am.stamps = nullptr;
+#ifdef CRFP_LAB
     // diagnostic: CRFP_STAMP_PTR=<device address> CRFP_STAMP_NAME=<launch site> records phase cycles per block
     static const char* stamp_name = getenv("CRFP_STAMP_NAME");
     static long long* stamp_ptr = getenv("CRFP_STAMP_PTR") ? (long long*)strtoull(getenv("CRFP_STAMP_PTR"), nullptr, 0) : nullptr;
-    ConvArgs& am = const_cast<ConvArgs&>(a);  // callers pass a private, mutable plan copy
     am.stamps = (stamp_ptr && stamp_name && !strcmp(stamp_name, name)) ? stamp_ptr : nullptr;
-    am.wsplit16 = a.wsplit ? (const char*)a.wsplit + conv_split16_offset_bytes(a) : nullptr;   // fp16 pair image follows the bf16 triple
+#endif
+    am.wsplit16 = a.wsplit ? (const char*)a.wsplit + conv_split16_offset_bytes(a) : nullptr;
+    if (env_strict || a.strict) am.ovf = nullptr;   // nothing downstream turns this output into an fp16 operand
     if (a.kq <= CRFP_MAX_KQ) {  // per-quad load descriptors (wave-uniform in the kernel: one s_load per quad)
         int q = 0;
         for (int i = 0; i < a.nsrc; ++i)
@@ -1568,14 +1629,16 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
                 }
             }
     }
+#ifdef CRFP_LAB
+    const bool use_f16 = strcmp(lab_conv_mode(), "bf16x6") != 0;
     // warp-specialised variant: measured 346 vs 351.5 frames/s for the single-role kernels (loader issue is
     // throttled by the ~12 B/clk/CU the memory system delivers) -> kept as an opt-in experiment
-    static const bool use_ws = getenv("CRFP_SPLIT_WS") && atoi(getenv("CRFP_SPLIT_WS")) == 1;
+    const bool use_ws = lab_knob("CRFP_SPLIT_WS", 0) == 1;
     // input-stationary variant: wins for bf16x6 (65 KB workgroups, 2 per CU); with f16x3 the plain kernel runs 3 workgroups
     // per CU and is faster even for the 216-channel conv (139.8 vs 147.6 us), so it is opt-in there
-    static const bool use_is = getenv("CRFP_SPLIT_IS") ? atoi(getenv("CRFP_SPLIT_IS")) != 0 : !use_f16;
-    static const bool use_pipe = getenv("CRFP_SPLIT_PIPE") && atoi(getenv("CRFP_SPLIT_PIPE")) == 1;
-    static const int pipe_wgs = getenv("CRFP_PIPE_WGS") ? atoi(getenv("CRFP_PIPE_WGS")) : 256;
+    const bool use_is = lab_knob("CRFP_SPLIT_IS", use_f16 ? 0 : 1) != 0;
+    const bool use_pipe = lab_knob("CRFP_SPLIT_PIPE", 0) == 1;
+    const int pipe_wgs = lab_knob("CRFP_PIPE_WGS", 256);
     if (split && use_ws) {
         const int wtiles = ((a.W + TW - 1) / TW) * ((a.H + WS_TH - 1) / WS_TH);
         if (use_is && a.kq <= 8 && a.ctiles >= 2) {
@@ -1583,10 +1646,13 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         } else {
             conv3x3_split_ws_kernel<false><<<dim3(wtiles, a.ctiles, a.N), WS_NT, 0, s>>>(a);
         }
-    } else if (split && use_is && a.kq <= 8 && a.ctiles >= 2) {
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
+    if (split && use_is && a.kq <= 8 && a.ctiles >= 2) {
         // input-stationary: whole K in LDS, one workgroup per 4x64 tile walks every cout tile
         dim3 grid(((a.W + TW - 1) / TW) * ((a.H + 7) / 8), 1, a.N);
-        static const int is_waves = getenv("CRFP_IS_WAVES") ? atoi(getenv("CRFP_IS_WAVES")) : 8;   // tuning knob
+        const int is_waves = lab_knob("CRFP_IS_WAVES", 8);
         if (use_f16 && is_waves == 4) {
             dim3 grid4(((a.W + TW - 1) / TW) * ((a.H + 3) / 4), 1, a.N);
             if (a.kq == 4) conv3x3_split_is_kernel<1, 4, 2><<<grid4, 256, 0, s>>>(am);
@@ -1598,33 +1664,40 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
             if (a.kq == 4) conv3x3_split_is_kernel<1, 8, 3><<<grid, 512, 0, s>>>(am);
             else conv3x3_split_is_kernel<2, 8, 3><<<grid, 512, 0, s>>>(am);
         }
-    } else if (split && use_pipe) {
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
+    if (split && use_pipe) {
         // persistent: one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
         const int ntl = ((a.W + TW - 1) / TW) * ((a.H + PIPE_NW - 1) / PIPE_NW);
         const int per = (ntl + pipe_wgs - 1) / pipe_wgs;           // tiles per workgroup
         dim3 grid((ntl + per - 1) / per, a.ctiles, a.N);           // balanced shares
         conv3x3_split_pipe_kernel<<<grid, PIPE_NT, 0, s>>>(a);
-    } else if (split) {
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
+    if (split && (ct2 || split_rpw != 1 || !use_f16)) {
         if (ct2) {
             dim3 grid(tiles * (a.ctiles / 2), 1, a.N);
             if (use_f16) conv3x3_split_kernel<2, 1, 2><<<grid, 256, 0, s>>>(am);
             else conv3x3_split_kernel<2, 1, 3><<<grid, 256, 0, s>>>(am);
         } else if (split_rpw == 1) {
-            dim3 grid(tiles * a.ctiles, 1, a.N);
-            static const int dyn_lds = getenv("CRFP_SPLIT_DYNLDS") ? atoi(getenv("CRFP_SPLIT_DYNLDS")) : 0;  // occupancy experiment
-            if (use_f16) conv3x3_split_kernel<1, 1, 2><<<grid, 256, dyn_lds, s>>>(am);
-            else conv3x3_split_kernel<1, 1, 3><<<grid, 256, 0, s>>>(am);
+            conv3x3_split_kernel<1, 1, 3><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
         } else {
             dim3 grid(tiles * a.ctiles, 1, a.N);
             if (use_f16) conv3x3_split_kernel<1, 2, 2><<<grid, 256, 0, s>>>(am);
             else conv3x3_split_kernel<1, 2, 3><<<grid, 256, 0, s>>>(am);
         }
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
+#endif
+    if (split) {
+        conv3x3_split_kernel<1, 1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
     } else if (ct2) {
-        dim3 grid(tiles * (a.ctiles / 2), 1, a.N);
-        conv3x3_mfma_kernel<2, 1><<<grid, 256, 0, s>>>(a);
+        conv3x3_mfma_kernel<2, 1><<<dim3(tiles * (a.ctiles / 2), 1, a.N), 256, 0, s>>>(a);
     } else {
-        dim3 grid(tiles * a.ctiles, 1, a.N);
-        conv3x3_mfma_kernel<1, 2><<<grid, 256, 0, s>>>(a);
+        conv3x3_mfma_kernel<1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(a);
     }
     CRFP_CHECK_LAUNCH();
     return 0;

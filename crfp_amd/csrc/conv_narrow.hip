@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     const float* const resid = a.resid ? a.resid + (long long)n * a.resid_bstride : nullptr;
     const uint8_t* const mask = EPI == NE_BLEND ? a.mask + (long long)n * a.mask_bstride : nullptr;
     const float* const basep = EPI == NE_LAST ? a.base + (long long)n * a.base_bstride : nullptr;
+    // fp16-operand range guard (ConvArgs::ovf): the output head turns the frame into NaN once the sticky word is set
+    const bool poison = EPI == NE_LAST && a.ovf && *a.ovf != 0;
+    float vmax = 0.0f;
     const float* const flowp = EPI == NE_OFFMASK3 ? a.flow + (long long)n * a.flow_bstride : nullptr;
     const bool y_only = a.y_only != 0;
 
@@ -231,16 +234,18 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                                   m ? acc[i][3] : centre.w};
 #pragma unroll
                     for (int o = 0; o < 4; ++o) v[o] = v[o] > 0.0f ? v[o] : 0.1f * v[o];
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));   // the state feeds a split-fp16 conv
                     *reinterpret_cast<float4*>(dst + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 } else if (EPI == NE_LAST) {
                     const float4 b = *reinterpret_cast<const float4*>(basep + pix * 4);
+                    const float bad = poison ? __builtin_nanf("") : 0.0f;
                     if (y_only) {
-                        dst[pix] = acc[i][0] + (0.299f * b.x + 0.587f * b.y + 0.114f * b.z);
+                        dst[pix] = acc[i][0] + (0.299f * b.x + 0.587f * b.y + 0.114f * b.z) + bad;
                     } else {
                         const long long plane = (long long)H * W;
-                        dst[pix] = acc[i][0] + b.x;
-                        dst[plane + pix] = acc[i][1] + b.y;
-                        dst[2 * plane + pix] = acc[i][2] + b.z;
+                        dst[pix] = acc[i][0] + b.x + bad;
+                        dst[plane + pix] = acc[i][1] + b.y + bad;
+                        dst[2 * plane + pix] = acc[i][2] + b.z + bad;
                     }
                 } else {  // NE_OFFMASK3
                     const float2 f = *reinterpret_cast<const float2*>(flowp + pix * 2);
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                 }
             }
         }
+        if (EPI == NE_BLEND && a.ovf && !(vmax < 65504.0f)) { atomicOr(a.ovf, 1u); vmax = 0.0f; }
         if (t_next >= band1) break;
         t_cur = t_next;
         // every wave is done reading the tile before it is overwritten.  LDS-only barrier: __syncthreads() would also
@@ -294,9 +300,12 @@ int launch_narrow_pack(const NarrowArgs& a, const float* w, const float* bias, c
 
 int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     NarrowArgs a = a_in;
+    a.stamps = nullptr;
+#ifdef CRFP_LAB
     static const char* stamp_name = getenv("CRFP_STAMP_NAME");
     static long long* stamp_ptr = getenv("CRFP_STAMP_PTR") ? (long long*)strtoull(getenv("CRFP_STAMP_PTR"), nullptr, 0) : nullptr;
     a.stamps = (stamp_ptr && stamp_name && !strcmp(stamp_name, name)) ? stamp_ptr : nullptr;
+#endif
     if (a.kq < 1 || a.kq > 3 || a.cout < 1 || a.cout > 4) {
         set_error("conv_narrow %s: unsupported kq=%d cout=%d", name, a.kq, a.cout);
         return CRFP_E_UNSUPPORTED;
@@ -313,7 +322,11 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
                    2.0 * px * in_ch * a.cout * 9.0);
     // persistent: a few workgroups per CU walk the tiles (ceil-balanced shares)
     const int ntl = ((a.W + NTW - 1) / NTW) * ((a.H + NTH - 1) / NTH);
+#ifdef CRFP_LAB
     static const int per_cu_env = getenv("CRFP_NARROW_WGS_PER_CU") ? atoi(getenv("CRFP_NARROW_WGS_PER_CU")) : 0;   // tuning knob
+#else
+    constexpr int per_cu_env = 0;
+#endif
     const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? CRFP_NARROW_OCC1 : (a.kq == 2 ? CRFP_NARROW_OCC2 : 2));
     const int share = (ntl + 256 * per_cu - 1) / (256 * per_cu);
     dim3 grid((ntl + share - 1) / share, 1, a.N);

@@ -93,9 +93,16 @@ struct ConvArgs {
     int dstH, dstW;
     float* s3_dst;      // ST_Q4 only: also (or, with ndst == 0, only) write the output as an SRC_S3 image (cout % 8 == 0)
     long long s3_bstride;
+    // fp16-operand range guard of the split-fp16 scheme: every kernel whose output can become an fp16 operand (split convs,
+    // dcn_g8, the state-producing stencil) ORs 1 into *ovf when it stores |v| >= 65504; the output head turns the frame into
+    // NaN when the word is set (sticky per clip / stream).  Null: not tracked (per-op API, strict fp32).
+    unsigned* ovf;
+    int strict;         // 1: plain fp32 MFMA for this launch (CRFP_DSV_STRICT_F32)
+    int rsv2;
 };
 
 bool conv_s3_supported();   // the selected conv kernels consume SRC_S3 sources (default f16x3 path only)
+bool precision_env_strict(const char* legacy_knob);   // CRFP_PRECISION=f32 (or the round-1 knob) in the environment
 
 // packed row (0..ctiles*32) -> reference output channel, or -1 (padding)
 __host__ __device__ inline int conv_row_to_cout(int row, int cout, int store, int ps_r) {
@@ -174,6 +181,7 @@ struct NarrowArgs {
     float post_scale;
     int dst_pad, rsv;
     long long* stamps;  // diagnostic builds (-DCRFP_NARROW_STAMPS) only
+    unsigned* ovf;      // fp16-operand range guard (see ConvArgs::ovf): NE_BLEND raises it, NE_LAST poisons the frame when set
 };
 
 // Activations of the offset/mask heads (DCN modules, model/CRFP.py:338-340): hardware exp2/rcp, ~1 ulp each.
@@ -238,7 +246,8 @@ int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* 
 int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
                         int N, int nq, int H, int W, int border, int src_pad, hipStream_t s);
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
-                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16 = false);
+                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16 = false,
+                  unsigned* ovf = nullptr);
 int launch_dcn_g8_pack(const float* w_oihw, float* wpk, hipStream_t s, bool f16 = false);  // fp32 [36][2][32][4] or split-fp16 image
 bool dcn_g8_use_f16();   // engine: split-fp16 DCN GEMM unless CRFP_DCN_MODE=f32
 int launch_dcn3(const float* x, long long xb, const float* offmask3, long long omb, const float* w_oihw,

@@ -207,7 +207,7 @@ struct Model {
             dw.type = T_DCN8;
             dw.name = "dcn_g8_weights";
             dw.w1 = ci_dcn(l, 5);
-            dw.n_w = 36 * 2 * 32 * 4;
+            dw.n_w = 2 * 36 * 2 * 32 * 4;   // fp32 MFMA image (strict), then the split-fp16 image (default), 36 KB each
             dw.n_b = 32;
             // resblocks input = [prop(24) | carry(8)] | aligned(32)   (:1589); first frame: prop only (:1637)
             add_mfma(it_lvl(l, L_RB0), "conv_mfma:res.main0", ci_rb(l, 0), -1, {{Q, 24}, {Q, 8}, {Q, 32}}, ST_Q4, 0,
@@ -289,8 +289,8 @@ struct Q4 {
 struct Layout {
     Arena A;
     int t, h, w;
-    // persistent recurrent state first (stable offsets for streaming)
-    size_t state_hr, carry;
+    // status word (fp16-operand overflow flag), then the persistent recurrent state (stable offsets for streaming)
+    size_t status, state_hr, carry;
     // clip-level
     size_t flow_lr, e_lr0, x_lr;
     // FNet
@@ -304,6 +304,7 @@ struct Layout {
         const int nb = t > 1 ? t - 1 : 1;
         const int H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         h1 = h / 2; w1 = w / 2; h2 = h1 / 2; w2 = w1 / 2; h3 = h2 / 2; w3 = w2 / 2;
+        status = A.take("status", 1, 0, 1, 32, 1);   // 256 bytes; word 0 = overflow flag
         state_hr = A.take("state_hr", 1, 1, H8, W8, 0, 1);
         carry = A.take("carry", 1, 6, H2, W2, 0, 1);
         flow_lr = A.take("flow_lr", nb, 1, h, w);
@@ -373,9 +374,10 @@ struct Layout {
     size_t bytes() const { return A.cur; }
 };
 
-// One non-blocking side stream + an event pool per process: state-independent work of upcoming frames is
-// forked onto it (fork/join through events recorded on the caller's stream, so the call stays ordered
-// on `stream` and remains graph-capturable).
+// One non-blocking side stream + an event pool per (host thread, device): state-independent work of upcoming frames is
+// forked onto it (fork/join through events recorded on the caller's stream, so the call stays ordered on `stream` and
+// remains graph-capturable).  This is the ONLY state the library keeps between calls (documented in crfp_hip.h);
+// crfp_shutdown() destroys the calling thread's streams and events.
 struct SideStream {
     hipStream_t s = nullptr;
     std::vector<hipEvent_t> ev;
@@ -388,15 +390,28 @@ struct SideStream {
         }
         return ev[i];
     }
+    void destroy() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        if (s) (void)hipStreamDestroy(s);
+        s = nullptr;
+        ok = true;
+    }
 };
-// one per (host thread, device): streams and events belong to the device that was current when they were created
-static SideStream& side_stream() {
-    static thread_local SideStream per_dev[16];
+constexpr int kMaxDevices = 64;
+static thread_local SideStream g_side[kMaxDevices];
+// streams and events belong to the device that was current when they were created; a device index outside the table
+// gets no side stream (the caller then runs the single-stream schedule) instead of aliasing another device's slot
+static SideStream* side_stream() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    SideStream& ss = per_dev[dev];
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    SideStream& ss = g_side[dev];
     if (!ss.s && ss.ok && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
-    return ss;
+    return ss.ok ? &ss : nullptr;
+}
+static bool side_stream_enabled() {
+    static const bool on = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);   // read once
+    return on;
 }
 
 struct Runner {
@@ -406,7 +421,10 @@ struct Runner {
     const Layout& L;
     hipStream_t s;
     int rc = 0;
+    int strict = 0;     // CRFP_DSV_STRICT_F32: fp32 MFMA for every conv and for dcn_g8's GEMM
 
+    // null in strict mode: no kernel forms fp16 operands, the guard has nothing to watch (the word stays 0)
+    unsigned* ovf() const { return strict || !dcn_g8_use_f16() ? nullptr : reinterpret_cast<unsigned*>(ws + L.status); }
     float* F(size_t off) const { return reinterpret_cast<float*>(ws + off); }
     Q4 q(size_t off, int nq, int H, int W) const { Q4 r; r.p = F(off); r.nq = nq; r.H = H; r.W = W; return r; }
 
@@ -432,6 +450,8 @@ struct Runner {
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
         a.wsplit = packed + it.off_s;
+        a.ovf = ovf();
+        a.strict = strict;
         rc = launch_conv_mfma(a, it.name, s);
     }
     // plain Q4 -> Q4 conv on whole tensors
@@ -451,6 +471,7 @@ struct Runner {
         a.dst = dst; a.resid = resid; a.flow = flow; a.base = base; a.mask = mask;
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
+        a.ovf = ovf();
         rc = launch_narrow(a, it.name, s);
     }
 #define RUN(expr) do { if (!rc) rc = (expr); } while (0)
@@ -491,6 +512,7 @@ struct Runner {
 
     // zero the P4 buffers (pads must read as 0; also gives the zero initial state)
     void reset_state() {
+        if (!rc && hipMemsetAsync(ws + L.status, 0, 256, s) != hipSuccess) { set_error("dsv: hipMemsetAsync of the status word failed"); rc = 1; }
         for (size_t off : {L.state_hr, L.carry, L.prev2}) {
             const Buf* b = L.A.find(off);
             if (!rc && hipMemsetAsync(ws + off - b->guard, 0, b->bytes + b->guard, s) != hipSuccess) {
@@ -561,8 +583,9 @@ struct Runner {
                 }
                 mfma(it_lvl(l, L_OM), 1, H2, W2, {{f, 0}}, {{F(L.offmask), 0, 0, 54}}, 0, 0, nullptr, 0, flow2, 0);
                 const Item& dw = M.items[it_lvl(l, L_DCNW)];
-                RUN(launch_dcn_g8(F(L.prev2), 0, F(L.offmask), 0, packed + dw.off_w, packed + dw.off_b, F(L.aligned), 0,
-                                  1, H2, W2, s, dcn_g8_use_f16()));
+                const bool f16 = !strict && dcn_g8_use_f16();
+                RUN(launch_dcn_g8(F(L.prev2), 0, F(L.offmask), 0, packed + dw.off_w + (f16 ? 36 * 2 * 32 * 4 : 0), packed + dw.off_b,
+                                  F(L.aligned), 0, 1, H2, W2, s, f16, ovf()));
                 if (fg && l > 0) {  // model/CRFP_test.py:2361,2375: resblock input * fg (x0.25) for levels 1, 2
                     RUN(launch_scale_q4(prop, 0, F(L.sc_prop), 6, H2, W2, F(L.fg2), nullptr, s));
                     RUN(launch_scale_q4(cw, 0, F(L.sc_cw), 2, H2, W2, F(L.fg2), nullptr, s));
@@ -655,7 +678,8 @@ int crfp_dsv_pack_weights(const float* const* params, int y_only, void* packed, 
                 break;
             case T_NARROW: rc = launch_narrow_pack(it.nw, w, b, w2, b2, split, pk + it.off_w, pk + it.off_b, s); break;
             case T_DCN8:
-                rc = launch_dcn_g8_pack(w, pk + it.off_w, s, dcn_g8_use_f16());
+                rc = launch_dcn_g8_pack(w, pk + it.off_w, s, false);
+                if (!rc) rc = launch_dcn_g8_pack(w, pk + it.off_w + 36 * 2 * 32 * 4, s, true);
                 if (!rc && hipMemcpyAsync(pk + it.off_b, b, 32 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
                 break;
             default:
@@ -680,20 +704,26 @@ static int check_common(const void* packed, int t, int h, int w, void* ws, size_
     return 0;
 }
 
-int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, const float* fvs, const uint8_t* mks,
+size_t crfp_dsv_status_offset(int t, int h, int w) {
+    if (t < 1 || h < 8 || w < 8) return 0;
+    return Layout(t, h, w).status;
+}
+
+int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                           float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    const int y_only = flags & CRFP_DSV_Y_ONLY;
     Layout L(t, h, w);
     int rc = check_common(packed, t, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     if (!lrs || !fvs || !mks || !out) { set_error("dsv_forward_clip: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
     const long long lr_f = 3LL * h * w, hr_px = 64LL * h * w;
     const int co = y_only ? 1 : 3;
     const long long xq = 8LL * h * w * 4, fq = 1LL * h * w * 4;
-    const bool use_side = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);
-    SideStream& ss = side_stream();
+    SideStream* ssp = side_stream_enabled() && !prof_enabled() ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
-    if (!use_side || !ss.ok || prof_enabled()) {
+    if (!ssp) {
         // single-stream schedule (also used while per-kernel timing is on: events bracket launches per stream)
         R.reset_state();
         if (t > 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
@@ -707,10 +737,19 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
     }
     // two-stream schedule: the side stream runs FNet and the state-independent part of every frame up to two
     // frames ahead of the recurrent chain on the caller's stream
-    auto fail = [&](const char* what) { set_error("dsv_forward_clip: %s failed", what); return 1; };
+    SideStream& ss = *ssp;
+    bool forked = false;
+    // every exit after the fork joins the side stream back into the caller's stream: the caller may free or reuse
+    // lrs / fvs / mks / workspace as soon as its stream has drained, also after an error
+    auto join = [&]() {
+        hipEvent_t ej = ss.event(0);
+        if (forked && ej && hipEventRecord(ej, ss.s) == hipSuccess) (void)hipStreamWaitEvent(main_s, ej, 0);
+    };
+    auto fail = [&](const char* what) { join(); set_error("dsv_forward_clip: %s failed", what); return 1; };
     hipEvent_t ev_start = ss.event(0), ev_xlr = ss.event(1);
     if (!ss.ok) return fail("hipEventCreate");
     if (hipEventRecord(ev_start, main_s) != hipSuccess || hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
+    forked = true;
     R.reset_state();
     R.encode_lr(t, lrs, lr_f);
     if (hipEventRecord(ev_xlr, main_s) != hipSuccess) return fail("record");
@@ -732,21 +771,23 @@ int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, cons
         R.frame(i & 1, i == 0, mks + i * hr_px, out + (long long)i * co * hr_px);
         if (hipEventRecord(main_done, main_s) != hipSuccess) return fail("record");
     }
+    if (R.rc) join();   // a launch failed mid-clip: the last pre_done wait may not have been enqueued
     return R.rc;
 }
 
-int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const float* lr_prev, const float* fv,
+int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
                           const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream) {
+    const int y_only = flags & CRFP_DSV_Y_ONLY;
     Layout L(1, h, w);
     int rc = check_common(packed, 1, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     if (!lr || !fv || !mk || !out || (!first && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
-    const bool use_side = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);
-    SideStream& ss = side_stream();
+    R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
+    SideStream* ssp = (!first && side_stream_enabled() && !prof_enabled()) ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
-    if (first || !use_side || !ss.ok || prof_enabled()) {
+    if (!ssp) {
         if (first) R.reset_state();
         if (!first) R.fnet(1, lr, 0, lr_prev, 0);
         R.encode_lr(1, lr, 0);
@@ -757,7 +798,13 @@ int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const
     // two streams: FNet (one pair, small launch-latency-bound kernels, 0.45 ms) and the flow up-samplings stay on the
     // caller's stream; encoder_lr, the fovea blend, encoder_hr and the upsample conv run beside them on the side stream.
     // The caller's kernels are enqueued first (enqueue order across streams matters).
-    auto fail = [&](const char* what) { set_error("dsv_stream_frame: %s failed", what); return 1; };
+    SideStream& ss = *ssp;
+    bool forked = false;
+    auto join = [&]() {
+        hipEvent_t ej = ss.event(1);
+        if (forked && ej && hipEventRecord(ej, ss.s) == hipSuccess) (void)hipStreamWaitEvent(main_s, ej, 0);
+    };
+    auto fail = [&](const char* what) { join(); set_error("dsv_stream_frame: %s failed", what); return 1; };
     hipEvent_t ev_start = ss.event(0), ev_side = ss.event(1);
     if (!ss.ok) return fail("hipEventCreate");
     if (hipEventRecord(ev_start, main_s) != hipSuccess) return fail("record");
@@ -765,6 +812,7 @@ int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const
     R.frame_pre(0, false, lr, fv, mk, R.F(L.flow_lr), R.F(L.x_lr), nullptr, 2);
     R.s = ss.s;
     if (hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
+    forked = true;
     R.encode_lr(1, lr, 0);
     R.frame_pre(0, false, lr, fv, mk, nullptr, R.F(L.x_lr), nullptr, 1);
     if (hipEventRecord(ev_side, ss.s) != hipSuccess) return fail("record");
@@ -772,6 +820,11 @@ int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const
     if (hipStreamWaitEvent(main_s, ev_side, 0) != hipSuccess) return fail("join");
     R.frame(0, false, mk, out, fg);
     return R.rc;
+}
+
+int crfp_shutdown(void) {
+    for (int d = 0; d < kMaxDevices; ++d) g_side[d].destroy();
+    return 0;
 }
 
 int crfp_fnet_forward(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,

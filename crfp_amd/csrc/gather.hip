@@ -460,7 +460,8 @@ __device__ __forceinline__ void dcn_consume_pair(const DcnPair& P, f32x16& acc, 
 __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __restrict__ x, long long xb,
                                                              const float* __restrict__ offmask, long long omb,
                                                              const float* __restrict__ wpk, const float* __restrict__ bias,
-                                                             float* __restrict__ out, long long ob, int H, int W) {
+                                                             float* __restrict__ out, long long ob, int H, int W,
+                                                             unsigned* __restrict__ ovf) {
     __shared__ f32x4 wl[36 * 64];   // split-fp16 weight image (36 KB), shared by the 4 waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 36 * 64; i += 256) wl[i] = reinterpret_cast<const f32x4*>(wpk)[i];
@@ -522,13 +523,16 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
     float* o = out + (long long)n * ob + ((long long)py * W + px) * 4;
+    float vmax = 0.0f;   // fp16-operand range guard (ConvArgs::ovf): the aligned features feed a split-fp16 conv
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int cq = 2 * g + h;
         const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * cq);
-        *reinterpret_cast<float4*>(o + cq * plane) =
-            make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+        const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        *reinterpret_cast<float4*>(o + cq * plane) = v;
     }
+    if (ovf && !(vmax < 65504.0f)) atomicOr(ovf, 1u);
 }
 
 // wpk[((p36*2 + half)*32 + row)*4 + i] = W[row][4*(4*half + p36/9) + i][p36 % 9]
@@ -556,7 +560,7 @@ __global__ void dcn_g8_pack16_kernel(const float* __restrict__ w, unsigned short
 }
 
 bool dcn_g8_use_f16() {
-    static const bool f16 = !(getenv("CRFP_DCN_MODE") && !strcmp(getenv("CRFP_DCN_MODE"), "f32"));
+    static const bool f16 = !precision_env_strict("CRFP_DCN_MODE");
     return f16;
 }
 
@@ -569,30 +573,34 @@ int launch_dcn_g8_pack(const float* w, float* wpk, hipStream_t s, bool f16) {
 }
 
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
-                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16) {
+                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16, unsigned* ovf) {
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * (32 + 144 + 72 + 32) * 4.0 + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
+    // measured 89.1 vs 91.7 us for the software-pipelined kernel (and no gain at all until sched_barrier pinned the gathers
+    // ahead of the math): mostly bound by the L1 line rate of the 16-B corner gathers and VALU issue
+#ifdef CRFP_LAB
     static const int variant = getenv("CRFP_DCN_VARIANT") ? atoi(getenv("CRFP_DCN_VARIANT")) : 3;  // tuning knob (A/B: 3 fastest)
-    // measured 89.1 vs 91.7 us (and no gain at all until sched_barrier pinned the gathers ahead of the math): the kernel is
-    // mostly bound by the L1 line rate of the 16-B corner gathers (1.06 GB through the TA per launch) and VALU issue
     static const bool pipe = !(getenv("CRFP_DCN_PIPE") && atoi(getenv("CRFP_DCN_PIPE")) == 0);
-    if (f16 && pipe) {
-        dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
-        CRFP_CHECK_LAUNCH();
-        return 0;
-    }
-    if (f16) {
+    if (f16 && !pipe) {
         dcn_g8_kernel<4, 2, 4, true><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
         CRFP_CHECK_LAUNCH();
         return 0;
     }
-    switch (variant) {
-        case 1: dcn_g8_kernel<8, 2, 6, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
-        case 2: dcn_g8_kernel<8, 4, 4, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
-        case 3: dcn_g8_kernel<4, 2, 4, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
-        case 4: dcn_g8_kernel<8, 1, 8, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
-        default: dcn_g8_kernel<4, 4, 3, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+    if (!f16 && variant != 3) {
+        switch (variant) {
+            case 1: dcn_g8_kernel<8, 2, 6, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+            case 2: dcn_g8_kernel<8, 4, 4, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+            case 4: dcn_g8_kernel<8, 1, 8, false><<<dim3((W + 31) / 32, (H + 7) / 8, N), 512, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+            default: dcn_g8_kernel<4, 4, 3, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W); break;
+        }
+        CRFP_CHECK_LAUNCH();
+        return 0;
     }
+#endif
+    if (f16)
+        dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf);
+    else
+        dcn_g8_kernel<4, 2, 4, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
     CRFP_CHECK_LAUNCH();
     return 0;
 }

@@ -16,8 +16,16 @@ def param_names():
 
 
 class DSVEngine:
-    def __init__(self, state_dict, device, y_only: bool = False):
+    """precision: "split" (default: split-fp16 MFMA scheme, fp32-grade, operands must stay below 65504) or "f32" (strict
+    fp32 MFMA, CRFP_DSV_STRICT_F32).  on_overflow: what a clip / streamed frame does when the split scheme's range guard
+    fires -- "poison" (default, no host sync: the output frames are NaN and ``overflowed()`` tells why), "fallback"
+    (synchronise, rerun the call in strict fp32) or "raise" (FloatingPointError)."""
+
+    def __init__(self, state_dict, device, y_only: bool = False, precision: str = "split", on_overflow: str = "poison"):
         """state_dict: mapping with the reference's CRFP_DSV keys -> tensors (any device)."""
+        if precision not in ("split", "f32") or on_overflow not in ("poison", "fallback", "raise"):
+            raise ValueError(f"precision {precision!r} / on_overflow {on_overflow!r}")
+        self.precision, self.on_overflow = precision, on_overflow
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("crfp_amd.DSVEngine needs a CUDA/HIP device (no CPU path in the product)")
@@ -25,6 +33,7 @@ class DSVEngine:
         self._ws = {}
         self._stream_ws = None
         self._stream_prev = None
+        self._stream_prev_buf = None
         self._stream_hw = None
         self.pack(state_dict)
 
@@ -65,6 +74,33 @@ class DSVEngine:
             return mks.contiguous().view(torch.uint8)
         return (mks != 0).contiguous().view(torch.uint8)
 
+    def _flags(self, strict=None):
+        strict = (self.precision == "f32") if strict is None else strict
+        return self.y_only | (_lib.DSV_STRICT_F32 if strict else 0)
+
+    @staticmethod
+    def _status(ws, t, h, w) -> int:
+        off = _lib.lib().crfp_dsv_status_offset(t, h, w)
+        return int(ws[off:off + 4].view(torch.int32).item())   # synchronises
+
+    def overflowed(self, stream: bool = False) -> bool:
+        """True when the split-fp16 range guard fired in the last clip forward (or, stream=True, in the running
+        streamed sequence).  Synchronises the device."""
+        if stream:
+            return self._stream_ws is not None and bool(self._status(self._stream_ws, 1, *self._stream_hw) & 1)
+        return any(self._status(ws, *key) & 1 for key, ws in self._ws.items())
+
+    def _after(self, ws, key, rerun):
+        """on_overflow policy after a call that used workspace `ws`; `rerun(strict=True)` repeats it."""
+        if self.on_overflow == "poison" or self.precision == "f32":
+            return None
+        if not self._status(ws, *key) & 1:
+            return None
+        if self.on_overflow == "raise":
+            raise FloatingPointError("crfp_amd: an activation reached the fp16 operand range (|v| >= 65504) of the split-fp16 "
+                                     "convolution scheme; run with precision='f32' (CRFP_DSV_STRICT_F32)")
+        return rerun()
+
     def forward(self, lrs, fvs, mks):
         """lrs[n,t,3,h,w], fvs[n,t,3,8h,8w], mks[n,t,1,8h,8w] (bool) -> [n,t,3|1,8h,8w]."""
         lrs, fvs = _dev(lrs, "lrs"), _dev(fvs, "fvs")
@@ -76,11 +112,16 @@ class DSVEngine:
         out = torch.empty((n, t, 1 if self.y_only else 3, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
         ws = self._workspace(t, h, w)
         L = _lib.lib()
+
+        def run(b, strict=None):
+            _lib.check(L.crfp_dsv_forward_clip(self.packed.data_ptr(), self._flags(strict), lrs[b].data_ptr(),
+                                               fvs[b].data_ptr(), mk8[b].data_ptr(), out[b].data_ptr(), t, h, w,
+                                               ws.data_ptr(), ws.numel(), _stream()), "crfp_dsv_forward_clip")
+
         with torch.cuda.device(self.device):
             for b in range(n):
-                _lib.check(L.crfp_dsv_forward_clip(self.packed.data_ptr(), self.y_only, lrs[b].data_ptr(),
-                                                   fvs[b].data_ptr(), mk8[b].data_ptr(), out[b].data_ptr(), t, h, w,
-                                                   ws.data_ptr(), ws.numel(), _stream()), "crfp_dsv_forward_clip")
+                run(b)
+                self._after(ws, (t, h, w), lambda b=b: run(b, strict=True))
         return out
 
     # ---- streaming: one frame per call, state lives in a dedicated workspace
@@ -101,14 +142,22 @@ class DSVEngine:
             self._stream_prev = None
         first = self._stream_prev is None
         out = torch.empty((1 if self.y_only else 3, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
+        if self.on_overflow == "fallback" and self.precision != "f32":
+            raise NotImplementedError("on_overflow='fallback' cannot rewind a streamed sequence: use 'poison' or 'raise'")
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().crfp_dsv_stream_frame(
-                self.packed.data_ptr(), self.y_only, lr.data_ptr(),
+                self.packed.data_ptr(), self._flags(), lr.data_ptr(),
                 None if first else self._stream_prev.data_ptr(), fv.data_ptr(), mk8.data_ptr(),
                 None if fg8 is None else fg8.data_ptr(), out.data_ptr(),
                 1 if first else 0, h, w, self._stream_ws.data_ptr(), self._stream_ws.numel(), _stream()),
                 "crfp_dsv_stream_frame")
-        self._stream_prev = lr
+        self._after(self._stream_ws, (1, h, w), None)
+        # the reference keeps a COPY of the frame (model/CRFP_test.py:2234-2238, ``.clone()``): a caller that refills one
+        # input buffer in place must not change what the next call sees as the previous frame
+        if self._stream_prev_buf is None or self._stream_prev_buf.shape != lr.shape:
+            self._stream_prev_buf = torch.empty_like(lr)
+        self._stream_prev_buf.copy_(lr)
+        self._stream_prev = self._stream_prev_buf
         return out
 
     def compute_flow(self, cur, prev):

@@ -94,6 +94,19 @@ def evaluate(clip_fn: Callable[[int], Sequence[Sequence[float]]], n_clips: int, 
     return out
 
 
+def rgb2yuv(rgb: torch.Tensor) -> torch.Tensor:
+    """trainer.rgb2yuv(y_only=False) (trainer.py:19-36)."""
+    r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    return torch.stack([0.299 * r + 0.587 * g + 0.114 * b, -0.147 * r - 0.289 * g + 0.436 * b,
+                        0.615 * r - 0.515 * g - 0.100 * b], dim=1)
+
+
+def yuv2rgb(yuv: torch.Tensor) -> torch.Tensor:
+    """trainer.yuv2rgb (trainer.py:38-48)."""
+    y, u, v = yuv[:, 0], yuv[:, 1], yuv[:, 2]
+    return torch.stack([y + 1.14 * v, y + -0.396 * u - 0.581 * v, y + 2.029 * u], 1)
+
+
 def counted_frames(i_batch: int, n_frames: int) -> Iterable[int]:
     """trainer.py:349-351: frame 0 is skipped when i_batch % 50 == 0."""
     return (i for i in range(n_frames) if not (i == 0 and i_batch % 50 == 0))
@@ -106,6 +119,9 @@ def eval_clip(model, batch: dict, i_batch: int, with_ssim: bool = True):
     B, N, C, H, W = sr.shape
     sr = sr.view(B * N, C, H, W)
     hr = batch["HR"].view(B * N, -1, H, W)
+    if C == 1:   # y_only model (trainer.py:331-335): chroma of the bicubic LR_sr under the predicted luma, back to RGB
+        yuv = rgb2yuv(batch["LR_sr"].view(B * N, 3, H, W).to(sr.dtype))
+        sr = yuv2rgb(torch.cat((sr[:, 0:1], yuv[:, 1:3]), dim=1)).contiguous()
     fn = frame_metrics if with_ssim else frame_psnrs
     return [fn(sr[i:i + 1], hr[i:i + 1]) for i in counted_frames(i_batch, N)]
 

@@ -232,6 +232,9 @@ class CRFP_DSV(nn.Module):
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
         self._engine = None
         self._engine_sig = None
+        # numerics policy of the HIP engine (crfp_amd.engine.DSVEngine): not part of the reference's interface
+        self.precision = "split"      # "split": split-fp16 MFMA scheme (fp32-grade) | "f32": strict fp32 MFMA
+        self.on_overflow = "poison"   # "poison" | "fallback" | "raise" when an activation leaves the fp16 operand range
 
     # ---- engine management: repack whenever a parameter was modified or moved
     def _signature(self):
@@ -243,6 +246,7 @@ class CRFP_DSV(nn.Module):
         if self._engine is None or self._engine_sig != sig or self._engine.device != dev:
             self._engine = DSVEngine(self.state_dict(), dev, self.y_only)
             self._engine_sig = sig
+        self._engine.precision, self._engine.on_overflow = self.precision, self.on_overflow
         return self._engine
 
     def compute_flow(self, lrs):

@@ -24,6 +24,15 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t.contiguous()
 
 
+def _on(*tensors):
+    """Context that makes the operands' device current (the C-ABI enqueues on a stream of the CURRENT device, so the
+    stream handle must be taken inside this block); all operands must live on one device."""
+    devs = {t.device for t in tensors if isinstance(t, torch.Tensor)}
+    if len(devs) != 1:
+        raise RuntimeError(f"crfp_amd: operands on different devices: {sorted(map(str, devs))}")
+    return torch.cuda.device(devs.pop())
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -43,9 +52,10 @@ def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_cor
     out = torch.empty_like(x)
     nb = L.crfp_flow_warp_workspace_bytes(n, c, h, w)
     ws = _ws(nb, x.device)
-    _lib.check(L.crfp_flow_warp_f32(x.data_ptr(), flow.data_ptr(), out.data_ptr(), n, c, h, w,
-                                    1 if padding_mode == "border" else 0, ws.data_ptr(), ws.numel(), _stream()),
-               "crfp_flow_warp_f32")
+    with _on(x, flow):
+        _lib.check(L.crfp_flow_warp_f32(x.data_ptr(), flow.data_ptr(), out.data_ptr(), n, c, h, w,
+                                        1 if padding_mode == "border" else 0, ws.data_ptr(), ws.numel(), _stream()),
+                   "crfp_flow_warp_f32")
     return out
 
 
@@ -62,10 +72,11 @@ def dcnv2(x, offset, mask, weight, bias, kernel_size=3, padding=1, dilation=1, d
     L = _lib.lib()
     out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
     ws = _ws(L.crfp_dcnv2_workspace_bytes(n, cin, cout, h, w, kernel_size, deformable_groups), x.device)
-    _lib.check(L.crfp_dcnv2_forward_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), weight.data_ptr(),
-                                        bias.data_ptr(), out.data_ptr(), n, cin, cout, h, w, kernel_size, padding,
-                                        dilation, deformable_groups, ws.data_ptr(), ws.numel(), _stream()),
-               "crfp_dcnv2_forward_f32")
+    with _on(x, offset, mask, weight, bias):
+        _lib.check(L.crfp_dcnv2_forward_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), weight.data_ptr(),
+                                            bias.data_ptr(), out.data_ptr(), n, cin, cout, h, w, kernel_size, padding,
+                                            dilation, deformable_groups, ws.data_ptr(), ws.numel(), _stream()),
+                   "crfp_dcnv2_forward_f32")
     return out
 
 
@@ -81,9 +92,10 @@ def conv3x3(x, weight, bias=None, act="none", post_scale=1.0):
     L = _lib.lib()
     out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
     ws = _ws(L.crfp_conv3x3_workspace_bytes(n, cin, cout, h, w), x.device)
-    _lib.check(L.crfp_conv3x3_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n, cin, cout,
-                                  h, w, ACT[act], float(post_scale), ws.data_ptr(), ws.numel(), _stream()),
-               "crfp_conv3x3_f32")
+    with _on(x, weight, bias):
+        _lib.check(L.crfp_conv3x3_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n, cin, cout,
+                                      h, w, ACT[act], float(post_scale), ws.data_ptr(), ws.numel(), _stream()),
+                   "crfp_conv3x3_f32")
     return out
 
 
@@ -100,8 +112,9 @@ def upsample_bilinear(x, scale_factor=None, size=None, mul=1.0):
         sh = float(torch.tensor(h, dtype=torch.float32) / torch.tensor(oh, dtype=torch.float32))
         sw = float(torch.tensor(w, dtype=torch.float32) / torch.tensor(ow, dtype=torch.float32))
     out = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().crfp_upsample_bilinear_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, oh, ow, sh, sw,
-                                                     float(mul), _stream()), "crfp_upsample_bilinear_f32")
+    with _on(x):
+        _lib.check(_lib.lib().crfp_upsample_bilinear_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, oh, ow, sh, sw,
+                                                         float(mul), _stream()), "crfp_upsample_bilinear_f32")
     return out
 
 
@@ -110,8 +123,9 @@ def sq_err_sums(a, b):
     a, b = _dev(a, "a"), _dev(b, "b")
     n, c, h, w = a.shape
     acc = torch.zeros(2, dtype=torch.float64, device=a.device)
-    _lib.check(_lib.lib().crfp_psnr_partial_f32(a.data_ptr(), b.data_ptr(), acc.data_ptr(), n, c, h, w, _stream()),
-               "crfp_psnr_partial_f32")
+    with _on(a, b):
+        _lib.check(_lib.lib().crfp_psnr_partial_f32(a.data_ptr(), b.data_ptr(), acc.data_ptr(), n, c, h, w, _stream()),
+                   "crfp_psnr_partial_f32")
     return acc
 
 
@@ -120,7 +134,8 @@ def avgpool2(x):
     x = _dev(x, "x")
     n, c, h, w = x.shape
     out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().crfp_avgpool2_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "crfp_avgpool2_f32")
+    with _on(x):
+        _lib.check(_lib.lib().crfp_avgpool2_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "crfp_avgpool2_f32")
     return out
 
 
@@ -137,8 +152,9 @@ def fovea_head(state, x_hr, mask, lr, w_tttf, b_tttf, w_last, b_last, y_only=Fal
     ws = torch.empty(L.crfp_fovea_head_workspace_bytes(n, h, w), dtype=torch.uint8, device=state.device)
     new_state = torch.empty_like(state)
     out = torch.empty((n, 1 if y_only else 3, H, W), dtype=torch.float32, device=state.device)
-    _lib.check(L.crfp_fovea_head_f32(state.data_ptr(), x_hr.data_ptr(), m8.data_ptr(), lr.data_ptr(), w_tttf.data_ptr(),
-                                     b_tttf.data_ptr(), w_last.data_ptr(), b_last.data_ptr(), new_state.data_ptr(),
-                                     out.data_ptr(), n, h, w, int(bool(y_only)), ws.data_ptr(), ws.numel(), _stream()),
-               "crfp_fovea_head_f32")
+    with _on(state, x_hr, lr, w_tttf, b_tttf, w_last, b_last):
+        _lib.check(L.crfp_fovea_head_f32(state.data_ptr(), x_hr.data_ptr(), m8.data_ptr(), lr.data_ptr(), w_tttf.data_ptr(),
+                                         b_tttf.data_ptr(), w_last.data_ptr(), b_last.data_ptr(), new_state.data_ptr(),
+                                         out.data_ptr(), n, h, w, int(bool(y_only)), ws.data_ptr(), ws.numel(), _stream()),
+                   "crfp_fovea_head_f32")
     return new_state, out

@@ -5,7 +5,18 @@
  * documented as host memory; the library never allocates, frees or retains device memory --
  * scratch arrives through `workspace` (size from the matching *_workspace_bytes query).  Kernels
  * are enqueued asynchronously on `stream` (a hipStream_t passed as void*); no entry point
- * synchronises the device.  Return value: 0 = success, negative = CRFP_E_* argument error,
+ * synchronises the device.
+ *
+ * State kept between calls (all of it): per (host thread, device) ONE non-blocking HIP stream and a
+ * small pool of timing-disabled events, created lazily by the first crfp_dsv_forward_clip /
+ * crfp_dsv_stream_frame on that device.  The engine forks the state-independent part of each frame
+ * onto that stream and joins it back with events before returning control of `stream`'s order, on
+ * success AND on every error path, so for the caller each call behaves as if it ran on `stream`
+ * alone (buffers may be reused once `stream` has drained).  Clips issued by one host thread on
+ * several caller streams share that one side stream (their side work serialises; results are
+ * unaffected).  CRFP_SIDE_STREAM=0 in the environment (read once) selects a single-stream
+ * schedule that creates nothing.  crfp_shutdown() destroys the calling thread's side streams and
+ * events (call it after the thread's last stream has drained).  Return value: 0 = success, negative = CRFP_E_* argument error,
  * positive = hipError_t of a failed launch.  crfp_last_error_string() describes the last failure
  * on the calling thread.  No exceptions cross the boundary.
  *
@@ -29,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CRFP_VERSION 100 /* major*10000 + minor*100 + patch */
+#define CRFP_VERSION 200 /* major*10000 + minor*100 + patch */
 
 /* error codes (negative) */
 #define CRFP_E_BADARG (-1)      /* null pointer / non-positive size / unsupported combination */
@@ -49,6 +60,8 @@ extern "C" {
 
 int crfp_version(void);
 const char* crfp_last_error_string(void);
+/* destroy the calling thread's side streams / events (see "State kept between calls"); always 0 */
+int crfp_shutdown(void);
 
 /* ---- flow_warp: x[n,c,h,w] (NCHW f32), flow[n,h,w,2] = (dx,dy) pixels, out[n,c,h,w].
  * Bilinear backward warp, align_corners=True semantics of the reference (sample position =
@@ -114,16 +127,28 @@ size_t crfp_dsv_packed_weight_bytes(int y_only);
 int crfp_dsv_pack_weights(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
 
 size_t crfp_dsv_workspace_bytes(int t, int h, int w);
+
+/* `flags` of the two forward entry points (the round-1 ABI passed y_only in the same slot: 0 / 1 keep their meaning). */
+#define CRFP_DSV_Y_ONLY 1     /* the model was built with y_only=True: one output channel */
+#define CRFP_DSV_STRICT_F32 2 /* plain fp32 MFMA for every convolution and the DCN GEMM instead of the default split-fp16
+                               * scheme (fp32-grade, 3 fp16 MFMAs per product, needs |activation|, |weight| < 65504) */
+
+/* Numerics status: a 32-bit word inside the workspace at this byte offset.  Bit 0 is raised (sticky until the next clip
+ * / the next `first` streamed frame) when a kernel of the split-fp16 scheme stores a value an fp16 operand cannot hold
+ * (|v| >= 65504 or inf); from then on every output frame of the call is filled with NaN instead of plausible garbage.
+ * Read it (after synchronising the stream) to tell "overflow" from "NaN inputs", and rerun with CRFP_DSV_STRICT_F32. */
+size_t crfp_dsv_status_offset(int t, int h, int w);
+
 /* One clip: lrs[t,3,h,w], fvs[t,3,8h,8w] f32, mks[t,1,8h,8w] u8 (bool), out[t,3|1,8h,8w].
  * Zero initial state; flows from FNet(frame i, frame i-1).  Batches of clips: call once per clip. */
-int crfp_dsv_forward_clip(const void* packed, int y_only, const float* lrs, const float* fvs, const uint8_t* mks,
+int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                           float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Streaming: one frame per call, recurrent state kept inside `workspace` (same buffer every call).
  * `first` != 0 resets the state (clear_states of the reference's streaming model). lr_prev may be
  * NULL when first != 0.  fg: optional regional mask [8h,8w] u8 (the reference's `fgs`,
  * model/CRFP_test.py:2296-2298,2361,2375,2389), NULL = all ones. */
-int crfp_dsv_stream_frame(const void* packed, int y_only, const float* lr, const float* lr_prev, const float* fv,
+int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
                           const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream);
 

@@ -42,7 +42,7 @@ def _nograd():
 
 def test_library_loaded_and_version():
     from crfp_amd import _lib
-    assert _lib.lib().crfp_version() == 100
+    assert _lib.lib().crfp_version() == 200
     assert os.path.exists(_lib.LIB_PATH)
 
 
@@ -266,21 +266,40 @@ def test_streaming_variant_golden():
     assert maxdiff(torch.cat(outs, dim=1), g["out"]) < 2e-4
 
 
-@pytest.mark.parametrize("env", [{"CRFP_CONV_MODE": "f32"}, {"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "0"},
-                                 {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"}, {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SIDE_STREAM": "0"}, {"CRFP_SPLIT_PIPE": "1"}, {"CRFP_CONV_MODE": "bf16x6"},
-                                 {"CRFP_CONV_MODE": "bf16x6", "CRFP_SPLIT_IS": "0"}, {"CRFP_CONV_S3": "0"}])
-def test_alternate_kernel_paths(env):
-    """Every selectable conv main loop (fp32 MFMA, split-bf16 single-role / input-stationary /
-    warp-specialised, 4- and 8-row tiles) must give the same clip within the parity tolerance."""
+LAB_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "crfp_amd", "libcrfp_hip_lab.so")
+
+
+def _golden_check(env, lab=False, want="MAXDIFF"):
     import subprocess
     import sys
     e = dict(os.environ)
     e.update(env)
+    if lab:
+        if not os.path.exists(LAB_LIB):
+            pytest.skip("lab library not built (make -C crfp_amd/csrc lab)")
+        e["CRFP_HIP_LIB"] = LAB_LIB
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "run_golden_check.py")],
                          capture_output=True, text=True, env=e, timeout=600)
-    line = [l for l in out.stdout.splitlines() if l.startswith("MAXDIFF")]
+    line = [l for l in out.stdout.splitlines() if l.startswith(want)]
     assert line, out.stderr[-2000:]
-    assert float(line[0].split()[1]) < 2e-4
+    return line[0]
+
+
+@pytest.mark.parametrize("env", [{"CRFP_PRECISION": "f32"}, {"CRFP_CONV_MODE": "f32"}, {"CRFP_DCN_MODE": "f32"},
+                                 {"CRFP_SIDE_STREAM": "0"}])
+def test_alternate_kernel_paths(env):
+    """The process-wide switches the product library reads (strict fp32 MFMA for convs and / or the DCN GEMM, single-stream
+    schedule) give the same clip within the parity tolerance."""
+    assert float(_golden_check(env).split()[1]) < 2e-4
+
+
+@pytest.mark.parametrize("env", [{"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "1"}, {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"},
+                                 {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SPLIT_PIPE": "1"}, {"CRFP_CONV_MODE": "bf16x6"},
+                                 {"CRFP_CONV_MODE": "bf16x6", "CRFP_SPLIT_IS": "0"}, {"CRFP_CONV_S3": "0"}, {}])
+def test_lab_kernel_paths(env):
+    """The lab library (-DCRFP_LAB: every conv main loop that was tried -- split-bf16 single-role / input-stationary /
+    warp-specialised / pipelined, 4- and 8-row tiles) stays correct, so the A/B numbers in DESIGN.md remain reproducible."""
+    assert float(_golden_check(env, lab=True).split()[1]) < 2e-4
 
 
 @pytest.mark.parametrize("h,w,t,fv", [(18, 26, 3, 48), (33, 47, 3, 64), (17, 65, 3, 48), (64, 16, 2, 48), (21, 130, 2, 64)])
@@ -328,19 +347,10 @@ def test_runtime_rig_smoke():
 
 def test_producer_split_is_bit_identical():
     """SRC_S3 (the producing conv writes the fp16 pair image) must not change a single bit: the
-    producer applies the same split the consumer would."""
-    import subprocess
-    import sys
-    digests = []
-    for s3 in ("1", "0"):
-        e = dict(os.environ)
-        e["CRFP_CONV_S3"] = s3
-        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "run_golden_check.py")],
-                             capture_output=True, text=True, env=e, timeout=600)
-        line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")]
-        assert line, out.stderr[-2000:]
-        digests.append(line[0])
+    producer applies the same split the consumer would.  (The switch exists in the lab library only.)"""
+    digests = [_golden_check({"CRFP_CONV_S3": s3}, lab=True, want="DIGEST") for s3 in ("1", "0")]
     assert digests[0] == digests[1]
+    assert _golden_check({}, want="DIGEST") == digests[0]      # and the product library computes exactly the same clip
 
 
 def test_config_b_geometry_vs_oracle(orc):
@@ -532,7 +542,8 @@ def test_avgpool2_and_fovea_head_ops():
         assert maxdiff(ns, ns_ref) < 2e-5 and maxdiff(out, out_ref) < 2e-5
 
 
-def test_eval_reds_end_to_end_vs_oracle(orc, tmp_path):
+@pytest.mark.parametrize("y_only", [False, True])
+def test_eval_reds_end_to_end_vs_oracle(orc, tmp_path, y_only):
     """dataset.reds.EvalSet -> model -> per-frame PSNR/SSIM/-Y -> means (Trainer.eval_basicvsr, trainer.py:295-413) on a
     synthetic REDS-shaped PNG tree: HIP path vs the oracle driven through the same harness code."""
     import types
@@ -552,14 +563,21 @@ def test_eval_reds_end_to_end_vs_oracle(orc, tmp_path):
                 os.makedirs(d, exist_ok=True)
                 PIL.Image.fromarray(img).save(os.path.join(d, f"{i:08d}.png"))
     args = types.SimpleNamespace(dataset_dir=gt_root, scale=8, N_frames=3, GT_size=128, FV_size=32)
-    sd = synth.make_state_dict(7)
-    m = _model(sd)
+    sd = synth.make_state_dict(7, y_only=y_only)
+    m = _model(sd, y_only)
     res = evalrig.eval_reds(m, args, device=dev())
     P = orc.load_numpy_state(sd)
 
     def oracle_frames(i_batch):
         item = reds.EvalSet(args)[i_batch]
-        sr = orc.crfp_dsv_forward(P, item["LR"][None], item["Ref"][None], item["Ref_sp"][None].float())[0]
+        sr = orc.crfp_dsv_forward(P, item["LR"][None], item["Ref"][None], item["Ref_sp"][None].float(),
+                                  orc.DSVConfig(y_only=y_only))[0]
+        if y_only:   # trainer.py:331-335, restated with the trainer's own coefficients (:19-48)
+            r, g_, b = item["LR_sr"][:, 0], item["LR_sr"][:, 1], item["LR_sr"][:, 2]
+            u = -0.147 * r - 0.289 * g_ + 0.436 * b
+            v = 0.615 * r - 0.515 * g_ - 0.100 * b
+            y = sr[:, 0]
+            sr = torch.stack([y + 1.14 * v, y + -0.396 * u - 0.581 * v, y + 2.029 * u], 1)
         out = []
         ones = torch.ones(1, 1, *sr.shape[2:])
         for i in evalrig.counted_frames(i_batch, sr.shape[0]):
