@@ -14,9 +14,71 @@
 #include <stddef.h>
 #include "../../include/crfp_hip.h"
 
-namespace crfp {
+// ------------------------------------------------------------------ storage type of activations in HBM
+// conv_mfma / conv_narrow / gather / resample / engine are compiled TWICE (csrc/Makefile): as they are (namespace crfp,
+// act_t = float: the fp32 path of round 1) and with -DCRFP_ACT_BF16 (namespace crfp_bf16, act_t = __bf16: BASELINE configs
+// 3-5, "bf16 storage").  In the bf16 build every Q4 / P4 activation tensor and the recurrent state hold bf16 -- same
+// element counts and index arithmetic, 8-byte instead of 16-byte pixel quads -- all arithmetic stays fp32 (MFMA
+// accumulators, bilinear weights, activations), and everything that is a coordinate stays fp32 in memory: flow fields,
+// DCN offsets and masks, the API tensors (lrs / fvs / out).  Pointers in the plan structs stay `const float*` for both
+// builds (opaque: SRC_NCHW / SRC_FLOW2 sources really are float); kernels cast activation pointers to act_t.
+#ifdef CRFP_ACT_BF16
+#define CRFP_NS crfp_bf16
+#define CRFP_API(name) name##_bf16
+#else
+#define CRFP_NS crfp
+#define CRFP_API(name) name
+#endif
+
+namespace crfp {   // compiled once (runtime.hip): errors, per-kernel timing, environment
+void set_error(const char* fmt, ...);
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t s, double bytes, double flops);
+    ~ProfScope();
+    hipStream_t s_;
+    int slot_;
+};
+bool prof_enabled();
+bool precision_env_strict(const char* legacy_knob);   // CRFP_PRECISION=f32 (or the round-1 knob) in the environment
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace crfp
+
+namespace CRFP_NS {
+using crfp::set_error;
+using crfp::ProfScope;
+using crfp::prof_enabled;
+using crfp::precision_env_strict;
+using crfp::align_up;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float cf32x4 __attribute__((ext_vector_type(4)));
+typedef float cf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned cu32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef CRFP_ACT_BF16
+typedef __bf16 act_t;
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+constexpr bool kActBf16 = true;
+// 4 bf16 (one pixel quad, 8 bytes) <-> 4 fp32.  bf16 -> fp32 is a shift; fp32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ cf32x4 quad_from_bits(cu32x2 b) {
+    return cf32x4{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
+                  __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
+}
+__device__ __forceinline__ cu32x2 quad_to_bits(cf32x4 v) {
+    const cbf16x2 lo = __builtin_convertvector(cf32x2{v.x, v.y}, cbf16x2), hi = __builtin_convertvector(cf32x2{v.z, v.w}, cbf16x2);
+    return cu32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
+__device__ __forceinline__ cf32x4 ldq(const act_t* p) { return quad_from_bits(*reinterpret_cast<const cu32x2*>(p)); }
+__device__ __forceinline__ void stq(act_t* p, cf32x4 v) { *reinterpret_cast<cu32x2*>(p) = quad_to_bits(v); }
+#else
+typedef float act_t;
+constexpr bool kActBf16 = false;
+__device__ __forceinline__ cf32x4 ldq(const act_t* p) { return *reinterpret_cast<const cf32x4*>(p); }
+__device__ __forceinline__ void stq(act_t* p, cf32x4 v) { *reinterpret_cast<cf32x4*>(p) = v; }
+#endif
+constexpr int kQuadBytes = 4 * (int)sizeof(act_t);   // bytes of one pixel quad in HBM (16 / 8)
+__device__ __forceinline__ const act_t* as_act(const float* p) { return reinterpret_cast<const act_t*>(p); }
+__device__ __forceinline__ act_t* as_act(float* p) { return reinterpret_cast<act_t*>(p); }
 
 // ------------------------------------------------------------------ conv plan
 enum SrcKind : int {
@@ -101,8 +163,7 @@ struct ConvArgs {
     int rsv2;
 };
 
-bool conv_s3_supported();   // the selected conv kernels consume SRC_S3 sources (default f16x3 path only)
-bool precision_env_strict(const char* legacy_knob);   // CRFP_PRECISION=f32 (or the round-1 knob) in the environment
+bool conv_s3_supported();   // the selected conv kernels consume SRC_S3 sources (default f16x3 path of the fp32 build only)
 
 // packed row (0..ctiles*32) -> reference output channel, or -1 (padding)
 __host__ __device__ inline int conv_row_to_cout(int row, int cout, int store, int ps_r) {
@@ -206,16 +267,7 @@ __device__ __forceinline__ int xcd_band_tile(int b, int total) {
     return x * q + min(x, r) + i;
 }
 
-// ------------------------------------------------------------------ profiling + errors
-void set_error(const char* fmt, ...);
-struct ProfScope {
-    ProfScope(const char* name, hipStream_t s, double bytes, double flops);
-    ~ProfScope();
-    hipStream_t s_;
-    int slot_;
-};
-bool prof_enabled();
-
+// ------------------------------------------------------------------ errors
 #define CRFP_CHECK_LAUNCH()                                     \
     do {                                                        \
         hipError_t e__ = hipGetLastError();                     \
@@ -277,6 +329,4 @@ int launch_psnr_ssim_partial(const float* a, const float* b, const uint8_t* mask
                              float mul, float add, hipStream_t s);
 int launch_psnr_partial(const float* a, const float* b, double* acc, int N, int C, int H, int W, hipStream_t s);
 
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-}  // namespace crfp
+}  // namespace CRFP_NS

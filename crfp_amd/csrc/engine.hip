@@ -150,6 +150,7 @@ struct Model {
     Item items[IT_COUNT];
     size_t total_floats = 0;
     int y_only = 0;
+    bool use_s3 = false;   // producer-split SRC_S3 edges (default precision only); packed weights are identical either way
 
     void add_mfma(int id, const char* name, int ci, int ci2, std::vector<SrcSpec> srcs, int store, int ps_r, int act,
                   float post_scale = 1.0f) {
@@ -174,7 +175,7 @@ struct Model {
         it.n_b = 4;
     }
 
-    explicit Model(int y_only_) : y_only(y_only_) {
+    Model(int y_only_, bool use_s3_) : y_only(y_only_), use_s3(use_s3_) {
         const int Q = SRC_Q4;
         static const char* fn[14] = {"conv_mfma:fnet.enc1a", "conv_mfma:fnet.enc1b", "conv_mfma:fnet.enc2a",
                                      "conv_mfma:fnet.enc2b", "conv_mfma:fnet.enc3a", "conv_mfma:fnet.enc3b",
@@ -191,7 +192,7 @@ struct Model {
         // The DCN offset feature of a level (dcn_block.2 / conv_fuse output, model/CRFP.py:331-336) only ever feeds convs
         // (offset/mask head, next level's conv_fuse, dcn_3's pre-offset conv): it is stored as the producer-split SRC_S3
         // image instead of fp32 Q4 (same bytes), so the 216-channel head no longer converts the same tile 7 times.
-        const int FS = conv_s3_supported() ? (int)SRC_S3 : (int)Q;
+        const int FS = use_s3 ? (int)SRC_S3 : (int)Q;
         for (int l = 0; l < 3; ++l) {
             if (l > 0)
                 add_mfma(it_lvl(l, L_FUSE), "conv_mfma:dcn.conv_fuse", ci_dcn(l, 0), -1, {{Q, 32}, {FS, 32}}, ST_Q4, 0,
@@ -253,9 +254,11 @@ struct Model {
     }
 };
 
-static const Model& model_for(int y_only) {
-    static const Model m0(0), m1(1);
-    return y_only ? m1 : m0;
+// strict: the fp32-MFMA wiring (no SRC_S3 edges); same packed-weight layout as the default wiring
+static const Model& model_for(int y_only, bool strict = false) {
+    static const Model m0(0, false), m1(1, false), s0(0, true), s1(1, true);
+    if (strict || !conv_s3_supported()) return y_only ? m1 : m0;
+    return y_only ? s1 : s0;
 }
 
 // ------------------------------------------------------------------ workspace arena
@@ -424,7 +427,10 @@ struct Runner {
     int strict = 0;     // CRFP_DSV_STRICT_F32: fp32 MFMA for every conv and for dcn_g8's GEMM
 
     // null in strict mode: no kernel forms fp16 operands, the guard has nothing to watch (the word stays 0)
-    unsigned* ovf() const { return strict || !dcn_g8_use_f16() ? nullptr : reinterpret_cast<unsigned*>(ws + L.status); }
+    unsigned* ovf() const {
+        static const bool env_strict = precision_env_strict("CRFP_CONV_MODE");
+        return strict || env_strict ? nullptr : reinterpret_cast<unsigned*>(ws + L.status);
+    }
     float* F(size_t off) const { return reinterpret_cast<float*>(ws + off); }
     Q4 q(size_t off, int nq, int H, int W) const { Q4 r; r.p = F(off); r.nq = nq; r.H = H; r.W = W; return r; }
 
@@ -572,7 +578,7 @@ struct Runner {
                 mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
                      {{F(L.fa), 0, 0, 8}});
                 float* f = F(L.offfeat[l]);
-                const bool s3 = conv_s3_supported();   // f holds the SRC_S3 image (same size) instead of fp32 Q4
+                const bool s3 = M.use_s3;   // f holds the SRC_S3 image (same size) instead of fp32 Q4
                 if (l == 0) {
                     if (s3) mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, 0);
                     else mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{f, 0, 0, 8}});
@@ -716,7 +722,7 @@ int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const
     int rc = check_common(packed, t, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     if (!lrs || !fvs || !mks || !out) { set_error("dsv_forward_clip: null tensor"); return CRFP_E_BADARG; }
-    Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
     const long long lr_f = 3LL * h * w, hr_px = 64LL * h * w;
     const int co = y_only ? 1 : 3;
@@ -783,7 +789,7 @@ int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const 
     int rc = check_common(packed, 1, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     if (!lr || !fv || !mk || !out || (!first && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
-    Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
     SideStream* ssp = (!first && side_stream_enabled() && !prof_enabled()) ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
