@@ -54,6 +54,10 @@ SIGNATURES = {
     "crfp_dsv_debug_fetch": (C.c_int, [C.c_char_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p] +
                              [C.POINTER(C.c_int)] * 3 + [C.c_void_p]),
 }
+# bf16-storage twins of the engine entry points (same argument lists)
+for _n in ("crfp_dsv_packed_weight_bytes", "crfp_dsv_pack_weights", "crfp_dsv_workspace_bytes", "crfp_dsv_status_offset",
+           "crfp_dsv_forward_clip", "crfp_dsv_stream_frame", "crfp_fnet_forward", "crfp_dsv_debug_fetch"):
+    SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 
 _lib = None
 

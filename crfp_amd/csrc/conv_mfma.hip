@@ -27,7 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 
-namespace crfp {
+namespace CRFP_NS {
 
 constexpr int TW = 64, LW = TW + 2;
 #ifndef CRFP_TAP_UNROLL
@@ -36,34 +36,6 @@ constexpr int TW = 64, LW = TW + 2;
 #ifndef CRFP_SPLIT_TAP_UNROLL
 #define CRFP_SPLIT_TAP_UNROLL 9   // default split kernel: full unroll measured +1.4 % frames/s over 3 (168 VGPRs, still 3 waves/SIMD)
 #endif
-
-__device__ __forceinline__ float4 load_src_quad(const ConvSrc& s, int n, int kql, int gy, int gx, int H, int W) {
-    const float* base = s.p + (long long)n * s.bstride;
-    switch (s.kind) {
-        case SRC_Q4:
-            return *reinterpret_cast<const float4*>(base + (((long long)kql * (H + s.pad) + gy) * (W + s.pad) + gx) * 4);
-        case SRC_NCHW: {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ch = 4 * kql + c;
-                v[c] = ch < s.nch ? base[((long long)ch * H + gy) * W + gx] : 0.0f;
-            }
-            return make_float4(v[0], v[1], v[2], v[3]);
-        }
-        case SRC_UNSHUF4: {
-            const int Qp = kql >> 4, ij = kql & 15, i = ij >> 2, jj = ij & 3;
-            const int H4 = 4 * H + s.pad, W4 = 4 * W + s.pad;
-            return *reinterpret_cast<const float4*>(base + (((long long)Qp * H4 + 4 * gy + i) * W4 + 4 * gx + jj) * 4);
-        }
-        case SRC_FLOW2: {
-            const float2 f = *reinterpret_cast<const float2*>(base + ((long long)gy * W + gx) * 2);
-            return make_float4(f.x, f.y, 0.0f, 0.0f);
-        }
-        default:
-            return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-}
 
 // tanh / sigmoid on the hardware exp2 + rcp (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of the libm
 // versions (~30 VALU instructions each): the 216-channel offset/mask epilogue is transcendental-bound
@@ -96,10 +68,10 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
     switch (s.kind) {
         case SRC_Q4: {
             const int PW = W + s.pad;
-            const float* b = base + (long long)kql * (H + s.pad) * PW * 4;
+            const act_t* b = as_act(s.p) + (long long)n * s.bstride + (long long)kql * (H + s.pad) * PW * 4;
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
-                if (ok[k]) r[k] = *reinterpret_cast<const float4*>(b + ((long long)gy[k] * PW + gx[k]) * 4);
+                if (ok[k]) { const cf32x4 v = ldq(b + ((long long)gy[k] * PW + gx[k]) * 4); r[k] = make_float4(v.x, v.y, v.z, v.w); }
             break;
         }
         case SRC_NCHW: {
@@ -118,10 +90,10 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
         case SRC_UNSHUF4: {
             const int Qp = kql >> 4, ij = kql & 15, i = ij >> 2, jj = ij & 3;
             const int H4 = 4 * H + s.pad, W4 = 4 * W + s.pad;
-            const float* b = base + (long long)Qp * H4 * W4 * 4;
+            const act_t* b = as_act(s.p) + (long long)n * s.bstride + (long long)Qp * H4 * W4 * 4;
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
-                if (ok[k]) r[k] = *reinterpret_cast<const float4*>(b + ((long long)(4 * gy[k] + i) * W4 + 4 * gx[k] + jj) * 4);
+                if (ok[k]) { const cf32x4 v = ldq(b + ((long long)(4 * gy[k] + i) * W4 + 4 * gx[k] + jj) * 4); r[k] = make_float4(v.x, v.y, v.z, v.w); }
             break;
         }
         case SRC_FLOW2: {
@@ -175,8 +147,9 @@ struct EpiCtx {
     long long* dbg; // diagnostic stamps (null in production)
     float slope, post;
     const float4* bp;
-    const float* rp;
+    const act_t* rp;
     const float* flp;
+    bool f32dst;         // ST_Q4: the (single) destination is a float tensor also in the bf16 build (flow fields)
     unsigned* ovf;       // fp16-operand overflow word (null: not tracked)
     float* s3p;          // SRC_S3 image of the output (null: none)
     int s3_ngroups;      // cout / 8
@@ -195,7 +168,8 @@ __device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
     e.slope = a.act == CRFP_ACT_RELU ? 0.0f : (a.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
     e.post = a.post_scale;
     e.bp = reinterpret_cast<const float4*>(a.bpk);
-    e.rp = a.resid ? a.resid + (long long)n * a.resid_bstride : nullptr;
+    e.rp = a.resid ? as_act(a.resid) + (long long)n * a.resid_bstride : nullptr;
+    e.f32dst = a.dst_f32 != 0;
     e.flp = a.flow + (long long)n * a.flow_bstride;
     e.s3p = a.s3_dst ? a.s3_dst + (long long)n * a.s3_bstride : nullptr;
     e.s3_ngroups = a.cout >> 3;
@@ -254,7 +228,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cq = min((T0 + ct) * 8 + 2 * g + h, e.ncq - 1);
-                    rr[ct][g] = *reinterpret_cast<const float4*>(e.rp + (((long long)cq * H + y) * W + x) * 4);
+                    { const cf32x4 rv = ldq(e.rp + (((long long)cq * H + y) * W + x) * 4); rr[ct][g] = make_float4(rv.x, rv.y, rv.z, rv.w); }
                 }
         }
 #pragma unroll
@@ -293,6 +267,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 // store addresses = per-lane pixel offset (one 32-bit multiply per pixel tile) + wave-uniform 64-bit
                 // part per quad: the per-lane 64-bit multiplies of the first version were most of the epilogue's 6 k cycles
+#ifndef CRFP_ACT_BF16
                 if (STORE == ST_Q4 && e.s3p) {   // SRC_S3 image: this lane's 4 channels are half h of the 8-channel element
                     unsigned hi2[2], lo2[2];
                     split_f16x4(v, hi2, lo2);
@@ -305,24 +280,29 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
                     const int plane = (T0 + ct) * 4 + g + h * e.s3_ngroups;
                     *reinterpret_cast<uint4*>(e.s3p + (((long long)plane * H + y) * W + x) * 4) = make_uint4(r0.x, r1.x, r0.y, r1.y);
                 }
-                if (STORE == ST_Q4 || STORE == ST_OFFMASK) {
+#endif
+                if (STORE == ST_OFFMASK || (STORE == ST_Q4 && kActBf16 && e.f32dst)) {   // float destination (offsets / masks / flow), single
+                    const int cq0u = (T0 + ct) * 8 + 2 * g;
+                    *reinterpret_cast<float4*>(e.dp[0] + (long long)cq0u * e.dplane[0] + h * e.dplane[0] + (y * e.dpitch[0] + x) * 4) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else if (STORE == ST_Q4) {
                     if (e.single) {   // one destination that takes every quad (wave-uniform)
                         const int cq0u = (T0 + ct) * 8 + 2 * g;
-                        *reinterpret_cast<float4*>(e.dp[0] + (long long)cq0u * e.dplane[0] + h * e.dplane[0] + (y * e.dpitch[0] + x) * 4) =
-                            make_float4(v[0], v[1], v[2], v[3]);
+                        stq(as_act(e.dp[0]) + (long long)cq0u * e.dplane[0] + h * e.dplane[0] + (y * e.dpitch[0] + x) * 4,
+                            cf32x4{v[0], v[1], v[2], v[3]});
                     } else {
 #pragma unroll
                         for (int d = 0; d < CRFP_MAX_DST; ++d)
                             if (cq >= e.dq0[d] && cq < e.dq1[d])
-                                *reinterpret_cast<float4*>(e.dp[d] + (cq - e.dq0[d]) * e.dplane[d] + (y * e.dpitch[d] + x) * 4) =
-                                    make_float4(v[0], v[1], v[2], v[3]);
+                                stq(as_act(e.dp[d]) + (cq - e.dq0[d]) * e.dplane[d] + (y * e.dpitch[d] + x) * 4,
+                                    cf32x4{v[0], v[1], v[2], v[3]});
                     }
                 } else if (STORE == ST_PS) {
                     // cq0 is even and r >= 2: both lane halves share (Q, i) and differ by jj = +h
                     const int lr = e.lr, cq0u = (T0 + ct) * 8 + 2 * g;
                     const int Q = cq0u >> (2 * lr), sidx = cq0u & ((1 << (2 * lr)) - 1), i = sidx >> lr, jj = sidx & ((1 << lr) - 1);
-                    *reinterpret_cast<float4*>(e.dp[0] + ((long long)Q * e.dstH + i) * e.dstW * 4 + jj * 4 +
-                                               (((y << lr) * e.dstW + (x << lr)) + h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    stq(as_act(e.dp[0]) + ((long long)Q * e.dstH + i) * e.dstW * 4 + jj * 4 + (((y << lr) * e.dstW + (x << lr)) + h) * 4,
+                        cf32x4{v[0], v[1], v[2], v[3]});
                 } else {  // ST_NCHW
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -496,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 // K-chunk = 16 channels = 4 quads (lane-half h supplies k = 8h..8h+7 = quads 2h, 2h+1 of the chunk).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef CRFP_ACT_BF16   // the split-operand schemes exist for fp32 activations only
 __device__ __forceinline__ void split_bf16x8(const f32x4& lo, const f32x4& hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
     const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
@@ -869,6 +850,155 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
     }
 #endif
 }
+
+#endif  // !CRFP_ACT_BF16
+
+#ifdef CRFP_ACT_BF16
+// ================================================================ bf16-storage main loop
+// Activations arrive as bf16 pixel quads (8 bytes): the halo tile is COPIED into one bf16 LDS image (no conversion, no
+// split), weights are bf16 (rounded once at pack time), one v_mfma_f32_32x32x16_bf16 per (tap, 16-channel chunk,
+// 32-pixel tile) with fp32 accumulators that start at the fp32 bias.  Same tile shape, lane map, K order and epilogue as
+// conv3x3_split_kernel<1,1,2> of the fp32 build.  The only fp32 operand left is the flow field of dcn_block.0
+// (SRC_FLOW2, QuadDesc::mask bit 5): its (dx, dy) pair has the width of a bf16 quad and is rounded to bf16 on the way
+// into LDS.  LDS 22 KB per workgroup.
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 h2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{a, b}, h2_t));
+}
+// one raw 8-byte K-quad -> its two packed bf16 words; m = component mask (bit 5: fp32 (dx, dy) pair)
+__device__ __forceinline__ cu32x2 quad_words(cu32x2 r, int m, bool valid) {
+    if (!valid) return cu32x2{0u, 0u};
+    if (m & 32) return cu32x2{pack_bf16x2(__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y)), 0u};
+    const unsigned k0 = ((m & 1) ? 0x0000ffffu : 0u) | ((m & 2) ? 0xffff0000u : 0u);
+    const unsigned k1 = ((m & 4) ? 0x0000ffffu : 0u) | ((m & 8) ? 0xffff0000u : 0u);
+    return cu32x2{r.x & k0, r.y & k1};
+}
+
+template <int RPW>
+__global__ __launch_bounds__(256, 4) void conv3x3_bf16_kernel(const ConvArgs a) {
+    constexpr int CT = 1, TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
+    constexpr int NEL = LH * LW;                 // halo pixels
+    constexpr int NIN = (NEL + 255) / 256;       // halo pixels per thread; each carries the chunk's 4 quads
+    constexpr int WPC = 9 * 64;                  // weight vectors per (cout tile, chunk)
+    constexpr int NWS = (WPC + 255) / 256;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ u32x4_t tile[2][NEL];             // [quad pair][halo pixel]: 8 bf16 = 16 B
+    __shared__ bf16x8 wlds[WPC];                 // [tap][lane]: this chunk's A fragments
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int ngrp = a.ctiles;
+    const int bwork = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int btile = bwork / ngrp;
+    const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
+    const int T0 = bwork - btile * ngrp;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+
+    int cgy[NIN], cgx[NIN];
+    bool sval[NIN];
+#pragma unroll
+    for (int t = 0; t < NIN; ++t) {
+        const int idx = min(tid + 256 * t, NEL - 1);
+        const int r = idx / LW, c = idx - r * LW;
+        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+        sval[t] = tid + 256 * t < NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        cgy[t] = min(max(gy, 0), H - 1);
+        cgx[t] = min(max(gx, 0), W - 1);
+    }
+
+    f32x16 acc[CT][PT];
+    {   // accumulators start at the bias
+        const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bq = bp[T0 * 8 + 2 * g + h];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                acc[0][pt][4 * g + 0] = bq.x; acc[0][pt][4 * g + 1] = bq.y;
+                acc[0][pt][4 * g + 2] = bq.z; acc[0][pt][4 * g + 3] = bq.w;
+            }
+        }
+    }
+
+    const int nchunks = a.kq >> 2;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit16);
+    cu32x2 rq0[NIN], rq1[NIN], rq2[NIN], rq3[NIN];
+    bf16x8 rws[NWS];
+    const float* qb0; const float* qb1; const float* qb2; const float* qb3;
+    int qrs0, qrs1, qrs2, qrs3, qcs0, qcs1, qcs2, qcs3, qm0 = 0, qm1 = 0, qm2 = 0, qm3 = 0;
+#define CRFP_QDESC(QB_, QRS, QCS, QM, QI, CH)                                                             \
+    {                                                                                                     \
+        const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
+        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+    }
+#define CRFP_BF16_ISSUE(CH)                                                                               \
+    {                                                                                                     \
+        CRFP_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) CRFP_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                   \
+        CRFP_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) CRFP_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                   \
+        _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                                 \
+            rq0[t] = *reinterpret_cast<const cu32x2*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);               \
+            rq1[t] = *reinterpret_cast<const cu32x2*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);               \
+            rq2[t] = *reinterpret_cast<const cu32x2*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);               \
+            rq3[t] = *reinterpret_cast<const cu32x2*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);               \
+        }                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < NWS; ++k) {                                                 \
+            const int idx = min(tid + 256 * k, WPC - 1);                                                  \
+            rws[k] = wp[((long long)T0 * nchunks + (CH)) * WPC + idx];                                    \
+        }                                                                                                 \
+    }
+
+    CRFP_BF16_ISSUE(0)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;
+        __syncthreads();  // every wave finished reading the previous chunk
+        if ((m0 & m1 & m2 & m3) == 15 && !((m0 | m1 | m2 | m3) & 32)) {   // wave-uniform: 16 real bf16 channels -> plain copy
+#pragma unroll
+            for (int t = 0; t < NIN; ++t) {
+                const int idx = tid + 256 * t;
+                if (idx < NEL) {
+                    const unsigned km = sval[t] ? 0xffffffffu : 0u;
+                    tile[0][idx] = u32x4_t{rq0[t].x & km, rq0[t].y & km, rq1[t].x & km, rq1[t].y & km};
+                    tile[1][idx] = u32x4_t{rq2[t].x & km, rq2[t].y & km, rq3[t].x & km, rq3[t].y & km};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NIN; ++t) {
+                const int idx = tid + 256 * t;
+                if (idx < NEL) {
+                    const cu32x2 w0 = quad_words(rq0[t], m0, sval[t]), w1 = quad_words(rq1[t], m1, sval[t]);
+                    const cu32x2 w2 = quad_words(rq2[t], m2, sval[t]), w3 = quad_words(rq3[t], m3, sval[t]);
+                    tile[0][idx] = u32x4_t{w0.x, w0.y, w1.x, w1.y};
+                    tile[1][idx] = u32x4_t{w2.x, w2.y, w3.x, w3.y};
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NWS; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < WPC) wlds[idx] = rws[k];
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) CRFP_BF16_ISSUE(ch + 1)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const bf16x8 wa = wlds[tap * 64 + lane];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int pix = (wave * RPW + (pt >> 1) + ky) * LW + (pt & 1) * 32 + j + kx;
+                const bf16x8 bq = __builtin_bit_cast(bf16x8, tile[h][pix]);
+                acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bq, acc[0][pt], 0, 0, 0);
+            }
+        }
+    }
+#undef CRFP_BF16_ISSUE
+#undef CRFP_QDESC
+    const EpiCtx ec = epi_ctx(a, n);
+    conv_epilogue<CT, PT, RPW, 2>(ec, acc, T0, tx0, ty0, wave, j, h);
+}
+#endif  // CRFP_ACT_BF16
 
 #ifdef CRFP_LAB   // experiments that lose to conv3x3_split_kernel<1,1,2>: built only into the lab library (make lab)
 // ---------------------------------------------------------------- software-pipelined persistent variant (f16x3)
@@ -1435,7 +1565,9 @@ __global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict
             val = co < cout_split ? w[((long long)co * a.cin_total + ci) * 9 + tap]
                                   : w2[((long long)(co - cout_split) * a.cin_total + ci) * 9 + tap];
         const long long base = (((((long long)T * nchunks + ch) * 9 + tap) * np) * 64 + lane) * 8 + jj;
-        if (np == 3) {
+        if (np == 1) {   // bf16 build: the weight IS its bf16 rounding
+            wsplit[base] = __builtin_bit_cast(unsigned short, (__bf16)val);
+        } else if (np == 3) {
             const __bf16 p0 = (__bf16)val;
             const float r = val - (float)p0;
             const __bf16 p1 = (__bf16)r;
@@ -1445,7 +1577,7 @@ __global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict
             wsplit[base + 2 * 64 * 8] = __builtin_bit_cast(unsigned short, p2);
         } else {
             const _Float16 p0 = (_Float16)val;
-            const _Float16 p1 = (_Float16)((val - (float)p0) * F16_RES_SCALE);
+            const _Float16 p1 = (_Float16)((val - (float)p0) * 2048.0f);   // F16_RES_SCALE
             wsplit[base] = __builtin_bit_cast(unsigned short, p0);
             wsplit[base + 64 * 8] = __builtin_bit_cast(unsigned short, p1);
         }
@@ -1456,6 +1588,9 @@ __global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict
 #ifdef CRFP_LAB
 size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * (3 + 2) * 64 * 16; }
 size_t conv_split16_offset_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 3 * 64 * 16; }
+#elif defined(CRFP_ACT_BF16)
+size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 1 * 64 * 16; }   // one bf16 image
+size_t conv_split16_offset_bytes(const ConvArgs&) { return 0; }
 #else
 size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 2 * 64 * 16; }
 size_t conv_split16_offset_bytes(const ConvArgs&) { return 0; }
@@ -1471,7 +1606,7 @@ int launch_conv_pack_split(const ConvArgs& a, const float* w, const float* w2, i
     CRFP_CHECK_LAUNCH();
 #endif
     conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout,
-                                                  (unsigned short*)((char*)wsplit + conv_split16_offset_bytes(a)), 2);
+                                                  (unsigned short*)((char*)wsplit + conv_split16_offset_bytes(a)), kActBf16 ? 1 : 2);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1503,6 +1638,7 @@ __global__ void conv_pack_kernel(const ConvArgs a, const float* __restrict__ w, 
         if (co >= 0 && ci >= 0 && ci < a.cin_total)
             val = co < cout_split ? w[((long long)co * a.cin_total + ci) * 9 + tap]
                                   : w2[((long long)(co - cout_split) * a.cin_total + ci) * 9 + tap];
+        if (kActBf16) val = (float)(__bf16)val;   // bf16 build: every conv weight of the engine is a bf16 value
         wpk[idx] = val;
     }
     const int nb = a.ctiles * 32;
@@ -1527,12 +1663,18 @@ int launch_conv_pack(const ConvArgs& a, const float* w, const float* bias, const
 // |operand| < 65504, guarded by the overflow word, see ConvArgs::ovf).  Strict: plain fp32 MFMA everywhere -- selected per
 // call through ConvArgs::strict (CRFP_DSV_STRICT_F32 of the C-ABI) or for the whole process with CRFP_PRECISION=f32
 // (read once; CRFP_CONV_MODE=f32 / CRFP_DCN_MODE=f32 of round 1 still work).
+#ifndef CRFP_ACT_BF16
+}  // namespace CRFP_NS
+namespace crfp {
 bool precision_env_strict(const char* legacy_knob) {
     const char* p = getenv("CRFP_PRECISION");
     if (p && !strcmp(p, "f32")) return true;
     const char* l = getenv(legacy_knob);
     return l && !strcmp(l, "f32");
 }
+}  // namespace crfp
+namespace CRFP_NS {
+#endif
 
 #ifdef CRFP_LAB
 static const char* lab_conv_mode() { static const char* m = getenv("CRFP_CONV_MODE"); return m ? m : "f16x3"; }
@@ -1542,7 +1684,7 @@ static int lab_knob(const char* k, int dflt) { const char* v = getenv(k); return
 // SRC_S3 sources / s3_dst are understood by conv3x3_split_kernel<1,1,2> (the default) only
 bool conv_s3_supported() {
     static const bool ok = [] {
-        if (precision_env_strict("CRFP_CONV_MODE")) return false;
+        if (kActBf16 || precision_env_strict("CRFP_CONV_MODE")) return false;
 #ifdef CRFP_LAB
         if (strcmp(lab_conv_mode(), "f16x3")) return false;
         if (lab_knob("CRFP_SPLIT_WS", 0) || lab_knob("CRFP_SPLIT_IS", 0) || lab_knob("CRFP_SPLIT_PIPE", 0)) return false;
@@ -1587,7 +1729,7 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     const double px = (double)a.N * a.H * a.W;
     double in_ch = 0;
     for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].kind == SRC_ZERO ? 0 : a.src[i].nch;
-    ProfScope prof(name, s, px * (in_ch + a.cout) * 4.0 + (double)a.cout * in_ch * 9 * 4.0,
+    ProfScope prof(name, s, px * (in_ch + a.cout) * (double)sizeof(act_t) + (double)a.cout * in_ch * 9 * 4.0,
                    2.0 * px * a.cout * in_ch * 9.0);
     ConvArgs& am = const_cast<ConvArgs&>(a);  // callers pass a private, mutable plan copy
     am.stamps = nullptr;
@@ -1606,15 +1748,19 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
                 const ConvSrc& sr = a.src[i];
                 QuadDesc& d = am.qd[q];
                 d.bstride = sr.bstride; d.rsv = 0;
+                // strides and offsets are in FLOATS (4 bytes) for both builds: an activation quad spans kQuadBytes / 4 of them
+                constexpr int QF = kQuadBytes / 4;
                 if (sr.kind == SRC_Q4) {
-                    d.rs = (a.W + sr.pad) * 4; d.cs = 4; d.mask = 15;
+                    d.bstride = sr.bstride * (long long)sizeof(act_t) / 4;
+                    d.rs = (a.W + sr.pad) * QF; d.cs = QF; d.mask = 15;
                     d.base = sr.p + (long long)k * (a.H + sr.pad) * d.rs;
                 } else if (sr.kind == SRC_UNSHUF4) {
                     const int W4 = 4 * a.W + sr.pad, ij = k & 15;
-                    d.rs = 16 * W4; d.cs = 16; d.mask = 15;
-                    d.base = sr.p + ((long long)(k >> 4) * (4 * a.H + sr.pad) * W4 + (ij >> 2) * W4 + (ij & 3)) * 4;
+                    d.bstride = sr.bstride * (long long)sizeof(act_t) / 4;
+                    d.rs = 4 * W4 * QF; d.cs = 4 * QF; d.mask = 15;
+                    d.base = sr.p + ((long long)(k >> 4) * (4 * a.H + sr.pad) * W4 + (ij >> 2) * W4 + (ij & 3)) * QF;
                 } else if (sr.kind == SRC_FLOW2) {
-                    d.rs = 2 * a.W; d.cs = 2; d.mask = 3; d.base = sr.p;
+                    d.rs = 2 * a.W; d.cs = 2; d.mask = kActBf16 ? (32 | 3) : 3; d.base = sr.p;   // bit 5: fp32 (dx, dy) pair
                 } else if (sr.kind == SRC_S3) {
                     // chunk-local quad qi -> 16-byte plane: qi 0/1 = x0 image, channels 0..7 / 8..15 of the chunk; qi 2/3 = x1s image
                     if ((q & 3) != (k & 3) || (sr.nq & 3) || sr.pad) {
@@ -1693,7 +1839,11 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     }
 #endif
     if (split) {
+#ifdef CRFP_ACT_BF16
+        conv3x3_bf16_kernel<1><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
+#else
         conv3x3_split_kernel<1, 1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
+#endif
     } else if (ct2) {
         conv3x3_mfma_kernel<2, 1><<<dim3(tiles * (a.ctiles / 2), 1, a.N), 256, 0, s>>>(a);
     } else {
@@ -1703,4 +1853,4 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     return 0;
 }
 
-}  // namespace crfp
+}  // namespace CRFP_NS

@@ -11,18 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 
-namespace crfp {
+namespace CRFP_NS {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float4 narrow_load(const ConvSrc& s, int n, int kql, int gy, int gx, int H, int W) {
-    const float* base = s.p + (long long)n * s.bstride;
-    if (s.kind == SRC_FLOW2) {
-        const float2 f = *reinterpret_cast<const float2*>(base + ((long long)gy * W + gx) * 2);
-        return make_float4(f.x, f.y, 0.0f, 0.0f);
-    }
-    return *reinterpret_cast<const float4*>(base + (((long long)kql * H + gy) * W + gx) * 4);
-}
 
 __device__ __forceinline__ float n_act(float v, int act) {
     switch (act) {
@@ -56,6 +47,31 @@ __device__ __forceinline__ float n_act(float v, int act) {
 constexpr int NTW = 64, NTH = 16, NLW = NTW + 2, NLH = NTH + 2;
 constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per quad
 
+// raw halo element as it sits in the prefetch registers -> fp32 quad for the LDS tile
+#ifdef CRFP_ACT_BF16
+__device__ __forceinline__ cu32x2 raw_flow(const char* p) { return *reinterpret_cast<const cu32x2*>(p); }
+__device__ __forceinline__ f32x4 raw_to_quad(cu32x2 r, bool flow) {
+    return flow ? f32x4{__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y), 0.0f, 0.0f} : quad_from_bits(r);
+}
+#else
+__device__ __forceinline__ f32x4 raw_flow(const char* p) {
+    const float2 f = *reinterpret_cast<const float2*>(p);
+    return f32x4{f.x, f.y, 0.0f, 0.0f};
+}
+__device__ __forceinline__ f32x4 raw_to_quad(f32x4 r, bool) { return r; }
+#endif
+
+// PyTorch's source index for align_corners=False (same as resample.hip's src_index): the x8 bilinear base of the output
+// head recomputed from the LR frame (NarrowArgs::base_lr) instead of read back from a staged quad
+__device__ __forceinline__ void narrow_src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    i0 = min((int)floorf(src), in_size - 1);
+    i1 = min(i0 + 1, in_size - 1);
+    l1 = fminf(fmaxf(src - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+
 template <int KQ, int EPI>
 __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_NARROW_OCC2 : 2)) void conv3x3_narrow_kernel(const NarrowArgs a) {
     __shared__ float4 tile[KQ][NLH][NLW];
@@ -76,7 +92,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     const int tiles_x = (W + NTW - 1) / NTW, ntiles = tiles_x * ((H + NTH - 1) / NTH);
 
     // ---- everything that comes from the kernel arguments, once
-    const float* qbase[KQ];   // plane of K-quad k of its source
+    const char* qbase[KQ];    // plane of K-quad k of its source (byte pointer: act_t quads, or a float [H][W][2] flow field)
     int qpitch[KQ];           // row pitch in pixels
     bool qflow[KQ];           // [H][W][2] flow field instead of a Q4 plane
 #pragma unroll
@@ -86,7 +102,8 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         const ConvSrc src = a.src[s];
         qflow[k] = src.kind == SRC_FLOW2;
         qpitch[k] = W + src.pad;
-        qbase[k] = src.p + (long long)n * src.bstride + (qflow[k] ? 0 : (long long)kql * (H + src.pad) * qpitch[k] * 4);
+        qbase[k] = qflow[k] ? reinterpret_cast<const char*>(src.p + (long long)n * src.bstride)
+                            : reinterpret_cast<const char*>(as_act(src.p) + (long long)n * src.bstride + (long long)kql * (H + src.pad) * qpitch[k] * 4);
     }
     const float4 bias = *reinterpret_cast<const float4*>(a.bpk);
     const int cout = a.cout, act = a.act;
@@ -94,18 +111,25 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     const float slope = act == CRFP_ACT_RELU ? 0.0f : (act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
     const bool slow_act = act == CRFP_ACT_TANH || act == CRFP_ACT_SIGMOID;
     const float post = a.post_scale;
-    float* const dst = a.dst + (long long)n * a.dst_bstride;
+    float* const dst = a.dst + (long long)n * a.dst_bstride;          // NE_LAST / NE_OFFMASK3: float tensors
+    act_t* const dsta = as_act(a.dst) + (long long)n * a.dst_bstride;   // NE_PLAIN / NE_BLEND: activation (act_t) tensors
     const int dpitch = W + a.dst_pad;                       // Q4 destination may be padded (P4)
-    const float* const resid = a.resid ? a.resid + (long long)n * a.resid_bstride : nullptr;
+    const act_t* const resid = a.resid ? as_act(a.resid) + (long long)n * a.resid_bstride : nullptr;
     const uint8_t* const mask = EPI == NE_BLEND ? a.mask + (long long)n * a.mask_bstride : nullptr;
-    const float* const basep = EPI == NE_LAST ? a.base + (long long)n * a.base_bstride : nullptr;
+    const act_t* const basep = EPI == NE_LAST && a.base ? as_act(a.base) + (long long)n * a.base_bstride : nullptr;
+    const float* const baselr = EPI == NE_LAST && !a.base ? a.base_lr + (long long)n * a.base_bstride : nullptr;
     // fp16-operand range guard (ConvArgs::ovf): the output head turns the frame into NaN once the sticky word is set
     const bool poison = EPI == NE_LAST && a.ovf && *a.ovf != 0;
     float vmax = 0.0f;
     const float* const flowp = EPI == NE_OFFMASK3 ? a.flow + (long long)n * a.flow_bstride : nullptr;
     const bool y_only = a.y_only != 0;
 
-    f32x4 r[KQ][NST];
+#ifdef CRFP_ACT_BF16
+    typedef cu32x2 rawq_t;    // 8 bytes: 4 bf16 of a pixel quad, or the (dx, dy) floats of a flow element
+#else
+    typedef f32x4 rawq_t;
+#endif
+    rawq_t r[KQ][NST];
     bool okr[NST];   // halo element of the tile held in r[] lies inside the image
     // Every load of a tile is issued before anything consumes it, UNCONDITIONALLY at clamped coordinates: a predicated
     // load (`if (inside) r = load`) makes hipcc wait for each load right behind its issue (the select that merges the
@@ -125,13 +149,11 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         }                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < KQ; ++k) {                                                  \
             if (qflow[k]) {   /* wave-uniform */                                                          \
-                _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                         \
-                    const float2 f = *reinterpret_cast<const float2*>(qbase[k] + ((long long)cgy[t] * W + cgx[t]) * 2); \
-                    r[k][t] = f32x4{f.x, f.y, 0.0f, 0.0f};                                                \
-                }                                                                                         \
+                _Pragma("unroll") for (int t = 0; t < NST; ++t)                                           \
+                    r[k][t] = raw_flow(qbase[k] + ((long long)cgy[t] * W + cgx[t]) * 8);                  \
             } else {                                                                                      \
                 _Pragma("unroll") for (int t = 0; t < NST; ++t)                                           \
-                    r[k][t] = *reinterpret_cast<const f32x4*>(qbase[k] + ((long long)cgy[t] * qpitch[k] + cgx[t]) * 4); \
+                    r[k][t] = *reinterpret_cast<const rawq_t*>(qbase[k] + ((long long)cgy[t] * qpitch[k] + cgx[t]) * kQuadBytes); \
             }                                                                                             \
         }                                                                                                 \
     }
@@ -151,7 +173,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
 #pragma unroll
             for (int t = 0; t < NST; ++t) {
                 const int idx = tid + 256 * t;
-                if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = okr[t] ? r[k][t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = okr[t] ? raw_to_quad(r[k][t], qflow[k]) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
         __syncthreads();
         const int t_next = t_cur + t_step;
@@ -223,10 +245,10 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                     for (int o = 0; o < 4; ++o)
                         if (o >= cout) v[o] = 0.0f;
                     if (resid) {
-                        const float4 rv = *reinterpret_cast<const float4*>(resid + pix * 4);
+                        const cf32x4 rv = ldq(resid + pix * 4);
                         v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                     }
-                    *reinterpret_cast<float4*>(dst + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    stq(dsta + dpix * 4, cf32x4{v[0], v[1], v[2], v[3]});
                 } else if (EPI == NE_BLEND) {
                     const float4 centre = tile[0][4 * ty + i + 1][tx + 1];
                     const bool m = mask[pix] != 0;
@@ -235,9 +257,25 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
 #pragma unroll
                     for (int o = 0; o < 4; ++o) v[o] = v[o] > 0.0f ? v[o] : 0.1f * v[o];
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));   // the state feeds a split-fp16 conv
-                    *reinterpret_cast<float4*>(dst + dpix * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    stq(dsta + dpix * 4, cf32x4{v[0], v[1], v[2], v[3]});
                 } else if (EPI == NE_LAST) {
-                    const float4 b = *reinterpret_cast<const float4*>(basep + pix * 4);
+                    cf32x4 b;
+                    if (basep) {
+                        b = ldq(basep + pix * 4);
+                    } else {   // bilinear x8 of the LR frame [3][H/8][W/8], the arithmetic of hr_prep_kernel
+                        const int lh = H >> 3, lw = W >> 3;
+                        int y0, y1, x0, x1;
+                        float ly0, ly1, lx0, lx1;
+                        narrow_src_index(y, 0.125f, lh, y0, y1, ly0, ly1);
+                        narrow_src_index(x, 0.125f, lw, x0, x1, lx0, lx1);
+                        float u[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float* p = baselr + (long long)c * lh * lw;
+                            u[c] = ly0 * (lx0 * p[y0 * lw + x0] + lx1 * p[y0 * lw + x1]) + ly1 * (lx0 * p[y1 * lw + x0] + lx1 * p[y1 * lw + x1]);
+                        }
+                        b = cf32x4{u[0], u[1], u[2], 0.0f};
+                    }
                     const float bad = poison ? __builtin_nanf("") : 0.0f;
                     if (y_only) {
                         dst[pix] = acc[i][0] + (0.299f * b.x + 0.587f * b.y + 0.114f * b.z) + bad;
@@ -281,6 +319,7 @@ __global__ void narrow_pack_kernel(const NarrowArgs a, const float* __restrict__
         if (o < a.cout && ci >= 0 && ci < a.cin_total)
             val = o < cout_split ? w[((long long)o * a.cin_total + ci) * 9 + tap]
                                  : w2[((long long)(o - cout_split) * a.cin_total + ci) * 9 + tap];
+        if (kActBf16) val = (float)(__bf16)val;   // bf16 build: every conv weight of the engine is a bf16 value
         wpk[idx] = val;
     }
     if (blockIdx.x == 0 && threadIdx.x < 4) {
@@ -318,7 +357,7 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     if (a.epi == NE_LAST) extra = 3;                 // base quad (3 used)
     if (a.epi == NE_OFFMASK3) extra = 2;             // flow
     if (a.resid) extra += 4;
-    ProfScope prof(name, s, px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * 4.0,
+    ProfScope prof(name, s, px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * (double)sizeof(act_t),
                    2.0 * px * in_ch * a.cout * 9.0);
     // persistent: a few workgroups per CU walk the tiles (ceil-balanced shares)
     const int ntl = ((a.W + NTW - 1) / NTW) * ((a.H + NTH - 1) / NTH);
@@ -347,4 +386,4 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     return 0;
 }
 
-}  // namespace crfp
+}  // namespace CRFP_NS

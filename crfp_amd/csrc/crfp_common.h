@@ -22,6 +22,9 @@
 // accumulators, bilinear weights, activations), and everything that is a coordinate stays fp32 in memory: flow fields,
 // DCN offsets and masks, the API tensors (lrs / fvs / out).  Pointers in the plan structs stay `const float*` for both
 // builds (opaque: SRC_NCHW / SRC_FLOW2 sources really are float); kernels cast activation pointers to act_t.
+#if defined(CRFP_ACT_BF16) && defined(CRFP_LAB)
+#undef CRFP_LAB   // the lab experiments exist for the fp32 build only
+#endif
 #ifdef CRFP_ACT_BF16
 #define CRFP_NS crfp_bf16
 #define CRFP_API(name) name##_bf16
@@ -41,6 +44,13 @@ struct ProfScope {
 bool prof_enabled();
 bool precision_env_strict(const char* legacy_knob);   // CRFP_PRECISION=f32 (or the round-1 knob) in the environment
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// float-tensor helpers of the fp32 build that the bf16 engine borrows for its float tensors (flow fields, masks)
+int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
+                       int OW, float sh, float sw, float mul, hipStream_t s);
+int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long ob, int N, int H, int W, int r,
+                  hipStream_t s);
+int launch_fg_prep(const uint8_t* fg, float* fg2, int H8, int W8, hipStream_t s);
+int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s);
 }  // namespace crfp
 
 namespace CRFP_NS {
@@ -77,8 +87,8 @@ __device__ __forceinline__ cf32x4 ldq(const act_t* p) { return *reinterpret_cast
 __device__ __forceinline__ void stq(act_t* p, cf32x4 v) { *reinterpret_cast<cf32x4*>(p) = v; }
 #endif
 constexpr int kQuadBytes = 4 * (int)sizeof(act_t);   // bytes of one pixel quad in HBM (16 / 8)
-__device__ __forceinline__ const act_t* as_act(const float* p) { return reinterpret_cast<const act_t*>(p); }
-__device__ __forceinline__ act_t* as_act(float* p) { return reinterpret_cast<act_t*>(p); }
+__host__ __device__ __forceinline__ const act_t* as_act(const float* p) { return reinterpret_cast<const act_t*>(p); }
+__host__ __device__ __forceinline__ act_t* as_act(float* p) { return reinterpret_cast<act_t*>(p); }
 
 // ------------------------------------------------------------------ conv plan
 enum SrcKind : int {
@@ -160,7 +170,7 @@ struct ConvArgs {
     // NaN when the word is set (sticky per clip / stream).  Null: not tracked (per-op API, strict fp32).
     unsigned* ovf;
     int strict;         // 1: plain fp32 MFMA for this launch (CRFP_DSV_STRICT_F32)
-    int rsv2;
+    int dst_f32;        // bf16 build, ST_Q4, one destination: store float quads (FNet's flow output stays fp32)
 };
 
 bool conv_s3_supported();   // the selected conv kernels consume SRC_S3 sources (default f16x3 path of the fp32 build only)
@@ -233,7 +243,8 @@ struct NarrowArgs {
     float* dst;
     const float* resid;
     const float* flow;
-    const float* base;
+    const float* base;     // NE_LAST: Q4 quad holding the x8 bilinear LR (null: recompute it from base_lr)
+    const float* base_lr;  // NE_LAST with base == null: the LR frame [3][H/8][W/8] fp32 (base_bstride applies)
     const uint8_t* mask;
     long long dst_bstride, resid_bstride, flow_bstride, base_bstride, mask_bstride;
     int nsrc, kq, cin_total, cout;

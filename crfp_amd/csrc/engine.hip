@@ -20,7 +20,7 @@
 #include <string>
 #include <vector>
 
-namespace crfp {
+namespace CRFP_NS {
 
 struct ConvDef { const char* stem; int cout, cin; };
 // order == reference state_dict order (weight, bias per entry); checked against the imported
@@ -262,18 +262,20 @@ static const Model& model_for(int y_only, bool strict = false) {
 }
 
 // ------------------------------------------------------------------ workspace arena
-struct Buf { std::string name; size_t off; int N, nq, H, W, kind, pad; size_t bytes, guard; };  // kind 0 = Q4, 1 = NHW2
+struct Buf { std::string name; size_t off; int N, nq, H, W, kind, pad; size_t bytes, guard; bool f32; };  // kind 0 = Q4, 1 = NHW2 (always float)
 struct Arena {
     size_t cur = 0;
     std::vector<Buf> bufs;
     // pad = 1: "P4" planes of (H+1) x (W+1) with zero pad row / column (sources of the gather kernels)
-    size_t take(const char* name, int N, int nq, int H, int W, int kind = 0, int pad = 0) {
-        const size_t floats = kind == 0 ? (size_t)N * nq * (H + pad) * (W + pad) * 4 : (size_t)N * H * W * 2;
+    // f32 = true: a Q4 tensor that stays float in the bf16 build as well (flow, DCN offsets / masks: coordinates)
+    size_t take(const char* name, int N, int nq, int H, int W, int kind = 0, int pad = 0, bool f32 = false) {
+        const size_t elems = kind == 0 ? (size_t)N * nq * (H + pad) * (W + pad) * 4 : (size_t)N * H * W * 2;
+        const size_t esz = (kind == 0 && !f32) ? sizeof(act_t) : sizeof(float);
         // P4 tensors carry a zeroed guard (>= one pad row + one element) in front of plane 0
         const size_t guard = pad ? align_up((size_t)(W + 2) * 16, 256) : 0;
         const size_t off = cur + guard;
-        cur += guard + align_up(floats * sizeof(float), 256);
-        bufs.push_back({name, off, N, nq, H, W, kind, pad, floats * sizeof(float), guard});
+        cur += guard + align_up(elems * esz, 256);
+        bufs.push_back({name, off, N, nq, H, W, kind, pad, elems * esz, guard, kind != 0 || f32});
         return off;
     }
     const Buf* find(size_t off) const {
@@ -286,7 +288,6 @@ struct Q4 {
     float* p = nullptr;
     int nq = 0, H = 0, W = 0;
     long long bs() const { return (long long)nq * H * W * 4; }
-    float* plane(int q) const { return p + (long long)q * H * W * 4; }
 };
 
 struct Layout {
@@ -310,7 +311,7 @@ struct Layout {
         status = A.take("status", 1, 0, 1, 32, 1);   // 256 bytes; word 0 = overflow flag
         state_hr = A.take("state_hr", 1, 1, H8, W8, 0, 1);
         carry = A.take("carry", 1, 6, H2, W2, 0, 1);
-        flow_lr = A.take("flow_lr", nb, 1, h, w);
+        flow_lr = A.take("flow_lr", nb, 1, h, w, 0, 0, true);
         e_lr0 = A.take("enc_lr0", t, 8, h, w);
         x_lr = A.take("x_lr", t, 8, h, w);
         fa0 = A.take("fnet.a0", nb, 8, h, w);
@@ -332,7 +333,7 @@ struct Layout {
         ff1 = A.take("fnet.f1", nb, 16, 4 * h3, 4 * w3);
         fu3 = A.take("fnet.u3", nb, 16, 8 * h3, 8 * w3);
         fg0 = A.take("fnet.g0", nb, 8, 8 * h3, 8 * w3);
-        fg1 = A.take("fnet.g1", nb, 1, 8 * h3, 8 * w3);
+        fg1 = A.take("fnet.g1", nb, 1, 8 * h3, 8 * w3, 0, 0, true);
         // state-independent per-frame work (fovea blend, encoder_hr, upsample conv, flow upsampling) is
         // produced one or two frames ahead on a side stream -> two buffer sets, indexed by frame parity
         for (int p = 0; p < 2; ++p) {
@@ -352,7 +353,7 @@ struct Layout {
         fa = A.take("dcn.fa", 1, 8, H2, W2);
         fb = A.take("dcn.fb", 1, 8, H2, W2);
         for (int l = 0; l < 3; ++l) offfeat[l] = A.take(l == 0 ? "offfeat0" : (l == 1 ? "offfeat1" : "offfeat2"), 1, 8, H2, W2);
-        offmask = A.take("offmask", 1, 54, H2, W2);
+        offmask = A.take("offmask", 1, 54, H2, W2, 0, 0, true);
         aligned = A.take("aligned", 1, 8, H2, W2);
         y0 = A.take("res.y0", 1, 8, H2, W2);
         y1 = A.take("res.y1", 1, 8, H2, W2);
@@ -361,7 +362,7 @@ struct Layout {
         g0 = A.take("dcn3.g0", 1, 1, H8, W8);
         g1 = A.take("dcn3.g1", 1, 1, H8, W8);
         g2 = A.take("dcn3.g2", 1, 1, H8, W8);
-        om3 = A.take("om3", 1, 1, H8, W8);
+        om3 = A.take("om3", 1, 1, H8, W8, 0, 0, true);
         al3 = A.take("aligned3", 1, 1, H8, W8);
         z0 = A.take("res3.z0", 1, 1, H8, W8);
         z1 = A.take("res3.z1", 1, 1, H8, W8);
@@ -432,6 +433,9 @@ struct Runner {
         return strict || env_strict ? nullptr : reinterpret_cast<unsigned*>(ws + L.status);
     }
     float* F(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+    // activation pointers are opaque float* at this level: advance by ELEMENTS of the storage type
+    static float* adv(float* p, long long elems) { return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + elems * (long long)sizeof(act_t)); }
+    static const float* adv(const float* p, long long elems) { return adv(const_cast<float*>(p), elems); }
     Q4 q(size_t off, int nq, int H, int W) const { Q4 r; r.p = F(off); r.nq = nq; r.H = H; r.W = W; return r; }
 
     struct SrcBind { const float* p; long long bs; int pad = 0; };
@@ -440,7 +444,7 @@ struct Runner {
     // s3: the output goes (only, when dsts is empty) to an SRC_S3 image
     void mfma(int id, int N, int H, int W, std::vector<SrcBind> srcs, std::vector<DstBind> dsts, int dstH = 0, int dstW = 0,
               const float* resid = nullptr, long long resid_bs = 0, const float* flow = nullptr, long long flow_bs = 0,
-              float* s3 = nullptr, long long s3_bs = 0) {
+              float* s3 = nullptr, long long s3_bs = 0, int dst_f32 = 0) {
         if (rc) return;
         const Item& it = M.items[id];
         ConvArgs a = it.c;
@@ -452,7 +456,7 @@ struct Runner {
         }
         a.N = N; a.H = H; a.W = W; a.dstH = dstH; a.dstW = dstW;
         a.resid = resid; a.resid_bstride = resid_bs; a.flow = flow; a.flow_bstride = flow_bs;
-        a.s3_dst = s3; a.s3_bstride = s3_bs;
+        a.s3_dst = s3; a.s3_bstride = s3_bs; a.dst_f32 = dst_f32;
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
         a.wsplit = packed + it.off_s;
@@ -466,7 +470,7 @@ struct Runner {
     }
     void narrow(int id, int H, int W, std::vector<const float*> srcs, float* dst, const float* resid = nullptr,
                 const float* flow = nullptr, const float* base = nullptr, const uint8_t* mask = nullptr,
-                int src0_pad = 0, int dst_pad = 0) {
+                int src0_pad = 0, int dst_pad = 0, const float* base_lr = nullptr) {
         if (rc) return;
         const Item& it = M.items[id];
         NarrowArgs a = it.nw;
@@ -474,7 +478,7 @@ struct Runner {
         a.src[0].pad = src0_pad;
         a.dst_pad = dst_pad;
         a.N = 1; a.H = H; a.W = W;
-        a.dst = dst; a.resid = resid; a.flow = flow; a.base = base; a.mask = mask;
+        a.dst = dst; a.resid = resid; a.flow = flow; a.base = base; a.base_lr = base_lr; a.mask = mask;
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
         a.ovf = ovf();
@@ -511,9 +515,10 @@ struct Runner {
         mfma_q(IT_F0 + 11, nb, f0, f1);
         RUN(launch_upsample_q4(f1.p, f1.bs(), u3.p, u3.bs(), nb, 16, f1.H, f1.W, u3.H, u3.W, 0.5f, 0.5f, 1.0f, s));
         mfma_q(IT_F0 + 12, nb, u3, g0);
-        mfma_q(IT_F0 + 13, nb, g0, g1);
-        RUN(launch_upsample_q4(g1.p, g1.bs(), fl.p, fl.bs(), nb, 1, g1.H, g1.W, h, w, (float)g1.H / (float)h,
-                               (float)g1.W / (float)w, 1.0f, s));
+        // tanh * 256 flow and its resize to (h, w) stay float in both builds (coordinates)
+        mfma(IT_F0 + 13, nb, g0.H, g0.W, {{g0.p, g0.bs()}}, {{g1.p, g1.bs(), 0, g1.nq}}, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 1);
+        RUN(crfp::launch_upsample_q4(g1.p, g1.bs(), fl.p, fl.bs(), nb, 1, g1.H, g1.W, h, w, (float)g1.H / (float)h,
+                                     (float)g1.W / (float)w, 1.0f, s));
     }
 
     // zero the P4 buffers (pads must read as 0; also gives the zero initial state)
@@ -545,19 +550,19 @@ struct Runner {
         const long long P8q = (long long)H8 * W8 * 4;
         if (parts & 1) {
             RUN(launch_hr_prep(lr, fv, mk, F(L.xin8[par]), h, w, s));
-            narrow(IT_EH0, H8, W8, {F(L.xin8[par]), F(L.xin8[par]) + P8q}, F(L.eh[par]));
+            narrow(IT_EH0, H8, W8, {F(L.xin8[par]), adv(F(L.xin8[par]), P8q)}, F(L.eh[par]));
             narrow(IT_EH1, H8, W8, {F(L.eh[par])}, F(L.x_hr[par]));
             if (before_ups && !rc && hipStreamWaitEvent(s, before_ups, 0) != hipSuccess) { set_error("dsv: hipStreamWaitEvent failed"); rc = 1; }
             mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0[par]), 0, 0, 6}}, H2, W2);
         }
         if (!first && (parts & 2)) {
-            RUN(launch_upflow(flow_lr_q4, 0, F(L.flow2[par]), 0, 1, h, w, 2, s));
-            RUN(launch_upflow(flow_lr_q4, 0, F(L.flow8[par]), 0, 1, h, w, 8, s));
+            RUN(crfp::launch_upflow(flow_lr_q4, 0, F(L.flow2[par]), 0, 1, h, w, 2, s));
+            RUN(crfp::launch_upflow(flow_lr_q4, 0, F(L.flow8[par]), 0, 1, h, w, 8, s));
         }
     }
 
     // recurrent part of a frame (reference model/CRFP.py:1562-1684)
-    void frame(int par, bool first, const uint8_t* mk, float* out, const uint8_t* fg = nullptr) {
+    void frame(int par, bool first, const float* lr, const uint8_t* mk, float* out, const uint8_t* fg = nullptr) {
         const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         const long long P8q = (long long)H8 * W8 * 4, P2q = (long long)H2 * W2 * 4;
         const long long P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;   // padded (P4) plane at 2x resolution
@@ -572,9 +577,9 @@ struct Runner {
             RUN(launch_flow_warp_p4_dual_8_6(F(L.prev2), carry, flow2, F(L.prev2w), F(L.carryw), H2, W2, s));
             RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, 1, s));
             const float* offprev = nullptr;
-            if (fg) RUN(launch_fg_prep(fg, F(L.fg2), H8, W8, s));
+            if (fg) RUN(crfp::launch_fg_prep(fg, F(L.fg2), H8, W8, s));
             for (int l = 0; l < 3; ++l) {
-                const float* cw = F(L.carryw) + 2 * l * P2q;
+                const float* cw = adv(F(L.carryw), 2 * l * P2q);
                 mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
                      {{F(L.fa), 0, 0, 8}});
                 float* f = F(L.offfeat[l]);
@@ -600,7 +605,7 @@ struct Runner {
                 } else
                     mfma(it_lvl(l, L_RB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.aligned), 0}}, {{F(L.y0), 0, 0, 8}});
                 mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
-                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2qp, 0, 6, 8, 1}}, 0, 0,
+                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {adv(carry, 2 * l * P2qp), 0, 6, 8, 1}}, 0, 0,
                      F(L.y0), 0);
                 prop = prop_next;
                 std::swap(prop_next, prop_other);
@@ -624,7 +629,7 @@ struct Runner {
             for (int l = 0; l < 3; ++l) {
                 mfma(it_lvl(l, L_RB0F), 1, H2, W2, {{prop, 0}, {nullptr, 0}}, {{F(L.y0), 0, 0, 8}});
                 mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
-                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry + 2 * l * P2qp, 0, 6, 8, 1}}, 0, 0,
+                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {adv(carry, 2 * l * P2qp), 0, 6, 8, 1}}, 0, 0,
                      F(L.y0), 0);
                 prop = prop_next;
                 std::swap(prop_next, prop_other);
@@ -635,16 +640,31 @@ struct Runner {
         narrow(IT_R3_1, H8, W8, {F(L.z0)}, F(L.z1));
         narrow(IT_R3_2, H8, W8, {F(L.z1)}, F(L.feat), F(L.z0));
         narrow(IT_TTTF, H8, W8, {F(L.feat), F(L.x_hr[par])}, F(L.state_hr), nullptr, nullptr, nullptr, mk, 0, 1);
-        narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, F(L.xin8[par]) + P8q, nullptr, 1, 0);
+        // output head: conv_last(state) + x8 bilinear LR.  fp32 build: the base quad hr_prep staged; bf16 build: recomputed from
+        // the fp32 LR frame inside the kernel (a bf16 base would cost ~2^-9 of the output range)
+        if (kActBf16) narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, nullptr, nullptr, 1, 0, lr);
+        else narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, adv(F(L.xin8[par]), P8q), nullptr, 1, 0);
     }
 };
 
-}  // namespace crfp
+}  // namespace CRFP_NS
 
-using namespace crfp;
+using namespace CRFP_NS;
+
+#ifdef CRFP_ACT_BF16
+// dcn_3's raw OIHW weights: rounded to bf16 values on the way into the packed buffer (every conv weight of the bf16 engine is one)
+__global__ void round_bf16_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)(__bf16)src[i];
+}
+namespace crfp_bf16 { void shutdown_side_streams() { for (int d = 0; d < kMaxDevices; ++d) g_side[d].destroy(); } }
+#else
+namespace crfp_bf16 { void shutdown_side_streams(); }
+#endif
 
 extern "C" {
 
+#ifndef CRFP_ACT_BF16
 const char* crfp_dsv_param_name(int index) {
     static thread_local std::string s;
     if (index < 0 || index >= CRFP_DSV_NUM_PARAMS) return nullptr;
@@ -658,9 +678,11 @@ int crfp_dsv_param_numel(int index, int y_only) {
     return index % 2 ? co : co * kConvs[ci].cin * 9;
 }
 
-size_t crfp_dsv_packed_weight_bytes(int y_only) { return model_for(y_only).total_floats * sizeof(float); }
+#endif  // parameter table: exported once
 
-int crfp_dsv_pack_weights(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
+size_t CRFP_API(crfp_dsv_packed_weight_bytes)(int y_only) { return model_for(y_only).total_floats * sizeof(float); }
+
+int CRFP_API(crfp_dsv_pack_weights)(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
     const Model& M = model_for(y_only);
     if (!params || !packed) { set_error("pack_weights: null argument"); return CRFP_E_BADARG; }
     if (packed_bytes < M.total_floats * sizeof(float)) { set_error("pack_weights: packed buffer too small"); return CRFP_E_WORKSPACE; }
@@ -684,21 +706,25 @@ int crfp_dsv_pack_weights(const float* const* params, int y_only, void* packed, 
                 break;
             case T_NARROW: rc = launch_narrow_pack(it.nw, w, b, w2, b2, split, pk + it.off_w, pk + it.off_b, s); break;
             case T_DCN8:
-                rc = launch_dcn_g8_pack(w, pk + it.off_w, s, false);
+                if (!kActBf16) rc = launch_dcn_g8_pack(w, pk + it.off_w, s, false);   // fp32 MFMA image (strict mode, fp32 build)
                 if (!rc) rc = launch_dcn_g8_pack(w, pk + it.off_w + 36 * 2 * 32 * 4, s, true);
                 if (!rc && hipMemcpyAsync(pk + it.off_b, b, 32 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
                 break;
             default:
-                if (hipMemcpyAsync(pk + it.off_w, w, it.n_w * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-                    hipMemcpyAsync(pk + it.off_b, b, it.n_b * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-                    rc = 1;
+#ifdef CRFP_ACT_BF16
+                round_bf16_copy_kernel<<<((int)it.n_w + 255) / 256, 256, 0, s>>>(w, pk + it.off_w, (int)it.n_w);
+                if (hipGetLastError() != hipSuccess) rc = 1;
+#else
+                if (hipMemcpyAsync(pk + it.off_w, w, it.n_w * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
+#endif
+                if (!rc && hipMemcpyAsync(pk + it.off_b, b, it.n_b * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = 1;
         }
         if (rc) return rc;
     }
     return 0;
 }
 
-size_t crfp_dsv_workspace_bytes(int t, int h, int w) {
+size_t CRFP_API(crfp_dsv_workspace_bytes)(int t, int h, int w) {
     if (t < 1 || h < 8 || w < 8) return 0;
     return Layout(t, h, w).bytes();
 }
@@ -710,14 +736,15 @@ static int check_common(const void* packed, int t, int h, int w, void* ws, size_
     return 0;
 }
 
-size_t crfp_dsv_status_offset(int t, int h, int w) {
+size_t CRFP_API(crfp_dsv_status_offset)(int t, int h, int w) {
     if (t < 1 || h < 8 || w < 8) return 0;
     return Layout(t, h, w).status;
 }
 
-int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                           float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
     const int y_only = flags & CRFP_DSV_Y_ONLY;
+    if (kActBf16 && (flags & CRFP_DSV_STRICT_F32)) { set_error("dsv (bf16 storage): CRFP_DSV_STRICT_F32 belongs to the fp32 entry points"); return CRFP_E_UNSUPPORTED; }
     Layout L(t, h, w);
     int rc = check_common(packed, t, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
@@ -736,8 +763,8 @@ int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const
         R.encode_lr(t, lrs, lr_f);
         for (int i = 0; i < t && !R.rc; ++i) {
             R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
-                        i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq);
-            R.frame(i & 1, i == 0, mks + i * hr_px, out + (long long)i * co * hr_px);
+                        i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.adv(R.F(L.x_lr), i * xq));
+            R.frame(i & 1, i == 0, lrs + i * lr_f, mks + i * hr_px, out + (long long)i * co * hr_px);
         }
         return R.rc;
     }
@@ -769,22 +796,23 @@ int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const
         if (i == 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
         if (i >= 2 && hipStreamWaitEvent(ss.s, ss.event(3 + 2 * (i - 2)), 0) != hipSuccess) return fail("wait");
         R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
-                    i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.F(L.x_lr) + i * xq, i == 0 ? ev_xlr : nullptr);
+                    i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.adv(R.F(L.x_lr), i * xq), i == 0 ? ev_xlr : nullptr);
         if (hipEventRecord(pre_done, ss.s) != hipSuccess) return fail("record");
         // main: recurrent part of frame i
         R.s = main_s;
         if (hipStreamWaitEvent(main_s, pre_done, 0) != hipSuccess) return fail("wait");
-        R.frame(i & 1, i == 0, mks + i * hr_px, out + (long long)i * co * hr_px);
+        R.frame(i & 1, i == 0, lrs + i * lr_f, mks + i * hr_px, out + (long long)i * co * hr_px);
         if (hipEventRecord(main_done, main_s) != hipSuccess) return fail("record");
     }
     if (R.rc) join();   // a launch failed mid-clip: the last pre_done wait may not have been enqueued
     return R.rc;
 }
 
-int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
+int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
                           const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream) {
     const int y_only = flags & CRFP_DSV_Y_ONLY;
+    if (kActBf16 && (flags & CRFP_DSV_STRICT_F32)) { set_error("dsv (bf16 storage): CRFP_DSV_STRICT_F32 belongs to the fp32 entry points"); return CRFP_E_UNSUPPORTED; }
     Layout L(1, h, w);
     int rc = check_common(packed, 1, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
@@ -798,7 +826,7 @@ int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const 
         if (!first) R.fnet(1, lr, 0, lr_prev, 0);
         R.encode_lr(1, lr, 0);
         R.frame_pre(0, first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr));
-        R.frame(0, first != 0, mk, out, fg);
+        R.frame(0, first != 0, lr, mk, out, fg);
         return R.rc;
     }
     // two streams: FNet (one pair, small launch-latency-bound kernels, 0.45 ms) and the flow up-samplings stay on the
@@ -824,16 +852,19 @@ int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const 
     if (hipEventRecord(ev_side, ss.s) != hipSuccess) return fail("record");
     R.s = main_s;
     if (hipStreamWaitEvent(main_s, ev_side, 0) != hipSuccess) return fail("join");
-    R.frame(0, false, mk, out, fg);
+    R.frame(0, false, lr, mk, out, fg);
     return R.rc;
 }
 
+#ifndef CRFP_ACT_BF16
 int crfp_shutdown(void) {
     for (int d = 0; d < kMaxDevices; ++d) g_side[d].destroy();
+    crfp_bf16::shutdown_side_streams();
     return 0;
 }
+#endif
 
-int crfp_fnet_forward(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
+int CRFP_API(crfp_fnet_forward)(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
                       void* workspace, size_t workspace_bytes, void* stream) {
     Layout L(n + 1, h, w);
     int rc = check_common(packed, n + 1, h, w, workspace, workspace_bytes, L);
@@ -841,11 +872,11 @@ int crfp_fnet_forward(const void* packed, const float* cur, const float* prev, f
     if (!cur || !prev || !flow) { set_error("fnet_forward: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(0), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.fnet(n, cur, 3LL * h * w, prev, 3LL * h * w);
-    if (!R.rc) R.rc = launch_q4_to_nchw(R.F(L.flow_lr), flow, n, 2, h, w, 0, (hipStream_t)stream);
+    if (!R.rc) R.rc = crfp::launch_q4_to_nchw(R.F(L.flow_lr), flow, n, 2, h, w, 0, (hipStream_t)stream);
     return R.rc;
 }
 
-int crfp_dsv_debug_fetch(const char* name, int t, int h, int w, const void* workspace, float* out_nchw, int* c_out,
+int CRFP_API(crfp_dsv_debug_fetch)(const char* name, int t, int h, int w, const void* workspace, float* out_nchw, int* c_out,
                          int* h_out, int* w_out, void* stream) {
     if (!name || !workspace) return CRFP_E_BADARG;
     Layout L(t, h, w);
@@ -856,6 +887,7 @@ int crfp_dsv_debug_fetch(const char* name, int t, int h, int w, const void* work
             if (h_out) *h_out = b.H;
             if (w_out) *w_out = b.W;
             if (!out_nchw) return b.N;
+            if (b.kind == 0 && b.f32) return crfp::launch_q4_to_nchw(p, out_nchw, b.N, b.nq * 4, b.H, b.W, b.pad, (hipStream_t)stream);
             if (b.kind == 0) return launch_q4_to_nchw(p, out_nchw, b.N, b.nq * 4, b.H, b.W, b.pad, (hipStream_t)stream);
             return hipMemcpyAsync(out_nchw, p, (size_t)b.N * b.H * b.W * 2 * sizeof(float), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream) == hipSuccess ? 0 : 1;

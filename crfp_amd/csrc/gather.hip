@@ -12,7 +12,7 @@
 
 #include <cstdlib>
 
-namespace crfp {
+namespace CRFP_NS {
 
 // ---------------------------------------------------------------- flow_warp
 // Coordinate arithmetic restates the reference bit for bit in float32:
@@ -26,6 +26,7 @@ __device__ __forceinline__ float2 ldnt2(const float* p) {
     return make_float2(v.x, v.y);
 }
 
+#ifndef CRFP_ACT_BF16   // unpadded Q4 sources (per-operator API, border mode): fp32 build only
 template <int BORDER>
 __global__ __launch_bounds__(256) void flow_warp_q4_kernel(const float* __restrict__ x, long long xb,
                                                            const float* __restrict__ flow, long long fb,
@@ -77,6 +78,8 @@ __global__ __launch_bounds__(256) void flow_warp_q4_kernel(const float* __restri
     }
 }
 
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -90,9 +93,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CRFP_GATHER_AUX
 #define CRFP_GATHER_AUX 0   // cache-policy bits of the gather loads (gfx942+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
+// one pixel quad (16 bytes of fp32 / 8 bytes of bf16) at byte offset voff + soff; out-of-range reads return 0
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+#ifdef CRFP_ACT_BF16
+    return quad_from_bits(__builtin_bit_cast(cu32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, CRFP_GATHER_AUX)));
+#else
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CRFP_GATHER_AUX));
+#endif
 }
+constexpr int QB = kQuadBytes;   // bytes per pixel quad of a gathered plane
 
 __global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restrict__ x, long long xb,
                                                            const float* __restrict__ flow, long long fb,
@@ -114,19 +123,19 @@ __global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restri
     const float fx = floorf(ix), fy = floorf(iy);
     const float lx = ix - fx, ly = iy - fy, hx = 1.0f - lx, hy = 1.0f - ly;
     const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
-    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
+    const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
     // the descriptor starts one pad row + one element BEFORE plane 0 (zeroed guard that every P4
     // allocation carries) so that (y0,x0) = (-1,-1) is still a non-negative offset
-    const int guard = pitch + 16;
-    const int voff = ((int)fy * PW + (int)fx) * 16 + guard;
+    const int guard = pitch + QB;
+    const int voff = ((int)fy * PW + (int)fx) * QB + guard;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x + (long long)n * xb) - (guard >> 2), 0, nq * plane_b + guard, 0x00020000);
-    float* os = out + (long long)n * ob + pix * 4;
+        (char*)const_cast<act_t*>(as_act(x) + (long long)n * xb) - guard, 0, nq * plane_b + guard, 0x00020000);
+    act_t* os = as_act(out) + (long long)n * ob + pix * 4;
     const long long oplane = (long long)H * W * 4;
     for (int q = 0; q < nq; ++q) {
         const int vo = voff + q * plane_b;
-        const f32x4 a = bload(r, vo, 0), b = bload(r, vo, 16), c = bload(r, vo, pitch), d = bload(r, vo, pitch + 16);
-        *reinterpret_cast<f32x4*>(os + q * oplane) = a * w00 + b * w01 + c * w10 + d * w11;
+        const f32x4 a = bload(r, vo, 0), b = bload(r, vo, QB), c = bload(r, vo, pitch), d = bload(r, vo, pitch + QB);
+        stq(os + q * oplane, a * w00 + b * w01 + c * w10 + d * w11);
     }
 }
 
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restri
 // runtime-nq loop above waits for every quad's four loads before it issues the next four.
 template <int NQ>
 __device__ __forceinline__ void warp_quads(__amdgpu_buffer_rsrc_t r, int voff, int pitch, int plane_b, float w00, float w01,
-                                           float w10, float w11, float* os, long long oplane) {
+                                           float w10, float w11, act_t* os, long long oplane) {
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += 4) {
         constexpr int B = 4;
@@ -145,12 +154,12 @@ __device__ __forceinline__ void warp_quads(__amdgpu_buffer_rsrc_t r, int voff, i
         for (int i = 0; i < B; ++i)
             if (q0 + i < NQ) {
                 const int vo = voff + (q0 + i) * plane_b;
-                a[i] = bload(r, vo, 0); b[i] = bload(r, vo, 16); c[i] = bload(r, vo, pitch); d[i] = bload(r, vo, pitch + 16);
+                a[i] = bload(r, vo, 0); b[i] = bload(r, vo, QB); c[i] = bload(r, vo, pitch); d[i] = bload(r, vo, pitch + QB);
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < B; ++i)
-            if (q0 + i < NQ) *reinterpret_cast<f32x4*>(os + (q0 + i) * oplane) = a[i] * w00 + b[i] * w01 + c[i] * w10 + d[i] * w11;
+            if (q0 + i < NQ) stq(os + (q0 + i) * oplane, a[i] * w00 + b[i] * w01 + c[i] * w10 + d[i] * w11);
     }
 }
 
@@ -173,17 +182,17 @@ __global__ __launch_bounds__(256) void flow_warp_p4_dual_kernel(const float* __r
     const float fx = floorf(ix), fy = floorf(iy);
     const float lx = ix - fx, ly = iy - fy, hx = 1.0f - lx, hy = 1.0f - ly;
     const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
-    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
-    const int guard = pitch + 16;   // see flow_warp_p4_kernel
-    const int voff = ((int)fy * PW + (int)fx) * 16 + guard;
+    const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
+    const int guard = pitch + QB;   // see flow_warp_p4_kernel
+    const int voff = ((int)fy * PW + (int)fx) * QB + guard;
     const long long oplane = (long long)H * W * 4;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xa) - (guard >> 2), 0,
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((char*)const_cast<act_t*>(as_act(xa)) - guard, 0,
                                                                         NQA * plane_b + guard, 0x00020000);
-    warp_quads<NQA>(ra, voff, pitch, plane_b, w00, w01, w10, w11, outa + pix * 4, oplane);
+    warp_quads<NQA>(ra, voff, pitch, plane_b, w00, w01, w10, w11, as_act(outa) + pix * 4, oplane);
     if (NQB > 0) {
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb_) - (guard >> 2), 0,
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((char*)const_cast<act_t*>(as_act(xb_)) - guard, 0,
                                                                             NQB * plane_b + guard, 0x00020000);
-        warp_quads<NQB>(rb, voff, pitch, plane_b, w00, w01, w10, w11, outb + pix * 4, oplane);
+        warp_quads<NQB>(rb, voff, pitch, plane_b, w00, w01, w10, w11, as_act(outb) + pix * 4, oplane);
     }
 }
 
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void flow_warp_p4_dual_kernel(const float* __r
 int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* flow, float* outa, float* outb, int H, int W,
                                  hipStream_t s) {
     const double px = (double)H * W;
-    ProfScope prof("flow_warp_q4_c32+c24", s, px * (2.0 * 14 * 4 + 2) * 4.0, px * 14 * 4 * 7.0);
+    ProfScope prof("flow_warp_q4_c32+c24", s, px * (2.0 * 14 * 4 * sizeof(act_t) + 8), px * 14 * 4 * 7.0);
     flow_warp_p4_dual_kernel<8, 6><<<dim3((W + 63) / 64, (H + 3) / 4, 1), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W);
     CRFP_CHECK_LAUNCH();
     return 0;
@@ -201,21 +210,30 @@ int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long lo
                         int N, int nq, int H, int W, int border, int src_pad, hipStream_t s) {
     const double px = (double)N * H * W;
     ProfScope prof(nq == 1 ? "flow_warp_q4_c4" : (nq == 8 ? "flow_warp_q4_c32" : "flow_warp_q4_c24"), s,
-                   px * (2.0 * nq * 4 + 2) * 4.0, px * nq * 4 * 7.0);
+                   px * (2.0 * nq * 4 * sizeof(act_t) + 8), px * nq * 4 * 7.0);
     dim3 grid((W + 63) / 64, (H + 3) / 4, N);
     if (src_pad && !border)
         flow_warp_p4_kernel<<<grid, 256, 0, s>>>(x, xb, flow, fb, out, ob, nq, H, W);
     else if (src_pad) {
         set_error("flow_warp: border padding on a P4 source is not implemented");
         return CRFP_E_UNSUPPORTED;
-    } else if (border)
+    }
+#ifndef CRFP_ACT_BF16
+    else if (border)
         flow_warp_q4_kernel<1><<<grid, 256, 0, s>>>(x, xb, flow, fb, out, ob, nq, H, W);
     else
         flow_warp_q4_kernel<0><<<grid, 256, 0, s>>>(x, xb, flow, fb, out, ob, nq, H, W);
+#else
+    else {
+        set_error("flow_warp: the bf16 build warps padded (P4) sources only");
+        return CRFP_E_UNSUPPORTED;
+    }
+#endif
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
+#ifndef CRFP_ACT_BF16   // generic / fp32-MFMA DCN kernels of the per-operator API: fp32 build only
 // ---------------------------------------------------------------- DCNv2 sampling helper
 // Published DCNv2 semantics: p = (y - pad + ky*dil + dy, x - pad + kx*dil + dx); value 0 unless
 // -1 < p < size; bilinear with every out-of-range corner contributing 0.
@@ -259,6 +277,8 @@ __device__ __forceinline__ float4 sample_quad(const float* __restrict__ plane, c
     return r;
 }
 
+#endif
+
 // ---------------------------------------------------------------- DCNv2 32->32, 8 deformable groups
 // (dcn_0/1/2 of CRFP_DSV at 2x resolution).  x: Q4 8 quads (quad g = the 4 channels of deformable
 // group g).  offmask: Q4 54 quads = the reference's [offset(144) | mask(72)] channel order:
@@ -277,6 +297,7 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return __builtin_nontemp
 // 32 cycles instead of 8 fp32 MFMAs of 64.  The C-ABI op keeps the fp32 MFMA (F16 = false).
 typedef _Float16 dcn_f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef CRFP_ACT_BF16
 template <int NW, int NP, int MINW, bool F16>
 __global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __restrict__ x, long long xb,
                                                         const float* __restrict__ offmask, long long omb,
@@ -394,6 +415,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __re
     }
 }
 
+#endif   // fp32 build only
+
 // ---------------------------------------------------------------- dcn_g8, software-pipelined (engine path, f16x3)
 // Same mapping as dcn_g8_kernel (wave = 32 pixels of a row, lane half = 4 deformable groups, 36 sampling positions per
 // lane, consumed in 18 pairs), but the 8 corner loads of pair b+1 are issued BEFORE pair b is interpolated, split and
@@ -425,11 +448,11 @@ __device__ __forceinline__ void dcn_issue_pair(DcnPair& P, __amdgpu_buffer_rsrc_
         const float ly = sy - fy, lx = sx - fx;
         const float a = (1.0f - ly) * mmv[pp], b = ly * mmv[pp], hx = 1.0f - lx;
         P.w[pi][0] = a * hx; P.w[pi][1] = a * lx; P.w[pi][2] = b * hx; P.w[pi][3] = b * lx;
-        const int vo = ((int)fy * PW + (int)fx) * 16 + hbase + gi * plane_b;
+        const int vo = ((int)fy * PW + (int)fx) * QB + hbase + gi * plane_b;
         P.q[pi][0] = bload(rx, vo, 0);
-        P.q[pi][1] = bload(rx, vo, 16);
+        P.q[pi][1] = bload(rx, vo, QB);
         P.q[pi][2] = bload(rx, vo, pitch);
-        P.q[pi][3] = bload(rx, vo, pitch + 16);
+        P.q[pi][3] = bload(rx, vo, pitch + QB);
     }
 }
 
@@ -472,10 +495,10 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
     const int cx = min(px, W - 1), cy = min(py, H - 1);
     const long long plane = (long long)H * W * 4;
     const float* om = offmask + (long long)n * omb + ((long long)cy * W + cx) * 4;
-    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
-    const int guard = pitch + 16;  // zeroed guard in front of plane 0 (see flow_warp_p4_kernel)
+    const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
+    const int guard = pitch + QB;  // zeroed guard in front of plane 0 (see flow_warp_p4_kernel)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x + (long long)n * xb) - (guard >> 2), 0, 8 * plane_b + guard, 0x00020000);
+        (char*)const_cast<act_t*>(as_act(x) + (long long)n * xb) - guard, 0, 8 * plane_b + guard, 0x00020000);
     const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
     const int hbase = 4 * h * plane_b + guard;
 
@@ -522,7 +545,7 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
     if (!valid) return;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
-    float* o = out + (long long)n * ob + ((long long)py * W + px) * 4;
+    act_t* o = as_act(out) + (long long)n * ob + ((long long)py * W + px) * 4;
     float vmax = 0.0f;   // fp16-operand range guard (ConvArgs::ovf): the aligned features feed a split-fp16 conv
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -530,12 +553,13 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
         const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * cq);
         const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        *reinterpret_cast<float4*>(o + cq * plane) = v;
+        stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
     }
     if (ovf && !(vmax < 65504.0f)) atomicOr(ovf, 1u);
 }
 
 // wpk[((p36*2 + half)*32 + row)*4 + i] = W[row][4*(4*half + p36/9) + i][p36 % 9]
+#ifndef CRFP_ACT_BF16
 __global__ void dcn_g8_pack_kernel(const float* __restrict__ w, float* __restrict__ wpk) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 36 * 2 * 32 * 4) return;
@@ -543,6 +567,8 @@ __global__ void dcn_g8_pack_kernel(const float* __restrict__ w, float* __restric
     const int ci = 4 * (4 * half + p36 / 9) + i, tap = p36 % 9;
     wpk[idx] = w[(row * 32 + ci) * 9 + tap];
 }
+
+#endif
 
 // f16 image, same 36 864 bytes: wpk16[((u*2 + part)*64 + lane)*8 + i], lane = half*32 + row, i < 4: position 2u, else 2u+1
 __global__ void dcn_g8_pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk) {
@@ -552,7 +578,8 @@ __global__ void dcn_g8_pack16_kernel(const float* __restrict__ w, unsigned short
     const int row = lane & 31, half = lane >> 5;
     const int p36 = 2 * u + (i >> 2), ch = i & 3;
     const int ci = 4 * (4 * half + p36 / 9) + ch, tap = p36 % 9;
-    const float val = w[(row * 32 + ci) * 9 + tap];
+    float val = w[(row * 32 + ci) * 9 + tap];
+    if (kActBf16) val = (float)(__bf16)val;   // bf16 build: weights are bf16 values (same rule for every conv of the engine)
     const _Float16 p0 = (_Float16)val;
     const _Float16 p1 = (_Float16)((val - (float)p0) * 2048.0f);
     wpk[((u * 2 + 0) * 64 + lane) * 8 + i] = __builtin_bit_cast(unsigned short, p0);
@@ -566,8 +593,13 @@ bool dcn_g8_use_f16() {
 
 // f16 = true: the engine's split-fp16 image; false: the fp32 image of the per-op C-ABI
 int launch_dcn_g8_pack(const float* w, float* wpk, hipStream_t s, bool f16) {
+#ifdef CRFP_ACT_BF16
+    if (!f16) { set_error("dcn_g8_pack: the bf16 build has the split-fp16 GEMM only"); return CRFP_E_UNSUPPORTED; }
+    dcn_g8_pack16_kernel<<<(18 * 64 * 8 + 255) / 256, 256, 0, s>>>(w, (unsigned short*)wpk);
+#else
     if (f16) dcn_g8_pack16_kernel<<<(18 * 64 * 8 + 255) / 256, 256, 0, s>>>(w, (unsigned short*)wpk);
     else dcn_g8_pack_kernel<<<(36 * 2 * 32 * 4 + 255) / 256, 256, 0, s>>>(w, wpk);
+#endif
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -575,10 +607,10 @@ int launch_dcn_g8_pack(const float* w, float* wpk, hipStream_t s, bool f16) {
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
                   const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16, unsigned* ovf) {
     const double px = (double)N * H * W;
-    ProfScope prof("dcnv2_g8_c32", s, px * (32 + 144 + 72 + 32) * 4.0 + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
+    ProfScope prof("dcnv2_g8_c32", s, px * ((32 + 32) * sizeof(act_t) + (144 + 72) * 4.0) + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
     // measured 89.1 vs 91.7 us for the software-pipelined kernel (and no gain at all until sched_barrier pinned the gathers
     // ahead of the math): mostly bound by the L1 line rate of the 16-B corner gathers and VALU issue
-#ifdef CRFP_LAB
+#if defined(CRFP_LAB) && !defined(CRFP_ACT_BF16)
     static const int variant = getenv("CRFP_DCN_VARIANT") ? atoi(getenv("CRFP_DCN_VARIANT")) : 3;  // tuning knob (A/B: 3 fastest)
     static const bool pipe = !(getenv("CRFP_DCN_PIPE") && atoi(getenv("CRFP_DCN_PIPE")) == 0);
     if (f16 && !pipe) {
@@ -597,10 +629,15 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
         return 0;
     }
 #endif
+#ifdef CRFP_ACT_BF16
+    if (!f16) { set_error("dcn_g8: the bf16 build has the split-fp16 GEMM only"); return CRFP_E_UNSUPPORTED; }
+    dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf);
+#else
     if (f16)
         dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf);
     else
         dcn_g8_kernel<4, 2, 4, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
+#endif
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -620,10 +657,10 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
     const int cpx = min(px, W - 1), cpy = min(py, H - 1);
     const long long pix = (long long)cpy * W + cpx;
     const f32x4 om = ldg4(offmask3 + (long long)n * omb + pix * 4);   // read once: non-temporal
-    const int PW = W + 1, pitch = PW * 16, plane_b = (H + 1) * pitch;
-    const int guard = pitch + 16;
+    const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
+    const int guard = pitch + QB;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x + (long long)n * xb) - (guard >> 2), 0, plane_b + guard, 0x00020000);
+        (char*)const_cast<act_t*>(as_act(x) + (long long)n * xb) - guard, 0, plane_b + guard, 0x00020000);
     const float fy0 = (float)(cpy - 1), fx0 = (float)(cpx - 1), fH = (float)H, fW = (float)W;
     // per-row / per-column sampling coordinates exactly as the reference forms them per tap:
     // (float)(y - 1 + ky) + dy, clamped into [-1, H] (outside that range the sample is 0 either way)
@@ -643,12 +680,12 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
     // fractional parts stay per row / column (float rounding of y-1+ky+dy differs per ky).
     const bool regular = iy[1] == iy[0] + 1 && iy[2] == iy[0] + 2 && ix[1] == ix[0] + 1 && ix[2] == ix[0] + 2;
     if (__all(regular)) {
-        const int vo = (iy[0] * PW + ix[0]) * 16 + guard;
+        const int vo = (iy[0] * PW + ix[0]) * QB + guard;
         f32x4 nb[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) nb[r][c] = bload(rx, vo, r * pitch + c * 16);
+            for (int c = 0; c < 4; ++c) nb[r][c] = bload(rx, vo, r * pitch + c * QB);
         __builtin_amdgcn_sched_barrier(0);   // all 16 gathers in flight together (hipcc otherwise issues and waits row by row)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -671,8 +708,8 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
             for (int kx = 0; kx < 3; ++kx) {
                 const int tap = ky * 3 + kx;
                 const float hy = 1.0f - ly[ky], hx = 1.0f - lx[kx];
-                const int vo = (iy[ky] * PW + ix[kx]) * 16 + guard;
-                const f32x4 a = bload(rx, vo, 0), b = bload(rx, vo, 16), c = bload(rx, vo, pitch), d = bload(rx, vo, pitch + 16);
+                const int vo = (iy[ky] * PW + ix[kx]) * QB + guard;
+                const f32x4 a = bload(rx, vo, 0), b = bload(rx, vo, QB), c = bload(rx, vo, pitch), d = bload(rx, vo, pitch + QB);
                 const f32x4 v = a * (hy * hx) + b * (hy * lx[kx]) + c * (ly[ky] * hx) + d * (ly[ky] * lx[kx]);
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
@@ -682,8 +719,8 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
             }
     }
     if (!live) return;
-    *reinterpret_cast<float4*>(out + (long long)n * ob + ((long long)py * W + px) * 4) =
-        make_float4(acc[0] * om.z + bias[0], acc[1] * om.z + bias[1], acc[2] * om.z + bias[2], acc[3] * om.z + bias[3]);
+    stq(as_act(out) + (long long)n * ob + ((long long)py * W + px) * 4,
+        cf32x4{acc[0] * om.z + bias[0], acc[1] * om.z + bias[1], acc[2] * om.z + bias[2], acc[3] * om.z + bias[3]});
 }
 
 int launch_dcn3(const float* x, long long xb, const float* offmask3, long long omb, const float* w,
@@ -691,13 +728,14 @@ int launch_dcn3(const float* x, long long xb, const float* offmask3, long long o
     const double px = (double)N * H * W;
     // algorithmic bytes reported BOTH ways in DESIGN.md; the profiler record carries the compact
     // figure (4 in + 2 off + 1 mask + 4 out floats per pixel) that this kernel actually needs
-    ProfScope prof("dcnv2_shared_c4", s, px * (4 + 2 + 1 + 4) * 4.0, px * (2.0 * 4 * 4 * 9 + 36 * 7));
+    ProfScope prof("dcnv2_shared_c4", s, px * ((4 + 4) * sizeof(act_t) + (2 + 1) * 4.0), px * (2.0 * 4 * 4 * 9 + 36 * 7));
     dim3 grid((W + 63) / 64, (H + 3) / 4, N);
     dcn3_kernel<<<grid, 256, 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
+#ifndef CRFP_ACT_BF16
 // ---------------------------------------------------------------- generic DCNv2 (any C / groups), NCHW API tensors
 // One thread per (pixel, output channel block of 4).  Correct for every configuration the dcn_v2
 // module API accepts with k=3,pad=1,dil=1,stride=1; not a tuned path.
@@ -742,5 +780,6 @@ int launch_dcn_generic(const float* x, const float* offset, const float* mask, c
     CRFP_CHECK_LAUNCH();
     return 0;
 }
+#endif
 
-}  // namespace crfp
+}  // namespace CRFP_NS

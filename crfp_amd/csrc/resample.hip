@@ -5,7 +5,7 @@
 // (:1538,1542-1547) and the squared-error reduction behind PSNR (utils.py:166-185,328-330).
 #include "crfp_common.h"
 
-namespace crfp {
+namespace CRFP_NS {
 
 // PyTorch's source index for align_corners=False (area_pixel_compute_source_index + guard):
 //   src = scale*(dst+0.5)-0.5, clamped at 0; i0 = min(floor(src), in-1); i1 = min(i0+1, in-1);
@@ -20,7 +20,7 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
 }
 
 // pad = 1: destination / source planes are (H+1) x (W+1) ("P4"); pads are not touched here
-__global__ void nchw_to_q4_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W, int pad) {
+__global__ void nchw_to_q4_kernel(const float* __restrict__ x, act_t* __restrict__ out, int C, int H, int W, int pad) {
     const long long HW = (long long)H * W, PHW = (long long)(H + pad) * (W + pad);
     const int nq = (C + 3) / 4;
     const long long total = (long long)nq * HW;
@@ -33,12 +33,11 @@ __global__ void nchw_to_q4_kernel(const float* __restrict__ x, float* __restrict
         float v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = 4 * q + c < C ? x[((long long)n * C + 4 * q + c) * HW + pix] : 0.0f;
-        *reinterpret_cast<float4*>(out + (((long long)n * nq + q) * PHW + y * (W + pad) + xx) * 4) =
-            make_float4(v[0], v[1], v[2], v[3]);
+        stq(out + (((long long)n * nq + q) * PHW + y * (W + pad) + xx) * 4, cf32x4{v[0], v[1], v[2], v[3]});
     }
 }
 
-__global__ void q4_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int H, int W, int pad) {
+__global__ void q4_to_nchw_kernel(const act_t* __restrict__ x, float* __restrict__ out, int C, int H, int W, int pad) {
     const long long HW = (long long)H * W, PHW = (long long)(H + pad) * (W + pad);
     const int nq = (C + 3) / 4;
     const long long total = (long long)nq * HW;
@@ -48,7 +47,7 @@ __global__ void q4_to_nchw_kernel(const float* __restrict__ x, float* __restrict
         const int q = (int)(idx / HW);
         const long long pix = idx - (long long)q * HW;
         const long long y = pix / W, xx = pix - y * W;
-        const float4 v = *reinterpret_cast<const float4*>(x + (((long long)n * nq + q) * PHW + y * (W + pad) + xx) * 4);
+        const cf32x4 v = ldq(x + (((long long)n * nq + q) * PHW + y * (W + pad) + xx) * 4);
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -64,7 +63,7 @@ static inline int grid_for(long long total) {
 int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s) {
     const long long total = (long long)((C + 3) / 4) * H * W;
     ProfScope prof("nchw_to_q4", s, (double)N * H * W * (C + 4.0 * ((C + 3) / 4)) * 4.0, 0);
-    nchw_to_q4_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, out, C, H, W, pad);
+    nchw_to_q4_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, as_act(out), C, H, W, pad);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -72,11 +71,12 @@ int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, in
 int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s) {
     const long long total = (long long)((C + 3) / 4) * H * W;
     ProfScope prof("q4_to_nchw", s, (double)N * H * W * (C + 4.0 * ((C + 3) / 4)) * 4.0, 0);
-    q4_to_nchw_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, out, C, H, W, pad);
+    q4_to_nchw_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(as_act(x), out, C, H, W, pad);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
+#ifndef CRFP_ACT_BF16   // per-operator API helper: fp32 build only
 // offset[N,noff,H,W] + mask[N,nmask,H,W] (dcn_v2 API tensors) -> Q4 [offset | mask]
 __global__ void offmask_to_q4_kernel(const float* __restrict__ off, const float* __restrict__ msk,
                                      float* __restrict__ out, int noff, int nmask, int H, int W) {
@@ -107,8 +107,10 @@ int launch_offmask_nchw_to_q4(const float* offset, const float* mask, float* out
     return 0;
 }
 
+#endif
+
 // bilinear resize of a Q4 tensor; out = mul * (l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11))
-__global__ void upsample_q4_kernel(const float* __restrict__ x, long long xb, float* __restrict__ out, long long ob,
+__global__ void upsample_q4_kernel(const act_t* __restrict__ x, long long xb, act_t* __restrict__ out, long long ob,
                                    int nq, int H, int W, int OH, int OW, float sh, float sw, float mul) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -118,28 +120,29 @@ __global__ void upsample_q4_kernel(const float* __restrict__ x, long long xb, fl
     float ly0, ly1, lx0, lx1;
     src_index(oy, sh, H, y0, y1, ly0, ly1);
     src_index(ox, sw, W, x0, x1, lx0, lx1);
-    const float* p = x + (long long)n * xb + (long long)q * H * W * 4;
-    const float4 a = *reinterpret_cast<const float4*>(p + ((long long)y0 * W + x0) * 4);
-    const float4 b = *reinterpret_cast<const float4*>(p + ((long long)y0 * W + x1) * 4);
-    const float4 c = *reinterpret_cast<const float4*>(p + ((long long)y1 * W + x0) * 4);
-    const float4 d = *reinterpret_cast<const float4*>(p + ((long long)y1 * W + x1) * 4);
-    float4 r;
+    const act_t* p = x + (long long)n * xb + (long long)q * H * W * 4;
+    const cf32x4 a = ldq(p + ((long long)y0 * W + x0) * 4);
+    const cf32x4 b = ldq(p + ((long long)y0 * W + x1) * 4);
+    const cf32x4 c = ldq(p + ((long long)y1 * W + x0) * 4);
+    const cf32x4 d = ldq(p + ((long long)y1 * W + x1) * 4);
+    cf32x4 r;
     r.x = mul * (ly0 * (lx0 * a.x + lx1 * b.x) + ly1 * (lx0 * c.x + lx1 * d.x));
     r.y = mul * (ly0 * (lx0 * a.y + lx1 * b.y) + ly1 * (lx0 * c.y + lx1 * d.y));
     r.z = mul * (ly0 * (lx0 * a.z + lx1 * b.z) + ly1 * (lx0 * c.z + lx1 * d.z));
     r.w = mul * (ly0 * (lx0 * a.w + lx1 * b.w) + ly1 * (lx0 * c.w + lx1 * d.w));
-    *reinterpret_cast<float4*>(out + (long long)n * ob + (((long long)q * OH + oy) * OW + ox) * 4) = r;
+    stq(out + (long long)n * ob + (((long long)q * OH + oy) * OW + ox) * 4, r);
 }
 
 int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
                        int OW, float sh, float sw, float mul, hipStream_t s) {
     ProfScope prof("upsample_bilinear_q4", s, (double)N * nq * 16.0 * ((double)H * W + (double)OH * OW), 0);
     dim3 grid((OW + 63) / 64, (OH + 3) / 4, N * nq);
-    upsample_q4_kernel<<<grid, 256, 0, s>>>(x, xb, out, ob, nq, H, W, OH, OW, sh, sw, mul);
+    upsample_q4_kernel<<<grid, 256, 0, s>>>(as_act(x), xb, as_act(out), ob, nq, H, W, OH, OW, sh, sw, mul);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
+#ifndef CRFP_ACT_BF16   // float-only helpers (API tensors, flow fields): compiled once, the bf16 engine calls crfp::launch_upflow
 __global__ void upsample_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int OH,
                                      int OW, float sh, float sw, float mul) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -197,32 +200,34 @@ int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long
     return 0;
 }
 
+#endif
+
 // AvgPool2d(2,2), floor mode: out = (v00 + v01 + v10 + v11) / 4 in that order
-__global__ void avgpool2_q4_kernel(const float* __restrict__ x, long long xb, float* __restrict__ out, long long ob,
+__global__ void avgpool2_q4_kernel(const act_t* __restrict__ x, long long xb, act_t* __restrict__ out, long long ob,
                                    int nq, int H, int W) {
     const int OH = H / 2, OW = W / 2;
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= OW || oy >= OH) return;
     const int q = blockIdx.z % nq, n = blockIdx.z / nq;
-    const float* p = x + (long long)n * xb + (long long)q * H * W * 4;
-    const float4 a = *reinterpret_cast<const float4*>(p + ((long long)(2 * oy) * W + 2 * ox) * 4);
-    const float4 b = *reinterpret_cast<const float4*>(p + ((long long)(2 * oy) * W + 2 * ox + 1) * 4);
-    const float4 c = *reinterpret_cast<const float4*>(p + ((long long)(2 * oy + 1) * W + 2 * ox) * 4);
-    const float4 d = *reinterpret_cast<const float4*>(p + ((long long)(2 * oy + 1) * W + 2 * ox + 1) * 4);
-    float4 r;
+    const act_t* p = x + (long long)n * xb + (long long)q * H * W * 4;
+    const cf32x4 a = ldq(p + ((long long)(2 * oy) * W + 2 * ox) * 4);
+    const cf32x4 b = ldq(p + ((long long)(2 * oy) * W + 2 * ox + 1) * 4);
+    const cf32x4 c = ldq(p + ((long long)(2 * oy + 1) * W + 2 * ox) * 4);
+    const cf32x4 d = ldq(p + ((long long)(2 * oy + 1) * W + 2 * ox + 1) * 4);
+    cf32x4 r;
     r.x = (((a.x + b.x) + c.x) + d.x) / 4.0f;
     r.y = (((a.y + b.y) + c.y) + d.y) / 4.0f;
     r.z = (((a.z + b.z) + c.z) + d.z) / 4.0f;
     r.w = (((a.w + b.w) + c.w) + d.w) / 4.0f;
-    *reinterpret_cast<float4*>(out + (long long)n * ob + (((long long)q * OH + oy) * OW + ox) * 4) = r;
+    stq(out + (long long)n * ob + (((long long)q * OH + oy) * OW + ox) * 4, r);
 }
 
 int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W,
                        hipStream_t s) {
     ProfScope prof("avgpool2_q4", s, (double)N * nq * 16.0 * ((double)H * W * 1.25), 0);
     dim3 grid((W / 2 + 63) / 64, (H / 2 + 3) / 4, N * nq);
-    avgpool2_q4_kernel<<<grid, 256, 0, s>>>(x, xb, out, ob, nq, H, W);
+    avgpool2_q4_kernel<<<grid, 256, 0, s>>>(as_act(x), xb, as_act(out), ob, nq, H, W);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -231,7 +236,7 @@ int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, i
 //   quad 0 = (mk ? fv : up8(lr)) rgb, 0     (fvs*mk + lrs_lv3*(1-mk) with mk in {0,1} is a select)
 //   quad 1 = up8(lr) rgb, 0                 (also the base of the output head)
 __global__ void hr_prep_kernel(const float* __restrict__ lr, const float* __restrict__ fv,
-                               const uint8_t* __restrict__ mk, float* __restrict__ out, int h, int w) {
+                               const uint8_t* __restrict__ mk, act_t* __restrict__ out, int h, int w) {
     const int OH = 8 * h, OW = 8 * w;
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -248,20 +253,21 @@ __global__ void hr_prep_kernel(const float* __restrict__ lr, const float* __rest
     }
     const long long pix = (long long)oy * OW + ox, plane = (long long)OH * OW;
     const bool m = mk[pix] != 0;
-    float4 a = make_float4(u[0], u[1], u[2], 0.0f);
-    if (m) a = make_float4(fv[pix], fv[plane + pix], fv[2 * plane + pix], 0.0f);
-    *reinterpret_cast<float4*>(out + pix * 4) = a;
-    *reinterpret_cast<float4*>(out + (plane + pix) * 4) = make_float4(u[0], u[1], u[2], 0.0f);
+    cf32x4 a = cf32x4{u[0], u[1], u[2], 0.0f};
+    if (m) a = cf32x4{fv[pix], fv[plane + pix], fv[2 * plane + pix], 0.0f};
+    stq(out + pix * 4, a);
+    stq(out + (plane + pix) * 4, cf32x4{u[0], u[1], u[2], 0.0f});
 }
 
 int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s) {
     ProfScope prof("hr_prep_up8_blend", s, (double)64 * h * w * (12 + 1 + 32.0), 0);
     dim3 grid((8 * w + 63) / 64, (8 * h + 3) / 4, 1);
-    hr_prep_kernel<<<grid, 256, 0, s>>>(lr, fv, mk, out_q4, h, w);
+    hr_prep_kernel<<<grid, 256, 0, s>>>(lr, fv, mk, as_act(out_q4), h, w);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
+#ifndef CRFP_ACT_BF16
 // Regional mask of the streaming variant (reference model/CRFP_test.py:2296-2298): fg [8h,8w] (bool) ->
 // nn.Upsample(scale_factor=0.25, bilinear, align_corners=False) = mean of the centre 2x2 of each 4x4 block
 // (source index 4*d + 1.5 -> taps 4d+1, 4d+2 with weight 0.5 each), at 2x resolution.
@@ -282,24 +288,27 @@ int launch_fg_prep(const uint8_t* fg, float* fg2, int H8, int W8, hipStream_t s)
     return 0;
 }
 
-__global__ void scale_q4_kernel(const float* __restrict__ src, int src_pad, float* __restrict__ dst, int H, int W,
+#endif
+
+__global__ void scale_q4_kernel(const act_t* __restrict__ src, int src_pad, act_t* __restrict__ dst, int H, int W,
                                 const float* __restrict__ sf, const uint8_t* __restrict__ su) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), q = blockIdx.z;
     if (x >= W || y >= H) return;
     const long long pix = (long long)y * W + x;
     const float sc = sf ? sf[pix] : (su[pix] ? 1.0f : 0.0f);
-    const float4 v = *reinterpret_cast<const float4*>(src + (((long long)q * (H + src_pad) + y) * (W + src_pad) + x) * 4);
-    *reinterpret_cast<float4*>(dst + ((long long)q * H * W + pix) * 4) = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+    const cf32x4 v = ldq(src + (((long long)q * (H + src_pad) + y) * (W + src_pad) + x) * 4);
+    stq(dst + ((long long)q * H * W + pix) * 4, v * sc);
 }
 
 int launch_scale_q4(const float* src, int src_pad, float* dst, int nq, int H, int W, const float* scale_f,
                     const uint8_t* scale_u8, hipStream_t s) {
     ProfScope prof("scale_q4_fg", s, (double)nq * H * W * 32.0, 0);
-    scale_q4_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, nq), 256, 0, s>>>(src, src_pad, dst, H, W, scale_f, scale_u8);
+    scale_q4_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, nq), 256, 0, s>>>(as_act(src), src_pad, as_act(dst), H, W, scale_f, scale_u8);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
+#ifndef CRFP_ACT_BF16
 // nn.AvgPool2d(2, 2) on NCHW planes (floor mode: a trailing odd row / column is dropped) -- FNet's pooling (model/CRFP.py:755)
 __global__ void avgpool2_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int OH, int OW) {
     const long long plane = blockIdx.y;
@@ -362,5 +371,6 @@ int launch_psnr_partial(const float* a, const float* b, double* acc, int N, int 
     CRFP_CHECK_LAUNCH();
     return 0;
 }
+#endif
 
-}  // namespace crfp
+}  // namespace CRFP_NS

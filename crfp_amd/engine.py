@@ -21,11 +21,17 @@ class DSVEngine:
     fires -- "poison" (default, no host sync: the output frames are NaN and ``overflowed()`` tells why), "fallback"
     (synchronise, rerun the call in strict fp32) or "raise" (FloatingPointError)."""
 
-    def __init__(self, state_dict, device, y_only: bool = False, precision: str = "split", on_overflow: str = "poison"):
-        """state_dict: mapping with the reference's CRFP_DSV keys -> tensors (any device)."""
-        if precision not in ("split", "f32") or on_overflow not in ("poison", "fallback", "raise"):
-            raise ValueError(f"precision {precision!r} / on_overflow {on_overflow!r}")
-        self.precision, self.on_overflow = precision, on_overflow
+    def __init__(self, state_dict, device, y_only: bool = False, precision: str = "split", on_overflow: str = "poison",
+                 storage: str = "f32"):
+        """state_dict: mapping with the reference's CRFP_DSV keys -> tensors (any device).
+        storage: "f32" (default) or "bf16" -- activations and recurrent state held as bf16 in HBM (crfp_dsv_*_bf16 entry
+        points, BASELINE configs 3-5); API tensors, accumulators, flow / offsets / masks stay fp32."""
+        if precision not in ("split", "f32") or on_overflow not in ("poison", "fallback", "raise") or storage not in ("f32", "bf16"):
+            raise ValueError(f"precision {precision!r} / on_overflow {on_overflow!r} / storage {storage!r}")
+        if storage == "bf16" and precision == "f32":
+            raise ValueError("storage='bf16' has one precision (bf16 MFMA operands, fp32 accumulate)")
+        self.precision, self.on_overflow, self.storage = precision, on_overflow, storage
+        self._sfx = "_bf16" if storage == "bf16" else ""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("crfp_amd.DSVEngine needs a CUDA/HIP device (no CPU path in the product)")
@@ -36,6 +42,9 @@ class DSVEngine:
         self._stream_prev_buf = None
         self._stream_hw = None
         self.pack(state_dict)
+
+    def _fn(self, name):
+        return getattr(_lib.lib(), name + self._sfx)
 
     def pack(self, state_dict):
         L = _lib.lib()
@@ -52,17 +61,17 @@ class DSVEngine:
                 raise ValueError(f"parameter {k}: {t.numel()} elements, expected {want}")
             keep.append(t)
             ptrs[i] = t.data_ptr()
-        nbytes = L.crfp_dsv_packed_weight_bytes(self.y_only)
+        nbytes = self._fn("crfp_dsv_packed_weight_bytes")(self.y_only)
         self.packed = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(L.crfp_dsv_pack_weights(ptrs, self.y_only, self.packed.data_ptr(), nbytes, _stream()),
+            _lib.check(self._fn("crfp_dsv_pack_weights")(ptrs, self.y_only, self.packed.data_ptr(), nbytes, _stream()),
                        "crfp_dsv_pack_weights")
             torch.cuda.current_stream().synchronize()   # `keep` may be freed after this point
 
     def _workspace(self, t, h, w):
         key = (t, h, w)
         if key not in self._ws:
-            nb = _lib.lib().crfp_dsv_workspace_bytes(t, h, w)
+            nb = self._fn("crfp_dsv_workspace_bytes")(t, h, w)
             if nb == 0:
                 raise ValueError(f"unsupported clip shape t={t} h={h} w={w}")
             self._ws = {key: torch.empty(nb, dtype=torch.uint8, device=self.device)}  # keep one shape alive
@@ -78,9 +87,8 @@ class DSVEngine:
         strict = (self.precision == "f32") if strict is None else strict
         return self.y_only | (_lib.DSV_STRICT_F32 if strict else 0)
 
-    @staticmethod
-    def _status(ws, t, h, w) -> int:
-        off = _lib.lib().crfp_dsv_status_offset(t, h, w)
+    def _status(self, ws, t, h, w) -> int:
+        off = self._fn("crfp_dsv_status_offset")(t, h, w)
         return int(ws[off:off + 4].view(torch.int32).item())   # synchronises
 
     def overflowed(self, stream: bool = False) -> bool:
@@ -114,7 +122,7 @@ class DSVEngine:
         L = _lib.lib()
 
         def run(b, strict=None):
-            _lib.check(L.crfp_dsv_forward_clip(self.packed.data_ptr(), self._flags(strict), lrs[b].data_ptr(),
+            _lib.check(self._fn("crfp_dsv_forward_clip")(self.packed.data_ptr(), self._flags(strict), lrs[b].data_ptr(),
                                                fvs[b].data_ptr(), mk8[b].data_ptr(), out[b].data_ptr(), t, h, w,
                                                ws.data_ptr(), ws.numel(), _stream()), "crfp_dsv_forward_clip")
 
@@ -136,7 +144,7 @@ class DSVEngine:
         fg8 = None if fg is None else self._mask_u8(fg)
         _, h, w = lr.shape
         if self._stream_ws is None or self._stream_hw != (h, w):
-            nb = _lib.lib().crfp_dsv_workspace_bytes(1, h, w)
+            nb = self._fn("crfp_dsv_workspace_bytes")(1, h, w)
             self._stream_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
             self._stream_hw = (h, w)
             self._stream_prev = None
@@ -145,7 +153,7 @@ class DSVEngine:
         if self.on_overflow == "fallback" and self.precision != "f32":
             raise NotImplementedError("on_overflow='fallback' cannot rewind a streamed sequence: use 'poison' or 'raise'")
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().crfp_dsv_stream_frame(
+            _lib.check(self._fn("crfp_dsv_stream_frame")(
                 self.packed.data_ptr(), self._flags(), lr.data_ptr(),
                 None if first else self._stream_prev.data_ptr(), fv.data_ptr(), mk8.data_ptr(),
                 None if fg8 is None else fg8.data_ptr(), out.data_ptr(),
@@ -167,7 +175,7 @@ class DSVEngine:
         ws = self._workspace(n + 1, h, w)
         flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().crfp_fnet_forward(self.packed.data_ptr(), cur.data_ptr(), prev.data_ptr(),
+            _lib.check(self._fn("crfp_fnet_forward")(self.packed.data_ptr(), cur.data_ptr(), prev.data_ptr(),
                                                     flow.data_ptr(), n, h, w, ws.data_ptr(), ws.numel(), _stream()),
                        "crfp_fnet_forward")
         return flow
@@ -177,12 +185,12 @@ class DSVEngine:
         L = _lib.lib()
         ws = self._workspace(t, h, w)
         c, hh, ww = C.c_int(), C.c_int(), C.c_int()
-        n = L.crfp_dsv_debug_fetch(name.encode(), t, h, w, ws.data_ptr(), None, C.byref(c), C.byref(hh), C.byref(ww),
+        n = self._fn("crfp_dsv_debug_fetch")(name.encode(), t, h, w, ws.data_ptr(), None, C.byref(c), C.byref(hh), C.byref(ww),
                                    _stream())
         if n < 0:
             raise KeyError(name)
         shape = (n, c.value, hh.value, ww.value) if c.value != 2 or "flow" not in name else (n, hh.value, ww.value, 2)
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
-        _lib.check(L.crfp_dsv_debug_fetch(name.encode(), t, h, w, ws.data_ptr(), out.data_ptr(), None, None, None,
+        _lib.check(self._fn("crfp_dsv_debug_fetch")(name.encode(), t, h, w, ws.data_ptr(), out.data_ptr(), None, None, None,
                                           _stream()), "crfp_dsv_debug_fetch")
         return out

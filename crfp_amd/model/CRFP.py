@@ -235,6 +235,7 @@ class CRFP_DSV(nn.Module):
         # numerics policy of the HIP engine (crfp_amd.engine.DSVEngine): not part of the reference's interface
         self.precision = "split"      # "split": split-fp16 MFMA scheme (fp32-grade) | "f32": strict fp32 MFMA
         self.on_overflow = "poison"   # "poison" | "fallback" | "raise" when an activation leaves the fp16 operand range
+        self.storage = "f32"          # "f32" | "bf16": activation / state storage in HBM (BASELINE configs 3-5 are bf16)
 
     # ---- engine management: repack whenever a parameter was modified or moved
     def _signature(self):
@@ -243,8 +244,9 @@ class CRFP_DSV(nn.Module):
     def engine(self) -> DSVEngine:
         dev = next(self.parameters()).device
         sig = self._signature()
-        if self._engine is None or self._engine_sig != sig or self._engine.device != dev:
-            self._engine = DSVEngine(self.state_dict(), dev, self.y_only)
+        if (self._engine is None or self._engine_sig != sig or self._engine.device != dev
+                or self._engine.storage != self.storage):
+            self._engine = DSVEngine(self.state_dict(), dev, self.y_only, storage=self.storage)
             self._engine_sig = sig
         self._engine.precision, self._engine.on_overflow = self.precision, self.on_overflow
         return self._engine

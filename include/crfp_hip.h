@@ -152,6 +152,27 @@ int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const 
                           const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* ---- bf16 storage (BASELINE configs 3-5): the same engine with every activation tensor and the recurrent state held
+ * as bf16 in HBM (half the traffic of the HBM-bound kernels, one bf16 MFMA per product instead of three fp16 ones).
+ * What stays fp32: the API tensors (lrs, fvs, out), all accumulators and interpolation arithmetic, biases, and everything
+ * that is a coordinate -- flow fields, DCN offsets and masks.  Conv / DCN weights are rounded to bf16 once at pack time.
+ * Same arguments as the entry points above; `flags` takes CRFP_DSV_Y_ONLY only.  Packed weights and workspaces are NOT
+ * interchangeable between the two builds (query the *_bf16 sizes).  Numerics: see DESIGN.md section 4 (oracle twin that
+ * rounds at the same points). */
+size_t crfp_dsv_packed_weight_bytes_bf16(int y_only);
+int crfp_dsv_pack_weights_bf16(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+size_t crfp_dsv_workspace_bytes_bf16(int t, int h, int w);
+size_t crfp_dsv_status_offset_bf16(int t, int h, int w);
+int crfp_dsv_forward_clip_bf16(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                               float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+int crfp_dsv_stream_frame_bf16(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
+                               const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int crfp_fnet_forward_bf16(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int crfp_dsv_debug_fetch_bf16(const char* name, int t, int h, int w, const void* workspace, float* out_nchw,
+                              int* c_out, int* h_out, int* w_out, void* stream);
+
 /* FNet alone (compute_flow): pairs cur[n,3,h,w], prev[n,3,h,w] -> flow[n,2,h,w] (NCHW). */
 int crfp_fnet_forward(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
                       void* workspace, size_t workspace_bytes, void* stream);

@@ -30,6 +30,38 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
+# ----------------------------------------------------------------------------- bf16-storage twin
+# BASELINE configs 3-5 run the path with bf16 activation storage.  The reference has no bf16 mode of its own (it would be
+# ``model.bfloat16()`` / autocast, whose rounding points are an implementation detail of ATen), so the twin is defined by
+# the build's storage contract (include/crfp_hip.h, "bf16 storage"): every activation tensor that is
+# written to HBM and the recurrent state are rounded to bf16 (round-to-nearest-even) at the point where the HIP engine
+# stores them; conv / DCN weights are bf16 values; accumulation, interpolation, activations, biases, the API tensors and
+# everything that is a coordinate (flow, DCN offsets, masks) stay fp32.  ``R`` marks those store points below and is the
+# identity unless ``bf16_storage()`` is active, so the fp32 oracle is untouched.
+import contextlib  # noqa: E402
+
+_BF16 = [False]
+
+
+def R(x: Tensor) -> Tensor:
+    """Storage rounding of an activation tensor (identity in the fp32 oracle)."""
+    return x.to(torch.bfloat16).to(torch.float32) if _BF16[0] else x
+
+
+@contextlib.contextmanager
+def bf16_storage():
+    _BF16[0] = True
+    try:
+        yield
+    finally:
+        _BF16[0] = False
+
+
+def bf16_weights(P: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """The twin's parameters: every conv / DCN weight rounded to bf16, biases untouched."""
+    return {k: (v.to(torch.bfloat16).to(torch.float32) if v.dim() == 4 else v) for k, v in P.items()}
+
+
 # ----------------------------------------------------------------------------- primitives
 def conv(P: Dict[str, Tensor], stem: str, x: Tensor) -> Tensor:
     """3x3 stride-1 pad-1 conv with bias (every conv on the path; e.g. model/CRFP.py:48-50)."""
@@ -119,14 +151,14 @@ def fnet(P, pre: str, x1: Tensor, x2: Tensor) -> Tensor:
     _, _, h, w = x1.shape
     o = torch.cat([x1, x2], dim=1)
     for blk in ("encoder1", "encoder2", "encoder3"):
-        o = F.relu(conv(P, f"{pre}{blk}.0", o))
-        o = F.relu(conv(P, f"{pre}{blk}.2", o))
-        o = F.avg_pool2d(o, 2, 2)
+        o = R(F.relu(conv(P, f"{pre}{blk}.0", o)))
+        o = R(F.relu(conv(P, f"{pre}{blk}.2", o)))
+        o = R(F.avg_pool2d(o, 2, 2))
     for blk in ("decoder1", "decoder2", "decoder3"):
-        o = F.relu(conv(P, f"{pre}{blk}.0", o))
-        o = F.relu(conv(P, f"{pre}{blk}.2", o))
-        o = up_bilinear(o, 2)
-    o = conv(P, pre + "flow.2", F.relu(conv(P, pre + "flow.0", o)))
+        o = R(F.relu(conv(P, f"{pre}{blk}.0", o)))
+        o = R(F.relu(conv(P, f"{pre}{blk}.2", o)))
+        o = R(up_bilinear(o, 2))
+    o = conv(P, pre + "flow.2", R(F.relu(conv(P, pre + "flow.0", o))))     # the flow itself stays fp32
     o = torch.tanh(o) * 256
     return F.interpolate(o, size=(h, w), mode="bilinear", align_corners=False)
 
@@ -154,23 +186,25 @@ def pixel_unshuffle_pack_v2(P, pre: str, x: Tensor, r: int) -> Tensor:
 def resblocks_with_input_conv(P, pre: str, x: Tensor) -> Tensor:
     """ResidualBlocksWithInputConv(in,out,1).forward (model/CRFP.py:516-552 + :433-481):
     conv -> LReLU(0.1) -> one ResidualBlockNoBN (x + conv2(ReLU(conv1(x))), res_scale 1)."""
-    x = lrelu(conv(P, pre + "main.0", x))
-    return x + conv(P, pre + "main.2.0.conv2", F.relu(conv(P, pre + "main.2.0.conv1", x)))
+    x = R(lrelu(conv(P, pre + "main.0", x)))
+    return R(x + conv(P, pre + "main.2.0.conv2", R(F.relu(conv(P, pre + "main.2.0.conv1", x)))))
 
 
 def dcn_module(P, pre: str, cur: Tensor, prev: Tensor, prev_warped: Tensor, flow: Tensor,
                pre_offset: Optional[Tensor], *, dg: int, repeat: bool, interpolate: str,
-               max_mag: float = 10.0):
-    """DCN_module.forward (model/CRFP.py:324-352).  Returns (aligned, offset_feature)."""
-    f = torch.cat([cur, prev_warped, flow], dim=1)
-    f = lrelu(conv(P, pre + "dcn_block.0", f))
-    f = lrelu(conv(P, pre + "dcn_block.2", f))
+               max_mag: float = 10.0, flow_is_mfma_operand: bool = True):
+    """DCN_module.forward (model/CRFP.py:324-352).  Returns (aligned, offset_feature).
+    bf16 twin: the flow channels of dcn_block.0's input are an operand of the bf16 MFMA conv at 2x resolution (rounded on
+    the way into LDS); the 8x-resolution dcn_3 runs fp32 stencils on the float flow (flow_is_mfma_operand=False)."""
+    f = torch.cat([cur, prev_warped, R(flow) if flow_is_mfma_operand else flow], dim=1)
+    f = R(lrelu(conv(P, pre + "dcn_block.0", f)))
+    f = R(lrelu(conv(P, pre + "dcn_block.2", f)))
     if pre_offset is not None:
         if interpolate == "pixelshuffle":
-            pre_offset = pixel_shuffle_pack(P, pre + "upsample.", pre_offset, 4) * 2.0
+            pre_offset = R(pixel_shuffle_pack(P, pre + "upsample.", pre_offset, 4) * 2.0)
         elif interpolate == "bilinear":
-            pre_offset = up_bilinear(pre_offset, 4) * 2.0
-        f = lrelu(conv(P, pre + "conv_fuse", torch.cat([f, pre_offset], dim=1)))
+            pre_offset = R(up_bilinear(pre_offset, 4) * 2.0)
+        f = R(lrelu(conv(P, pre + "conv_fuse", torch.cat([f, pre_offset], dim=1))))
     offset = max_mag * torch.tanh(conv(P, pre + "dcn_offset", f))
     mask = torch.sigmoid(conv(P, pre + "dcn_mask", f))
     flow_yx = flow.flip(1)
@@ -181,7 +215,7 @@ def dcn_module(P, pre: str, cur: Tensor, prev: Tensor, prev_warped: Tensor, flow
         mask = mask.repeat(1, 9, 1, 1)
     else:
         offset = offset + flow_yx.repeat(1, offset.shape[1] // 2, 1, 1)
-    out = dcnv2(prev, offset, mask, P[pre + "dcn.weight"], P[pre + "dcn.bias"], dg)
+    out = R(dcnv2(prev, offset, mask, P[pre + "dcn.weight"], P[pre + "dcn.bias"], dg))
     return out, f
 
 
@@ -222,20 +256,20 @@ def dsv_frame(P, cfg: DSVConfig, st, lr: Tensor, fv: Tensor, mk: Tensor, flow: O
     n, _, h, w = lr.shape
     mkf = mk.float()
     lr8 = up_bilinear(lr, 8)                                                  # :1538
-    x_lr = lrelu(conv(P, "encoder_lr.slice1.2", lrelu(conv(P, "encoder_lr.slice1.0", lr))))  # :1540
+    x_lr = R(lrelu(conv(P, "encoder_lr.slice1.2", R(lrelu(conv(P, "encoder_lr.slice1.0", lr))))))  # :1540
     fvb = fv * mkf + lr8 * (1 - mkf)                                          # :1544
-    x_hr = torch.cat((fvb, lr8), dim=1)                                       # :1547
-    x_hr = lrelu(conv(P, "encoder_hr.slice1.2", lrelu(conv(P, "encoder_hr.slice1.0", x_hr))))
+    x_hr = torch.cat((R(fvb), R(lr8)), dim=1)                                 # :1547 (staged as conv input; the head keeps the fp32 lr8)
+    x_hr = R(lrelu(conv(P, "encoder_hr.slice1.2", R(lrelu(conv(P, "encoder_hr.slice1.0", x_hr))))))
 
-    prop = pixel_shuffle_pack(P, "upsample.", x_lr, 2)                        # :1560  [n,24,2h,2w]
+    prop = R(pixel_shuffle_pack(P, "upsample.", x_lr, 2))                     # :1560  [n,24,2h,2w]
     if flow is not None:
         flow2 = up_bilinear(flow, 2) * 2.0                                    # :1565
         flow8 = up_bilinear(flow, 8) * 8.0                                    # :1566
         prev_hr = st["hr"]                                                    # :1568
-        prev2 = pixel_unshuffle_pack_v2(P, "downsample.", prev_hr, 4)         # :1569 [n,32,2h,2w]
-        prev2_w = flow_warp(prev2, flow2.permute(0, 2, 3, 1))                 # :1570
-        prev_hr_w = flow_warp(prev_hr, flow8.permute(0, 2, 3, 1))             # :1571
-        carry = torch.chunk(flow_warp(torch.cat(st["carry"], dim=1), flow2.permute(0, 2, 3, 1)), 3, dim=1)  # :1573-1582
+        prev2 = R(pixel_unshuffle_pack_v2(P, "downsample.", prev_hr, 4))      # :1569 [n,32,2h,2w]
+        prev2_w = R(flow_warp(prev2, flow2.permute(0, 2, 3, 1)))              # :1570
+        prev_hr_w = R(flow_warp(prev_hr, flow8.permute(0, 2, 3, 1)))          # :1571
+        carry = torch.chunk(R(flow_warp(torch.cat(st["carry"], dim=1), flow2.permute(0, 2, 3, 1))), 3, dim=1)  # :1573-1582
         off_feat = None
         new_carry = []
         # streaming variant only (model/CRFP_test.py:2296-2298): regional mask, bilinear x0.25 at 2x res
@@ -246,16 +280,16 @@ def dsv_frame(P, cfg: DSVConfig, st, lr: Tensor, fv: Tensor, mk: Tensor, flow: O
                                            dg=cfg.dg, repeat=False, interpolate="none")
             res_in = torch.cat([cur, aligned], dim=1)
             if fg2 is not None and lvl > 0:     # CRFP_test.py:2361,2375 (the level-0 product :2347 is a no-op)
-                res_in = res_in * fg2
+                res_in = R(res_in * fg2)
             y = resblocks_with_input_conv(P, f"forward_resblocks_{lvl}.", res_in)
             prop, c_new = y[:, :cfg.prop], y[:, cfg.prop:]
             new_carry.append(c_new)
-        up = lrelu(pixel_shuffle_pack(P, "upsample_post.", prop, 4))          # :1625
+        up = R(lrelu(pixel_shuffle_pack(P, "upsample_post.", prop, 4)))       # :1625
         aligned, _ = dcn_module(P, "dcn_3.", up, prev_hr, prev_hr_w, flow8, off_feat,
-                                dg=1, repeat=True, interpolate="pixelshuffle")  # :1626
+                                dg=1, repeat=True, interpolate="pixelshuffle", flow_is_mfma_operand=False)  # :1626
         res_in = torch.cat([up, aligned], dim=1)
         if fg is not None:                      # CRFP_test.py:2389
-            res_in = res_in * fg.float()
+            res_in = R(res_in * fg.float())
         feat = resblocks_with_input_conv(P, "forward_resblocks_3.", res_in)   # :1629-1630
     else:
         zeros2 = lr.new_zeros(n, cfg.mid, 2 * h, 2 * w)
@@ -265,11 +299,11 @@ def dsv_frame(P, cfg: DSVConfig, st, lr: Tensor, fv: Tensor, mk: Tensor, flow: O
                                           torch.cat([prop, zeros2, st["carry"][lvl]], dim=1))
             prop, c_new = y[:, :cfg.prop], y[:, cfg.prop:]
             new_carry.append(c_new)
-        up = lrelu(pixel_shuffle_pack(P, "upsample_post.", prop, 4))          # :1664
+        up = R(lrelu(pixel_shuffle_pack(P, "upsample_post.", prop, 4)))       # :1664
         feat = resblocks_with_input_conv(P, "forward_resblocks_3.", torch.cat([up, st["hr"]], dim=1))  # :1666-1667
 
     fused = conv(P, "conv_tttf", torch.cat([feat, x_hr], dim=1))              # :1672-1673
-    feat = lrelu(mkf * fused + (1 - mkf) * feat)                              # :1674-1675
+    feat = R(lrelu(mkf * fused + (1 - mkf) * feat))                           # :1674-1675 (the new recurrent state)
     out = conv(P, "conv_last", feat)                                          # :1678
     out = out + (up_bilinear(rgb_to_y(lr), 8) if cfg.y_only else lr8)         # :1679-1683
     return out, {"hr": feat, "carry": new_carry, "first": False}

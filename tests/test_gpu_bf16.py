@@ -1,0 +1,190 @@
+"""GPU (-m gpu): the bf16-storage engine (crfp_dsv_*_bf16, BASELINE configs 3-5) against the oracle TWIN that rounds at the
+same points (oracle.bf16_storage(): activations + state to bf16 where the engine stores them, bf16 conv / DCN weights,
+fp32 accumulate / coordinates / API tensors).
+
+Tolerance.  HIP and twin do identical arithmetic up to fp32 summation order, but a value that lands
+within an fp32 round-off of a bf16 rounding boundary can round the other way: one bf16 ulp (2^-8 relative) on isolated
+elements, which the recurrence then carries along.  So the checks are statistical and per tensor: almost every element
+equal or one ulp apart near the inputs, and on the x8 SR frame mean |delta| <= 1e-4, max |delta| <= 2.5e-2 (about twice the
+distance between the twin and the fp32 oracle), PSNR(HIP, twin) >= 70 dB, and HIP no further from the fp32 oracle than
+the twin is (+10 %)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import crfp_oracle
+    return crfp_oracle
+
+
+@pytest.fixture(autouse=True)
+def _nograd():
+    with torch.no_grad():
+        yield
+
+
+def _model(sd_np, y_only=False, cls="CRFP_DSV", storage="bf16"):
+    from crfp_amd.model import CRFP
+    m = getattr(CRFP, cls)(device=dev(), mid_channels=32, y_only=y_only, hr_dcn=True, offset_prop=True)
+    m.load_state_dict({k: T(v.copy()) for k, v in sd_np.items()}, strict=True)
+    m.storage = storage
+    return m.to(dev()).eval()
+
+
+def _stats(got, ref):
+    d = (got.detach().cpu().double() - ref.double()).abs()
+    mse = float((d ** 2).mean())
+    return float(d.max()), float(d.mean()), (99.0 if mse == 0 else -10 * np.log10(mse))
+
+
+def _twin(orc, sd, lrs, fvs, mks, y_only=False):
+    P = orc.load_numpy_state(sd)
+    with orc.bf16_storage():
+        return orc.crfp_dsv_forward(orc.bf16_weights(P), T(lrs), T(fvs), T(mks), orc.DSVConfig(y_only=y_only))
+
+
+def _check_frame_stats(got, twin, ref32, what):
+    mx, mean, psnr = _stats(got, twin)
+    mx32, mean32, psnr32 = _stats(got, ref32)
+    tmx, tmean, tpsnr = _stats(twin, ref32)
+    print(f"{what}: HIP-bf16 vs twin max {mx:.2e} mean {mean:.2e} PSNR {psnr:.1f} dB | vs fp32 oracle max {mx32:.2e} mean {mean32:.2e} "
+          f"PSNR {psnr32:.1f} dB | twin vs fp32 oracle max {tmx:.2e} mean {tmean:.2e} PSNR {tpsnr:.1f} dB")
+    assert torch.isfinite(got).all()
+    assert mean <= 1e-4 and mx <= 2.5e-2 and psnr >= 70.0, (mx, mean, psnr)
+    assert mean32 <= 1.1 * tmean + 1e-6, (mean32, tmean)     # bf16 storage costs what the twin says it costs, no more
+
+
+@pytest.mark.parametrize("h,w,t,fv,y_only", [(24, 40, 4, 64, False), (16, 24, 3, 48, True), (33, 47, 3, 64, False), (17, 65, 2, 48, False)])
+def test_bf16_clip_vs_twin(orc, h, w, t, fv, y_only):
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7, y_only=y_only)
+    lrs, fvs, mks = synth.make_clip(100 + h, 1, t, h, w, fv_size=fv, sigma_t=10.0)
+    m = _model(sd, y_only)
+    d = dev()
+    out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    assert not m.engine().overflowed()
+    twin = _twin(orc, sd, lrs, fvs, mks, y_only)
+    ref32 = orc.crfp_dsv_forward(orc.load_numpy_state(sd), T(lrs), T(fvs), T(mks), orc.DSVConfig(y_only=y_only))
+    _check_frame_stats(out, twin, ref32, f"{t}x{h}x{w}")
+
+
+def test_bf16_intermediates_round_where_the_twin_rounds(orc):
+    """Bisect: tensors close to the inputs must equal the twin's except for isolated one-ulp flips."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    P = orc.bf16_weights(orc.load_numpy_state(sd))
+    t, h, w = 2, 24, 40
+    lrs, fvs, mks = synth.make_clip(3, 1, t, h, w, fv_size=64)
+    m = _model(sd)
+    d = dev()
+    m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    eng = m.engine()
+    with orc.bf16_storage():
+        e0 = orc.R(orc.lrelu(orc.conv(P, "encoder_lr.slice1.0", T(lrs)[0])))
+        x_lr = orc.R(orc.lrelu(orc.conv(P, "encoder_lr.slice1.2", e0)))
+        flow = orc.compute_flow(P, T(lrs))[0]
+    for name, ref, frac_tol in (("enc_lr0", e0, 0.01), ("x_lr", x_lr, 0.03)):
+        got = eng.debug_fetch(name, t, h, w).cpu()
+        assert got.shape == ref.shape
+        assert torch.equal(got.to(torch.bfloat16).float(), got), f"{name} is not bf16-valued"
+        ulp = ref.abs().clamp_min(1e-3) * 2.0 ** -7          # one bf16 ulp is at most 2^-7 of the value
+        diff = (got - ref).abs()
+        assert float((diff > 0).float().mean()) <= frac_tol, (name, float((diff > 0).float().mean()))
+        assert bool((diff <= ulp).all()), (name, float(diff.max()))
+    got_flow = eng.debug_fetch("flow_lr", t, h, w).cpu()[:, :2]
+    assert float((got_flow - flow).abs().max()) < 0.05          # pixels; fp32 tensor, bf16 trunk in front of tanh*256
+
+
+def test_bf16_streaming_equals_clip_and_survives_buffer_reuse():
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    h, w, t = 16, 24, 4
+    lrs, fvs, mks = synth.make_clip(5, 1, t, h, w, fv_size=48)
+    d = dev()
+    L, Fv, M = T(lrs).to(d), T(fvs).to(d), T(mks).to(d)
+    clip = _model(sd)(lrs=L, fvs=Fv, mks=M)
+    ms = _model(sd, cls="MRCF_simple_v18")
+    ms.clear_states()
+    lb = torch.empty_like(L[:, :1])
+    outs = []
+    for i in range(t):
+        lb.copy_(L[:, i:i + 1])
+        outs.append(ms(lb, Fv[:, i:i + 1], M[:, i:i + 1]).clone())
+    assert float((torch.cat(outs, dim=1) - clip).abs().max()) == 0.0
+
+
+def test_bf16_fp32_storage_are_separate_engines():
+    """Switching `storage` repacks; the fp32 result is untouched by the bf16 engine having run."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    lrs, fvs, mks = synth.make_clip(5, 1, 2, 16, 24, fv_size=48)
+    d = dev()
+    a = dict(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    m = _model(sd, storage="f32")
+    ref = m(**a).clone()
+    m.storage = "bf16"
+    b = m(**a).clone()
+    m.storage = "f32"
+    again = m(**a)
+    assert torch.equal(again, ref) and not torch.equal(b, ref)
+    assert float((b - ref).abs().max()) < 5e-2
+
+
+def test_bf16_config5_geometry_vs_twin(orc):
+    """BASELINE config 5 geometry (270x480 -> 2160x3840, 144 px fovea), 2 frames, bf16 storage, against the twin."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    lrs, fvs, mks = synth.make_clip(77, 1, 2, 270, 480, fv_size=144, sigma_t=10.0)
+    m = _model(sd)
+    d = dev()
+    out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    twin = _twin(orc, sd, lrs, fvs, mks)
+    ref32 = orc.crfp_dsv_forward(orc.load_numpy_state(sd), T(lrs), T(fvs), T(mks))
+    _check_frame_stats(out, twin, ref32, "config 5 geometry, 2 frames")
+
+
+def test_bf16_stream_100_calls_sigma50_vs_twin(orc):
+    """BASELINE config 3 as stated: 100 streamed calls, bf16 storage, sigma^T = 50, against the streaming twin (45x80 LR
+    to keep the oracle affordable); the error must not grow along the sequence."""
+    from crfp_amd import gaze, synth
+    import torch.nn.functional as F
+    sd = synth.make_state_dict(7)
+    P = orc.bf16_weights(orc.load_numpy_state(sd))
+    h, w, N, fv = 45, 80, 100, 96
+    lrs = np.concatenate([synth.make_clip(1234 + i, 1, 10, h, w, fv_size=fv)[0][0] for i in range(0, N, 10)], 0)
+    lr = T(lrs)
+    rs = np.random.RandomState(9)
+    gt = torch.clamp(F.interpolate(lr, scale_factor=8, mode="bilinear", align_corners=False) +
+                     T(rs.normal(0, 0.03, (N, 3, 8 * h, 8 * w)).astype(np.float32)), 0, 1)
+    H, W = 8 * h, 8 * w
+    xs, ys = gaze.gaze_trajectory(N, H, W, 50.0, np.random.RandomState(1234))
+    masks = gaze.RegionMasks(H, W, fv, torch.device("cpu"))
+    m = _model(sd, cls="MRCF_simple_v18")
+    m.clear_states()
+    d = dev()
+    means, maxs = [], []
+    with orc.bf16_storage():
+        so = orc.StreamOracle(P)
+        for n in range(N):
+            cy, cx = gaze.window_origin(xs[n], ys[n], fv, H, W)
+            mk = masks.frame(n, cy, cx)["mk"]
+            f = gt[n:n + 1] * mk
+            ref = so(lr[n:n + 1].unsqueeze(0), f.unsqueeze(0), mk.unsqueeze(0))
+            got = m(lrs=lr[n:n + 1].unsqueeze(0).to(d), fvs=f.unsqueeze(0).to(d), mks=mk.unsqueeze(0).to(d)).cpu()
+            dd = (got - ref).abs()
+            means.append(float(dd.mean())); maxs.append(float(dd.max()))
+    curve = [float(np.mean(means[i:i + 10])) for i in range(0, N, 10)]
+    print("bf16 stream drift, mean|HIP - twin| per 10 calls:", " ".join(f"{v:.2e}" for v in curve), "| max over all:", f"{max(maxs):.2e}")
+    assert max(means) <= 2e-4 and max(maxs) <= 5e-2
+    assert np.mean(means[50:]) <= 2.0 * np.mean(means[5:50]) + 1e-6
