@@ -176,7 +176,10 @@ __device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
 #pragma unroll
     for (int d = 0; d < CRFP_MAX_DST; ++d) {
         const bool on = d < a.ndst;
-        e.dp[d] = a.dst[d].p + (long long)n * a.dst[d].bstride;
+        // batch stride counts ELEMENTS of the destination's storage type (float for offsets / masks / flow / NCHW planes)
+        const bool fdst = a.store == ST_OFFMASK || a.store == ST_NCHW || a.dst_f32;
+        e.dp[d] = fdst ? a.dst[d].p + (long long)n * a.dst[d].bstride
+                       : reinterpret_cast<float*>(as_act(a.dst[d].p) + (long long)n * a.dst[d].bstride);
         e.dpitch[d] = a.W + a.dst[d].pad;
         e.dplane[d] = (long long)(a.H + a.dst[d].pad) * e.dpitch[d] * 4;
         e.dq0[d] = on ? a.dst[d].q0 : 0;
@@ -868,7 +871,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 // one raw 8-byte K-quad -> its two packed bf16 words; m = component mask (bit 5: fp32 (dx, dy) pair)
 __device__ __forceinline__ cu32x2 quad_words(cu32x2 r, int m, bool valid) {
     if (!valid) return cu32x2{0u, 0u};
-    if (m & 32) return cu32x2{pack_bf16x2(__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y)), 0u};
+    if (m & 32) {   // (per-component bit casts of r.x / r.y were folded into pack(x, x) by hipcc 7.2: cast the whole pair)
+        typedef __bf16 h2_t __attribute__((ext_vector_type(2)));
+        return cu32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_bit_cast(cf32x2, r), h2_t)), 0u};
+    }
     const unsigned k0 = ((m & 1) ? 0x0000ffffu : 0u) | ((m & 2) ? 0xffff0000u : 0u);
     const unsigned k1 = ((m & 4) ? 0x0000ffffu : 0u) | ((m & 8) ? 0xffff0000u : 0u);
     return cu32x2{r.x & k0, r.y & k1};

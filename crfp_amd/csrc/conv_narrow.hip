@@ -51,7 +51,8 @@ constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per 
 #ifdef CRFP_ACT_BF16
 __device__ __forceinline__ cu32x2 raw_flow(const char* p) { return *reinterpret_cast<const cu32x2*>(p); }
 __device__ __forceinline__ f32x4 raw_to_quad(cu32x2 r, bool flow) {
-    return flow ? f32x4{__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y), 0.0f, 0.0f} : quad_from_bits(r);
+    const cf32x2 fl = __builtin_bit_cast(cf32x2, r);   // whole-pair cast (see quad_words in conv_mfma.hip)
+    return flow ? f32x4{fl.x, fl.y, 0.0f, 0.0f} : quad_from_bits(r);
 }
 #else
 __device__ __forceinline__ f32x4 raw_flow(const char* p) {

@@ -57,6 +57,25 @@ def bf16_storage():
         _BF16[0] = False
 
 
+_TAP = [None]
+
+
+@contextlib.contextmanager
+def tapping(store: dict):
+    """Record named intermediates of dsv_frame (names = workspace buffers of the engine, crfp_dsv_debug_fetch) for bisecting."""
+    _TAP[0] = store
+    try:
+        yield store
+    finally:
+        _TAP[0] = None
+
+
+def tap(name: str, x: Tensor) -> Tensor:
+    if _TAP[0] is not None:
+        _TAP[0][name] = x.detach().clone()
+    return x
+
+
 def bf16_weights(P: Dict[str, Tensor]) -> Dict[str, Tensor]:
     """The twin's parameters: every conv / DCN weight rounded to bf16, biases untouched."""
     return {k: (v.to(torch.bfloat16).to(torch.float32) if v.dim() == 4 else v) for k, v in P.items()}
@@ -197,14 +216,15 @@ def dcn_module(P, pre: str, cur: Tensor, prev: Tensor, prev_warped: Tensor, flow
     bf16 twin: the flow channels of dcn_block.0's input are an operand of the bf16 MFMA conv at 2x resolution (rounded on
     the way into LDS); the 8x-resolution dcn_3 runs fp32 stencils on the float flow (flow_is_mfma_operand=False)."""
     f = torch.cat([cur, prev_warped, R(flow) if flow_is_mfma_operand else flow], dim=1)
-    f = R(lrelu(conv(P, pre + "dcn_block.0", f)))
-    f = R(lrelu(conv(P, pre + "dcn_block.2", f)))
+    f = tap(pre + "block0", R(lrelu(conv(P, pre + "dcn_block.0", f))))
+    f = tap(pre + "block2", R(lrelu(conv(P, pre + "dcn_block.2", f))))
     if pre_offset is not None:
         if interpolate == "pixelshuffle":
             pre_offset = R(pixel_shuffle_pack(P, pre + "upsample.", pre_offset, 4) * 2.0)
         elif interpolate == "bilinear":
             pre_offset = R(up_bilinear(pre_offset, 4) * 2.0)
-        f = R(lrelu(conv(P, pre + "conv_fuse", torch.cat([f, pre_offset], dim=1))))
+        tap(pre + "pre_offset", pre_offset)
+        f = tap(pre + "fuse", R(lrelu(conv(P, pre + "conv_fuse", torch.cat([f, pre_offset], dim=1)))))
     offset = max_mag * torch.tanh(conv(P, pre + "dcn_offset", f))
     mask = torch.sigmoid(conv(P, pre + "dcn_mask", f))
     flow_yx = flow.flip(1)
@@ -215,7 +235,9 @@ def dcn_module(P, pre: str, cur: Tensor, prev: Tensor, prev_warped: Tensor, flow
         mask = mask.repeat(1, 9, 1, 1)
     else:
         offset = offset + flow_yx.repeat(1, offset.shape[1] // 2, 1, 1)
-    out = R(dcnv2(prev, offset, mask, P[pre + "dcn.weight"], P[pre + "dcn.bias"], dg))
+    tap(pre + "offset", offset)
+    tap(pre + "mask", mask)
+    out = tap(pre + "aligned", R(dcnv2(prev, offset, mask, P[pre + "dcn.weight"], P[pre + "dcn.bias"], dg)))
     return out, f
 
 
@@ -256,20 +278,22 @@ def dsv_frame(P, cfg: DSVConfig, st, lr: Tensor, fv: Tensor, mk: Tensor, flow: O
     n, _, h, w = lr.shape
     mkf = mk.float()
     lr8 = up_bilinear(lr, 8)                                                  # :1538
-    x_lr = R(lrelu(conv(P, "encoder_lr.slice1.2", R(lrelu(conv(P, "encoder_lr.slice1.0", lr))))))  # :1540
+    x_lr = tap("x_lr", R(lrelu(conv(P, "encoder_lr.slice1.2", R(lrelu(conv(P, "encoder_lr.slice1.0", lr)))))))  # :1540
     fvb = fv * mkf + lr8 * (1 - mkf)                                          # :1544
     x_hr = torch.cat((R(fvb), R(lr8)), dim=1)                                 # :1547 (staged as conv input; the head keeps the fp32 lr8)
-    x_hr = R(lrelu(conv(P, "encoder_hr.slice1.2", R(lrelu(conv(P, "encoder_hr.slice1.0", x_hr))))))
+    tap("xin8", x_hr)
+    x_hr = tap("x_hr", R(lrelu(conv(P, "encoder_hr.slice1.2", tap("enc_hr0", R(lrelu(conv(P, "encoder_hr.slice1.0", x_hr))))))))
 
-    prop = R(pixel_shuffle_pack(P, "upsample.", x_lr, 2))                     # :1560  [n,24,2h,2w]
+    prop = tap("prop0", R(pixel_shuffle_pack(P, "upsample.", x_lr, 2)))       # :1560  [n,24,2h,2w]
     if flow is not None:
         flow2 = up_bilinear(flow, 2) * 2.0                                    # :1565
         flow8 = up_bilinear(flow, 8) * 8.0                                    # :1566
         prev_hr = st["hr"]                                                    # :1568
-        prev2 = R(pixel_unshuffle_pack_v2(P, "downsample.", prev_hr, 4))      # :1569 [n,32,2h,2w]
-        prev2_w = R(flow_warp(prev2, flow2.permute(0, 2, 3, 1)))              # :1570
-        prev_hr_w = R(flow_warp(prev_hr, flow8.permute(0, 2, 3, 1)))          # :1571
-        carry = torch.chunk(R(flow_warp(torch.cat(st["carry"], dim=1), flow2.permute(0, 2, 3, 1))), 3, dim=1)  # :1573-1582
+        tap("flow2", flow2.permute(0, 2, 3, 1))
+        prev2 = tap("prev2", R(pixel_unshuffle_pack_v2(P, "downsample.", prev_hr, 4)))   # :1569 [n,32,2h,2w]
+        prev2_w = tap("prev2w", R(flow_warp(prev2, flow2.permute(0, 2, 3, 1))))          # :1570
+        prev_hr_w = tap("prevhrw", R(flow_warp(prev_hr, flow8.permute(0, 2, 3, 1))))     # :1571
+        carry = torch.chunk(tap("carryw", R(flow_warp(torch.cat(st["carry"], dim=1), flow2.permute(0, 2, 3, 1)))), 3, dim=1)  # :1573-1582
         off_feat = None
         new_carry = []
         # streaming variant only (model/CRFP_test.py:2296-2298): regional mask, bilinear x0.25 at 2x res
@@ -281,16 +305,16 @@ def dsv_frame(P, cfg: DSVConfig, st, lr: Tensor, fv: Tensor, mk: Tensor, flow: O
             res_in = torch.cat([cur, aligned], dim=1)
             if fg2 is not None and lvl > 0:     # CRFP_test.py:2361,2375 (the level-0 product :2347 is a no-op)
                 res_in = R(res_in * fg2)
-            y = resblocks_with_input_conv(P, f"forward_resblocks_{lvl}.", res_in)
+            y = tap(f"res{lvl}", resblocks_with_input_conv(P, f"forward_resblocks_{lvl}.", res_in))
             prop, c_new = y[:, :cfg.prop], y[:, cfg.prop:]
             new_carry.append(c_new)
-        up = R(lrelu(pixel_shuffle_pack(P, "upsample_post.", prop, 4)))       # :1625
+        up = tap("up", R(lrelu(pixel_shuffle_pack(P, "upsample_post.", prop, 4))))       # :1625
         aligned, _ = dcn_module(P, "dcn_3.", up, prev_hr, prev_hr_w, flow8, off_feat,
                                 dg=1, repeat=True, interpolate="pixelshuffle", flow_is_mfma_operand=False)  # :1626
         res_in = torch.cat([up, aligned], dim=1)
         if fg is not None:                      # CRFP_test.py:2389
             res_in = R(res_in * fg.float())
-        feat = resblocks_with_input_conv(P, "forward_resblocks_3.", res_in)   # :1629-1630
+        feat = tap("feat", resblocks_with_input_conv(P, "forward_resblocks_3.", res_in))   # :1629-1630
     else:
         zeros2 = lr.new_zeros(n, cfg.mid, 2 * h, 2 * w)
         new_carry = []
@@ -303,7 +327,7 @@ def dsv_frame(P, cfg: DSVConfig, st, lr: Tensor, fv: Tensor, mk: Tensor, flow: O
         feat = resblocks_with_input_conv(P, "forward_resblocks_3.", torch.cat([up, st["hr"]], dim=1))  # :1666-1667
 
     fused = conv(P, "conv_tttf", torch.cat([feat, x_hr], dim=1))              # :1672-1673
-    feat = R(lrelu(mkf * fused + (1 - mkf) * feat))                           # :1674-1675 (the new recurrent state)
+    feat = tap("state_hr", R(lrelu(mkf * fused + (1 - mkf) * feat)))          # :1674-1675 (the new recurrent state)
     out = conv(P, "conv_last", feat)                                          # :1678
     out = out + (up_bilinear(rgb_to_y(lr), 8) if cfg.y_only else lr8)         # :1679-1683
     return out, {"hr": feat, "carry": new_carry, "first": False}
