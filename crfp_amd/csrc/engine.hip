@@ -578,9 +578,7 @@ struct Runner {
             RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, 1, s));
             const float* offprev = nullptr;
             if (fg) RUN(crfp::launch_fg_prep(fg, F(L.fg2), H8, W8, s));
-            static const int dbg_levels = getenv("CRFP_DEBUG_LEVELS") ? atoi(getenv("CRFP_DEBUG_LEVELS")) : 3;   // TEMP-DEBUG
-            if (getenv("CRFP_DEBUG_ZERO_FLOW")) (void)hipMemsetD32Async((hipDeviceptr_t)flow2, atoi(getenv("CRFP_DEBUG_ZERO_FLOW")) == 2 ? 0x3f800000 : 0, (size_t)H2 * W2 * 2, s);   // TEMP-DEBUG
-            for (int l = 0; l < dbg_levels; ++l) {
+            for (int l = 0; l < 3; ++l) {
                 const float* cw = adv(F(L.carryw), 2 * l * P2q);
                 mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
                      {{F(L.fa), 0, 0, 8}});

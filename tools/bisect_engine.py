@@ -66,21 +66,6 @@ if a.storage == "bf16":   # fp32 build: these hold the producer-split S3 image, 
     show("offfeat0 (lvl0 block2)", f("offfeat0"), taps["dcn_0.block2"])
     show("offfeat1 (lvl1 fuse)", f("offfeat1"), taps["dcn_1.fuse"])
     show("offfeat2 (lvl2 fuse)", f("offfeat2"), taps["dcn_2.fuse"])
-lv = int(os.environ.get("CRFP_DEBUG_LEVELS", "3")) - 1
-got_fa, ref_fa = f("dcn.fa"), taps[f"dcn_{lv}.block0"]
-show(f"dcn.fa (lvl{lv} block0)", got_fa, ref_fa)
-for q in range(8):
-    dd = (got_fa[:, 4 * q:4 * q + 4].cpu() - ref_fa[:, 4 * q:4 * q + 4]).abs()
-    print(f"   quad {q}: max {float(dd.max()):.3e} mean {float(dd.mean()):.3e}; rows with err>0.05: {sorted(set(torch.nonzero(dd > 0.05)[:, 2].tolist()))[:12]} cols: {sorted(set(torch.nonzero(dd > 0.05)[:, 3].tolist()))[:12]}")
-if lv == 0 and a.storage == "bf16":   # which variant of level-0 block0 does the engine compute?
-    with orc.bf16_storage():
-        prop0, cwv, p2w, fl2 = taps["prop0"], taps["carryw"][:, :8], taps["prev2w"], taps["flow2"].permute(0, 3, 1, 2)
-        for tag, fl in (("flow rounded", orc.R(fl2)), ("flow = 0", fl2 * 0), ("flow = 1", fl2 * 0 + 1), ("flow = (1,0)", torch.cat([fl2[:, :1] * 0 + 1, fl2[:, 1:] * 0], 1)), ("flow = (0,1)", torch.cat([fl2[:, :1] * 0, fl2[:, 1:] * 0 + 1], 1)), ("flow fp32", fl2), ("flow swapped", orc.R(fl2.flip(1)))):
-            v = orc.R(orc.lrelu(orc.conv(P, "dcn_0.dcn_block.0", torch.cat([prop0, cwv, p2w, fl], 1))))
-            show(f"   variant {tag}", got_fa, v)
-        for tag, parts in (("no prop", [prop0 * 0, cwv, p2w, orc.R(fl2)]), ("no carry", [prop0, cwv * 0, p2w, orc.R(fl2)]), ("no warped", [prop0, cwv, p2w * 0, orc.R(fl2)])):
-            v = orc.R(orc.lrelu(orc.conv(P, "dcn_0.dcn_block.0", torch.cat(parts, 1))))
-            show(f"   variant {tag}", got_fa, v)
 show("dcn.fa (lvl2 block0)", f("dcn.fa"), taps["dcn_2.block0"])
 show("dcn.fb (lvl2 block2)", f("dcn.fb"), taps["dcn_2.block2"])
 om = f("offmask")
