@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: SR frames/s of the CRFP_DSV recurrent x8 path on synthetic 7-frame
-180x320 -> 1440x2560 clips (BASELINE.json configs[1]), one process per GPU.
+"""Benchmark of the CRFP_DSV recurrent x8 path on MI355X: SR frames/s (BASELINE.json `metric`), one process per GPU.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py                                   # headline: BASELINE configs[1], N = 1
+  python bench.py --config 3|4|5                    # the bf16 configs (streaming 100 frames / 4 clips per GPU / 4K)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus 8 --steps 20 --warmup 3
+         bench.py --gpus 8 --steps 20 --warmup 3 [--config 4]
 
-A step = one clip (7 frames) per rank through crfp_dsv_forward_clip with inputs resident in HBM.
-Clips are independent, so ranks share nothing on the data path (weak scaling); the only collective
-is one RCCL all-reduce of the PSNR sums after the timed region.  Rank 0 prints ONE JSON line.
+Configs (BASELINE.json `configs`, 0-based index in brackets):
+  2 [1]  single MI355X, 7-frame 180x320 -> 1440x2560, batch 1, fp32, sigma^T = 10        (default; the headline)
+  3 [2]  100-frame 180x320 streaming recurrent inference (one frame per call), bf16 storage, sigma^T = 50
+  4 [3]  32 independent 7-frame clips over 8 GPUs = 4 clips per GPU per step, bf16 storage
+  5 [4]  270x480 -> 2160x3840 (4K), 7 frames, bf16 storage
+A step = one pass of the hot path over one batch of synthetic input resident in HBM: config 2/5 one clip per rank,
+config 4 four clips per rank, config 3 one 100-frame streamed sequence per rank.  Clips / sequences are independent,
+so ranks share nothing on the data path (weak scaling); the only collective is one RCCL all-reduce of the PSNR sums
+after the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      dominant kernel family by GPU time: algorithmic bytes (or flops) / hipEvent-measured
-                duration, from a second, instrumented pass of the same steps (every launch bracketed
-                by hipEvents on its own stream inside libcrfp_hip.so: crfp_prof_*).
+  roofline      dominant kernel family by GPU time: algorithmic flops (or bytes) / hipEvent-measured duration, from a
+                second, instrumented single-stream pass of the same steps (every launch bracketed by hipEvents on its
+                own stream inside libcrfp_hip.so: crfp_prof_*).  `traffic` = HBM bytes per launch from the committed
+                rocprofv3 PMC summary, tagged with its provenance (it is not re-measured in this run).
   warp_dcn      the same for the flow_warp + DCNv2 gather kernels (the north star's 60 % HBM target).
-  kernels       per-kernel table (ms per clip, achieved GB/s and TFLOP/s).
-  cpu_baseline  the oracle (CPU port of the reference path) timed on this host on a bounded sample.
-  parity        max|HIP - oracle| and PSNR-Y delta on that same sample.
+  kernels       per-kernel table (ms per step, achieved GB/s and TFLOP/s).
+  strict_f32    (config 2) the same clip with CRFP_DSV_STRICT_F32: plain fp32 MFMA instead of the split-fp16 scheme.
+  per_op_us     microseconds per call of the per-operator C-ABI entry points at this config's sizes.
+  cpu_baseline  the oracle (CPU port of the reference path; its bf16 twin for the bf16 configs) timed on this host:
+                1 warm-up + 1 timed pass over the config-2 clip (or a bounded sample of the bigger configs).
+  parity        max|HIP - oracle| (bf16 configs: statistics against the twin) and PSNR-Y delta on that sample.
 """
 import argparse
 import json
@@ -34,12 +44,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
-# The wide convs run as 3 fp16 MFMA products per algorithmic fp32 MAC (split-fp16 "f16x3", fp32-grade result:
-# DESIGN.md section 3.1), or 6 bf16 products with CRFP_CONV_MODE=bf16x6; fp16 and bf16 MFMAs share the 2.5 PF dense
-# peak, so the algorithmic-flop ceiling is that peak / 3 (/ 6).
-SPLIT_F16_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
-SPLIT_BF16_EQUIV_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+MFMA16_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak
+# fp32 storage: the wide convs run 3 fp16 MFMA products per algorithmic fp32 MAC (split-fp16, fp32-grade result,
+# DESIGN.md 3.1), so the algorithmic-flop ceiling is the 16-bit peak / 3; bf16 storage: one bf16 product per MAC.
+SPLIT_F16_EQUIV_PEAK_TFLOPS = MFMA16_PEAK_TFLOPS / 3.0
+
+CONFIGS = {
+    2: dict(index=1, storage="f32", mode="clip", t=7, h=180, w=320, fv=96, sigma=10.0, clips=1,
+            name="BASELINE configs[1]: single MI355X, 7-frame 180x320 -> 1440x2560 x8 SR, batch=1, fp32, sigma_T=10"),
+    3: dict(index=2, storage="bf16", mode="stream", t=100, h=180, w=320, fv=96, sigma=50.0, clips=1,
+            name="BASELINE configs[2]: single MI355X, 100-frame 180x320 streaming recurrent inference (one frame per call), bf16, sigma_T=50"),
+    4: dict(index=3, storage="bf16", mode="clip", t=7, h=180, w=320, fv=96, sigma=10.0, clips=4,
+            name="BASELINE configs[3]: 32 independent 7-frame 180x320 clips sharded over 8 GPUs (4 clips per GPU per step), bf16"),
+    5: dict(index=4, storage="bf16", mode="clip", t=7, h=270, w=480, fv=144, sigma=10.0, clips=1,
+            name="BASELINE configs[4]: single MI355X, 270x480 -> 2160x3840 (4K) x8 SR, 7 frames, bf16"),
+}
 
 
 def kernel_family(name: str) -> str:
@@ -51,16 +70,20 @@ def kernel_family(name: str) -> str:
 
 
 # hipEvent launch-site family -> rocprofv3 kernel names (for the PMC traffic lookup)
-ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_mfma_kernel"), "conv3x3_narrow": ("conv3x3_narrow_kernel",),
+ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_mfma_kernel", "conv3x3_bf16_kernel"),
+                 "conv3x3_narrow": ("conv3x3_narrow_kernel",),
                  "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel",),
                  "flow_warp_q4_c4": ("flow_warp_p4_kernel",), "flow_warp_q4_c32": ("flow_warp_p4_kernel",),
-                 "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "flow_warp_q4_c32+c24": ("flow_warp_p4_dual_kernel",), "hr_prep_up8_blend": ("hr_prep_kernel",)}
+                 "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "flow_warp_q4_c32+c24": ("flow_warp_p4_dual_kernel",),
+                 "hr_prep_up8_blend": ("hr_prep_kernel",)}
 
 
-def pmc_traffic(family: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE, per
-    MI355X_MICROARCH.md), averaged over the family's kernels; None when no summary is present."""
-    path = os.path.join(ROOT, "profiles", "pmc_summary_latest.json")
+def pmc_traffic(family: str, storage: str):
+    """{"bytes_per_launch", "source", "measured_in_run": False} from the committed rocprofv3 PMC summary (2 x FETCH_SIZE +
+    WRITE_SIZE per MI355X_MICROARCH.md, separate --pmc passes, tools/collect_profiles.sh) of the same workload; None when
+    no summary exists for this storage mode.  It is a constant as far as this run is concerned -- hence the tag."""
+    fname = "pmc_summary_latest.json" if storage == "f32" else "pmc_summary_latest_bf16.json"
+    path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path) or family not in ROCPROF_NAMES:
         return None
     tot = calls = 0.0
@@ -68,7 +91,19 @@ def pmc_traffic(family: str):
         if any(r["kernel"].startswith(n) for n in ROCPROF_NAMES[family]) and r.get("hbm_MB_per_launch_corrected") is not None:
             tot += r["hbm_MB_per_launch_corrected"] * 1e6 * r["calls"]
             calls += r["calls"]
-    return tot / calls if calls else None
+    if not calls:
+        return None
+    return {"bytes_per_launch": tot / calls, "source": "profiles/" + fname, "measured_in_run": False}
+
+
+def time_op(fn, iters=20):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return 1e6 * (time.perf_counter() - t0) / iters
 
 
 def main():
@@ -76,24 +111,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=7)
-    ap.add_argument("--lr-h", type=int, default=180)
-    ap.add_argument("--lr-w", type=int, default=320)
-    ap.add_argument("--fv-size", type=int, default=96)
-    ap.add_argument("--sigma-t", type=float, default=10.0)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--lr-h", type=int, default=None)
+    ap.add_argument("--lr-w", type=int, default=None)
+    ap.add_argument("--fv-size", type=int, default=None)
+    ap.add_argument("--sigma-t", type=float, default=None)
+    ap.add_argument("--storage", choices=("f32", "bf16"), default=None)
+    ap.add_argument("--clips-per-gpu", type=int, default=None)
+    ap.add_argument("--in-flight", type=int, default=1, help="clips of one rank in flight on separate HIP streams (clip mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--no-multi-stream", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=3)
-    ap.add_argument("--cpu-timeout", type=float, default=240.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip strict_f32 / multi-stream / per-op legs")
+    ap.add_argument("--cpu-sample-frames", type=int, default=None)
+    ap.add_argument("--cpu-timeout", type=float, default=420.0)
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k, v in (("t", args.frames), ("h", args.lr_h), ("w", args.lr_w), ("fv", args.fv_size), ("sigma", args.sigma_t),
+                 ("storage", args.storage), ("clips", args.clips_per_gpu)):
+        if v is not None:
+            cfg[k] = v
+    custom = any(cfg[k] != CONFIGS[args.config][k] for k in cfg)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -102,18 +146,48 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from crfp_amd import _lib, synth
+    from crfp_amd import _lib, ops, synth
+    from crfp_amd.engine import DSVEngine
     from crfp_amd.model import CRFP
 
-    t, h, w = args.frames, args.lr_h, args.lr_w
+    t, h, w, fv, storage, clips, mode = cfg["t"], cfg["h"], cfg["w"], cfg["fv"], cfg["storage"], cfg["clips"], cfg["mode"]
     sd = synth.make_state_dict(7)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
     model = CRFP.CRFP_DSV(device=dev, mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True)
-    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    model.load_state_dict({k: v.clone() for k, v in sdt.items()}, strict=True)
+    model.storage = storage
     model = model.to(dev).eval()
-    # every rank gets its own clip (seed offset by rank): independent units, no data-path collective
-    lrs_np, fvs_np, mks_np = synth.make_clip(1234 + rank, 1, t, h, w, fv_size=args.fv_size, sigma_t=args.sigma_t)
-    lrs, fvs, mks = (torch.from_numpy(a).to(dev) for a in (lrs_np, fvs_np, mks_np))
+    # every rank (and every clip of a rank) gets its own clip: independent units, no data-path collective
+    data_np = [synth.make_clip(1234 + rank * clips + c, 1, t, h, w, fv_size=fv, sigma_t=cfg["sigma"]) for c in range(clips)]
+    data = [tuple(torch.from_numpy(a).to(dev) for a in d) for d in data_np]
     eng = model.engine()
+    n_flight = max(1, min(args.in_flight, clips)) if mode == "clip" else 1
+    engs = [eng] + [DSVEngine(sdt, dev, storage=storage) for _ in range(n_flight - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_flight)] if n_flight > 1 else None
+    if mode == "stream":
+        mk8 = data[0][2].contiguous()
+
+    def step(e=None):
+        """one step of this rank; returns the last output tensor(s)"""
+        if mode == "stream":
+            lrs, fvs, _ = data[0]
+            eng.clear_states()
+            o = None
+            for i in range(t):
+                o = eng.stream_frame(lrs[0, i], fvs[0, i], mk8[0, i])
+            return [o]
+        if n_flight == 1:
+            return [(e or eng).forward(*d) for d in data]
+        outs = [None] * clips
+        cur = torch.cuda.current_stream()
+        for s in streams:
+            s.wait_stream(cur)
+        for c, d in enumerate(data):
+            with torch.cuda.stream(streams[c % n_flight]):
+                outs[c] = engs[c % n_flight].forward(*d)
+        for s in streams:
+            cur.wait_stream(s)
+        return outs
 
     def barrier():
         if dist is not None:
@@ -122,49 +196,55 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            out = eng.forward(lrs, fvs, mks)
+            outs = step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = eng.forward(lrs, fvs, mks)
+            outs = step()
         barrier()
         elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    frames_per_step = t * clips
+    assert not eng.overflowed(stream=(mode == "stream")), "numerics guard fired on the benchmark clip"
 
-    # PSNR reduction (the only collective of the path): PSNR-Y of the SR frames against the synthetic HR
-    # scene inside the fovea window is not meaningful without trained weights, so reduce the raw sums.
-    from crfp_amd import ops
-    acc = ops.sq_err_sums(out[0], fvs[0]).clone()
-    vec = torch.cat([acc, torch.tensor([float(t)], dtype=torch.float64, device=dev)])
+    # PSNR reduction (the only collective of the path): raw squared-error sums of the last SR frame(s) against the synthetic
+    # HR scene inside the fovea window (not a quality figure without trained weights: it exercises the reduction)
+    last = outs[-1] if mode == "stream" else outs[-1][0, -1]
+    acc = ops.sq_err_sums(last[None].contiguous(), data[-1][1][0, -1][None].contiguous()).clone()
+    vec = torch.cat([acc, torch.tensor([float(frames_per_step)], dtype=torch.float64, device=dev)])
     if dist is not None:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
 
+    arithmetic = ("fp32 in / fp32 accumulate / fp32 out; products on the fp16 MFMA via an exact 2-term split (3 MFMAs per MAC, "
+                  "error at the fp32 summation-order floor, see `parity`)") if storage == "f32" else (
+                  "bf16 activations + recurrent state in HBM, bf16 conv / DCN weights, one bf16 MFMA per MAC, fp32 accumulate; fp32 "
+                  "flow / offsets / masks / API tensors (include/crfp_hip.h, 'bf16 storage')")
     result = {
-        "metric": "sr_frames_per_sec", "value": world * args.steps * t / elapsed, "unit": "frames/s",
+        "metric": "sr_frames_per_sec", "value": world * args.steps * frames_per_step / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: single MI355X, 7-frame 180x320 -> 1440x2560 x8 SR, "
-                               "batch=1, fp32, sigma_T=10 (one clip per GPU per step; clips sharded over GPUs)",
-                   "conv_arithmetic": "fp32 in / fp32 accumulate / fp32 out; products on the fp16 MFMA via an exact 2-term split "
-                                      "(3 MFMAs per MAC, error at the fp32 summation-order floor, see `parity`)",
-                   "frames_per_clip": t, "lr": [h, w], "sr": [8 * h, 8 * w], "fv_size": args.fv_size,
-                   "sigma_t": args.sigma_t, "clips_per_gpu_per_step": 1, "parallelism": f"clip-sharded x{world}"},
-        "per_gpu_frames_per_sec": args.steps * t / elapsed,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if storage == "f32" else "bf16",
+        "data": "synthetic",
+        "config": {"workload": cfg["name"] + (" [with command-line overrides]" if custom else ""), "baseline_config_index": cfg["index"],
+                   "conv_arithmetic": arithmetic, "mode": mode, "frames_per_clip": t, "lr": [h, w], "sr": [8 * h, 8 * w],
+                   "fv_size": fv, "sigma_t": cfg["sigma"], "clips_per_gpu_per_step": clips, "clips_in_flight_per_gpu": n_flight,
+                   "storage": storage, "parallelism": f"clip-sharded x{world}"},
+        "per_gpu_frames_per_sec": args.steps * frames_per_step / elapsed,
+        "frames_per_step_per_gpu": frames_per_step,
     }
 
     if rank == 0 and not args.no_kernel_profile:
         L = _lib.lib()
         L.crfp_prof_reset()
         L.crfp_prof_enable(1)
-        psteps = min(args.steps, 5)
+        psteps = min(args.steps, 5 if mode == "clip" else 1)
         with torch.no_grad():
             for _ in range(psteps):
-                eng.forward(lrs, fvs, mks)
+                step(eng) if mode == "clip" else step()
         torch.cuda.synchronize()
-        recs = _lib.prof_report()
+        recs = _lib.prof_report(512)
         L.crfp_prof_enable(0)
         L.crfp_prof_reset()
         fam = {}
@@ -175,35 +255,41 @@ def main():
         table = []
         for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
             s = f["ms"] * 1e-3
-            table.append({"kernel": name, "launches_per_clip": f["launches"] / psteps, "ms_per_clip": f["ms"] / psteps,
+            table.append({"kernel": name, "launches_per_step": f["launches"] / psteps, "ms_per_step": f["ms"] / psteps,
                           "avg_us": 1e3 * f["ms"] / f["launches"], "share": f["ms"] / total_ms,
                           "GBps": f["bytes"] / s / 1e9 if s > 0 else 0.0, "TFLOPs": f["flops"] / s / 1e12 if s > 0 else 0.0})
         result["kernels"] = table
-        result["kernel_ms_per_clip"] = total_ms / psteps
+        result["kernel_ms_per_step"] = total_ms / psteps
+        result["kernel_ms_note"] = ("sum of hipEvent-bracketed kernel durations of the instrumented pass, which runs the SINGLE-stream "
+                                    "schedule (events bracket launches per stream); the timed region uses the two-stream schedule, "
+                                    "so ms_per_step can be smaller than this sum")
         dom = table[0]
         domf = fam[dom["kernel"]]
         if dom["kernel"] == "conv3x3_mfma":
-            mode = os.environ.get("CRFP_CONV_MODE", "f16x3")
-            f32_mode = mode == "f32"
-            peak = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16x6": SPLIT_BF16_EQUIV_PEAK_TFLOPS}.get(mode, SPLIT_F16_EQUIV_PEAK_TFLOPS)
-            note = {"f32": "fp32 MFMA",
-                    "bf16x6": "algorithmic fp32 flops; executed as 6 bf16 MFMA products per MAC (split-bf16), so peak = 2.5 PF / 6"}.get(
-                        mode, "algorithmic fp32 flops; executed as 3 fp16 MFMA products per MAC (split-fp16, fp32-grade), so peak = "
-                              "2.5 PF dense fp16 / 3; PMC: MFMA pipe ~28 % busy (profiles/*_mfma_lds_util.txt), the rest is operand traffic through LDS (1.0 ds_read_b128 per MFMA), load wait, split and the tile-granularity tail")
+            strict_env = os.environ.get("CRFP_PRECISION") == "f32" or os.environ.get("CRFP_CONV_MODE") == "f32"
+            if storage == "bf16":
+                peak, scheme = MFMA16_PEAK_TFLOPS, "bf16"
+                note = "one v_mfma_f32_32x32x16_bf16 per MAC on bf16 operands, fp32 accumulate: peak = 2.5 PF dense bf16"
+            elif strict_env:
+                peak, scheme, note = F32_MFMA_PEAK_TFLOPS, "f32", "fp32 MFMA (CRFP_PRECISION=f32)"
+            else:
+                peak, scheme = SPLIT_F16_EQUIV_PEAK_TFLOPS, "f16x3"
+                note = ("algorithmic fp32 flops; executed as 3 fp16 MFMA products per MAC (split-fp16, fp32-grade), so peak = 2.5 PF "
+                        "dense fp16 / 3; see profiles/*_mfma_lds_util.txt for the MFMA / LDS pipe counters")
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["TFLOPs"],
                                   "peak": peak, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / peak,
-                                  "traffic": pmc_traffic(dom["kernel"]), "avg_launch_us": dom["avg_us"],
+                                  "traffic": pmc_traffic(dom["kernel"], storage), "avg_launch_us": dom["avg_us"],
                                   "algorithmic_flops_per_launch": domf["flops"] / domf["launches"],
                                   "frac_of_fp32_mfma_peak": dom["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                                  "conv_scheme": mode, "note": note}
+                                  "conv_scheme": scheme, "note": note}
         else:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"]),
+                                  "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"], storage),
                                   "avg_launch_us": dom["avg_us"],
                                   "algorithmic_bytes_per_launch": domf["bytes"] / domf["launches"]}
-        gat = [f for n, f in fam.items() if n.startswith("flow_warp") or n.startswith("dcnv2")]
+        gat = {n: f for n, f in fam.items() if n.startswith("flow_warp") or n.startswith("dcnv2")}
         if gat:
-            gb = sum(f["bytes"] for f in gat); gs = sum(f["ms"] for f in gat) * 1e-3
+            gb = sum(f["bytes"] for f in gat.values()); gs = sum(f["ms"] for f in gat.values()) * 1e-3
             # dcn_3 through the API moves 18 offset + 9 mask channels (the reference tiles 2+1 channels 9x); the kernel
             # reads the compact 2+1: SURVEY 8(d) asks for both figures
             d3 = fam.get("dcnv2_shared_c4")
@@ -211,72 +297,129 @@ def main():
             result["warp_dcn"] = {"bound": "hbm", "achieved": gb / gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": gb / gs / 1e9 / HBM_PEAK_GBS, "frac_of_copy_ceiling": gb / gs / 1e9 / HBM_COPY_CEILING_GBS,
                                   "achieved_api_tensor_bytes": gb_api / gs / 1e9, "frac_api_tensor_bytes": gb_api / gs / 1e9 / HBM_PEAK_GBS,
-                                  "ms_per_clip": 1e3 * gs / psteps,
-                                  "traffic": {n: pmc_traffic(n) for n in fam if n.startswith("flow_warp") or n.startswith("dcnv2")},
-                                  "note": "dcn_3 priced at its compact 2+1 offset/mask channels (162.2 MB/frame), "
-                                          "not the 9x-replicated API tensors (516.1 MB/frame)"}
+                                  "ms_per_step": 1e3 * gs / psteps,
+                                  "per_kernel": {n: {"avg_us": 1e3 * f["ms"] / f["launches"], "GBps": f["bytes"] / (f["ms"] * 1e-3) / 1e9,
+                                                     "frac": f["bytes"] / (f["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                     "traffic": pmc_traffic(n, storage)} for n, f in gat.items()},
+                                  "note": "dcn_3 priced at its compact 2+1 offset/mask channels, not the 9x-replicated API tensors; "
+                                          "bf16 storage: feature bytes halve, offsets / masks / flow stay fp32"}
 
-    if rank == 0 and world == 1 and not args.no_multi_stream:
-        # extra (not the headline): independent clips in flight on separate HIP streams of the same GPU fill
-        # each other's tails and pipeline bubbles (BASELINE config 4 runs 4 clips per GPU)
-        from crfp_amd.engine import DSVEngine
-        sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    extras = rank == 0 and world == 1 and not args.no_extras
+    if extras and mode == "clip" and storage == "f32":
+        # the same clip in strict fp32 (plain fp32 MFMA for every conv and the DCN GEMM): what the split-fp16 scheme buys
+        model.precision = "f32"
+        se = model.engine()
+        with torch.no_grad():
+            ref_strict = se.forward(*data[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_s = max(2, min(args.steps, 5))
+            for _ in range(n_s):
+                se.forward(*data[0])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        model.precision = "split"
+        eng = model.engine()
+        with torch.no_grad():
+            fast = eng.forward(*data[0])
+        result["strict_f32"] = {"frames_per_sec": n_s * t / dt, "ms_per_clip": 1e3 * dt / n_s,
+                                "max_abs_diff_split_vs_strict": float((fast - ref_strict).abs().max()),
+                                "note": "CRFP_DSV_STRICT_F32: v_mfma_f32_32x32x2_f32 everywhere, no fp16 operands, no range guard"}
+
+    if extras and mode == "clip":
+        # independent clips in flight on separate HIP streams of the same GPU fill each other's tails (config 4 runs 4 per GPU)
         ms = {}
         exact = True
+        with torch.no_grad():
+            ref_out = eng.forward(*data[0]).clone()
         for C in (2, 4):
-            engs = [DSVEngine(sdt, dev) for _ in range(C)]
-            streams = [torch.cuda.Stream(device=dev) for _ in range(C)]
+            es = [DSVEngine(sdt, dev, storage=storage) for _ in range(C)]
+            sts = [torch.cuda.Stream(device=dev) for _ in range(C)]
             with torch.no_grad():
                 for it in range(1 + min(args.steps, 5)):
                     if it == 1:
                         torch.cuda.synchronize()
                         tm = time.perf_counter()
-                    outs = []
-                    for e, st in zip(engs, streams):
+                    os_ = []
+                    for e, st in zip(es, sts):
                         with torch.cuda.stream(st):
-                            outs.append(e.forward(lrs, fvs, mks))
+                            os_.append(e.forward(*data[0]))
                 torch.cuda.synchronize()
             ms[str(C)] = C * min(args.steps, 5) * t / (time.perf_counter() - tm)
             # concurrent kernels must not disturb each other: every in-flight clip == the sequential result, bit for bit
-            exact = exact and all(bool(torch.equal(o, out)) for o in outs)
-            del engs, outs
+            exact = exact and all(bool(torch.equal(o, ref_out)) for o in os_)
+            del es, os_
         ms["bit_exact_vs_sequential"] = exact
         result["multi_stream_frames_per_sec"] = ms
 
+    if extras and storage == "f32":
+        # the per-operator C-ABI entry points (NCHW API tensors in and out: each call includes its layout conversions)
+        H2, W2, H8, W8 = 2 * h, 2 * w, 8 * h, 8 * w
+        g = torch.Generator(device="cpu").manual_seed(3)
+        rn = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+        x32, fl2 = rn(1, 32, H2, W2), rn(1, H2, W2, 2) * 3
+        x4, fl8 = rn(1, 4, H8, W8), rn(1, H8, W8, 2) * 8
+        off, msk = rn(1, 144, H2, W2) * 4, torch.sigmoid(rn(1, 72, H2, W2))
+        wd, bd = rn(32, 32, 3, 3) * 0.1, rn(32)
+        wc, bc = rn(32, 64, 3, 3) * 0.05, rn(32)
+        x64 = rn(1, 64, H2, W2)
+        with torch.no_grad():
+            result["per_op_us"] = {
+                "flow_warp_c32@2x": time_op(lambda: ops.flow_warp(x32, fl2)),
+                "flow_warp_c4@8x": time_op(lambda: ops.flow_warp(x4, fl8)),
+                "dcnv2_c32_dg8@2x": time_op(lambda: ops.dcnv2(x32, off, msk, wd, bd, 3, 1, 1, 8)),
+                "conv3x3_64to32@2x": time_op(lambda: ops.conv3x3(x64, wc, bc, "lrelu")),
+                "upsample_bilinear_x8_c3": time_op(lambda: ops.upsample_bilinear(data[0][0][0, :1], scale_factor=8)),
+                "note": "wall-clock per call incl. the NCHW <-> Q4 conversions the operator boundary needs (the engine pays none of them)"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # The oracle (CPU port of the reference path; checker / baseline only, never on the product
-        # path) runs in a child process so that a mis-sized host cannot stall the bench: bounded
-        # sample, bounded threads, hard timeout.
+        # The oracle (CPU port of the reference path; checker / baseline only, never on the product path) runs in a child
+        # process so that a mis-sized host cannot stall the bench: bounded sample, hard timeout.
         import subprocess
         import tempfile
         from oracle import crfp_oracle as orc
-        ns = max(2, min(args.cpu_sample_frames, t))
+        full = args.config == 2 and not custom
+        ns = args.cpu_sample_frames or (t if full else 3)
+        ns = max(2, min(ns, t))
         tmp = os.path.join(tempfile.mkdtemp(), "oracle_sample.npz")
         cmd = [sys.executable, "-m", "oracle.run_sample", "--frames", str(ns), "--h", str(h), "--w", str(w),
-               "--fv-size", str(args.fv_size), "--sigma-t", str(args.sigma_t), "--clip-seed", "1234",
-               "--clip-frames", str(t), "--out", tmp]
+               "--fv-size", str(fv), "--sigma-t", str(cfg["sigma"]), "--clip-seed", "1234", "--clip-frames", str(t),
+               "--storage", storage, "--warmup", "1" if full else "0", "--out", tmp]
         try:
             subprocess.run(cmd, cwd=ROOT, timeout=args.cpu_timeout, check=True)
             z = np.load(tmp)
             ref, cpu_s = torch.from_numpy(z["out"]), float(z["seconds"])
+            lrs, fvs, mks = data[0]
             with torch.no_grad():
-                got = eng.forward(lrs[:, :ns], fvs[:, :ns], mks[:, :ns]).cpu()
-            d = float((got - ref).abs().max())
-            hr = torch.from_numpy(np.clip(fvs_np[:, :ns], 0, 1))
+                if mode == "stream":
+                    eng.clear_states()
+                    got = torch.stack([eng.stream_frame(lrs[0, i], fvs[0, i], mk8[0, i]) for i in range(ns)])[None].cpu()
+                else:
+                    got = eng.forward(lrs[:, :ns], fvs[:, :ns], mks[:, :ns]).cpu()
+            dd = (got - ref).abs()
+            hr = torch.from_numpy(np.clip(data_np[0][1][:, :ns], 0, 1))
             py_ref = np.mean([orc.psnr_rgb_and_y(ref[0, i:i + 1], hr[0, i:i + 1])[1] for i in range(ns)])
             py_got = np.mean([orc.psnr_rgb_and_y(got[0, i:i + 1], hr[0, i:i + 1])[1] for i in range(ns)])
+            what = "oracle/crfp_oracle.py on torch-CPU fp32" if storage == "f32" else "oracle/crfp_oracle.py bf16-storage twin on torch-CPU"
             result["cpu_baseline"] = {"value": ns / cpu_s, "unit": "frames/s", "cores": int(z["threads"]), "kind": "port",
-                                      "sample": f"first {ns} frames of the same 180x320 clip (1 first frame + {ns - 1} "
-                                                f"steady-state frames), oracle/crfp_oracle.py on torch-CPU fp32, {cpu_s:.1f} s wall",
-                                      "host_cpus": os.cpu_count(), "usable_cpus": int(z["usable_cpus"])}
-            result["parity"] = {"max_abs_diff_vs_oracle": d, "tolerance": 1e-3, "frames": ns,
-                                "psnr_y_delta_db": float(abs(py_ref - py_got))}
+                                      "sample": (f"{'all' if ns == t else 'first'} {ns} frames of the same {h}x{w} clip, {what}, "
+                                                 f"{'1 warm-up pass + ' if full else ''}1 timed pass of {cpu_s:.1f} s wall"),
+                                      "host_cpus": os.cpu_count(), "usable_cpus": int(z["usable_cpus"]),
+                                      "torch_threads": int(z["threads"])}
+            if storage == "f32":
+                result["parity"] = {"max_abs_diff_vs_oracle": float(dd.max()), "tolerance": 1e-3, "frames": ns,
+                                    "psnr_y_delta_db": float(abs(py_ref - py_got))}
+            else:
+                result["parity"] = {"vs": "bf16-storage oracle twin (rounds where the engine stores)", "max_abs_diff": float(dd.max()),
+                                    "mean_abs_diff": float(dd.mean()), "psnr_db": float(-10 * torch.log10((dd.double() ** 2).mean())),
+                                    "tolerance": "mean <= 5e-4, max <= 3e-2 (tests/test_gpu_bf16.py; the twin itself sits ~1.3e-2 / 3.6e-4 from fp32)",
+                                    "frames": ns, "psnr_y_delta_db": float(abs(py_ref - py_got))}
         except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
                                       "sample": f"oracle sample of {ns} frames did not finish: {type(e).__name__}"}
 
     if rank == 0:
-        result["psnr_reduce"] = {"sum_sq_err": float(vec[0]), "frames": float(vec[2])}
+        result["psnr_reduce"] = {"sum_sq_err": float(vec[0]), "sum_sq_err_y": float(vec[1]), "frames": float(vec[2]), "ranks": world}
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

@@ -38,15 +38,24 @@ def main():
     ap.add_argument("--clip-frames", type=int, default=7)
     ap.add_argument("--weights-seed", type=int, default=7)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--storage", choices=("f32", "bf16"), default="f32", help="bf16: the storage-rounding twin")
+    ap.add_argument("--warmup", type=int, default=0, help="untimed passes before the timed one (BASELINE.md section 4: 1)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    threads = a.threads or min(16, usable_cpus())
+    # every usable CPU (affinity / cgroup quota); beyond ~64 threads the small 180x320 convs stop scaling
+    threads = a.threads or min(64, usable_cpus())
     torch.set_num_threads(threads)
     sd = synth.make_state_dict(a.weights_seed)
     lrs, fvs, mks = synth.make_clip(a.clip_seed, 1, a.clip_frames, a.h, a.w, fv_size=a.fv_size, sigma_t=a.sigma_t)
     P = orc.load_numpy_state(sd)
     T = torch.from_numpy
-    with torch.no_grad():
+    import contextlib
+    ctx = orc.bf16_storage() if a.storage == "bf16" else contextlib.nullcontext()
+    if a.storage == "bf16":
+        P = orc.bf16_weights(P)
+    with torch.no_grad(), ctx:
+        for _ in range(a.warmup):
+            orc.crfp_dsv_forward(P, T(lrs[:, :a.frames]), T(fvs[:, :a.frames]), T(mks[:, :a.frames]))
         t0 = time.perf_counter()
         out = orc.crfp_dsv_forward(P, T(lrs[:, :a.frames]), T(fvs[:, :a.frames]), T(mks[:, :a.frames]))
         dt = time.perf_counter() - t0
