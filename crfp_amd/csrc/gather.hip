@@ -103,6 +103,30 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int s
 }
 constexpr int QB = kQuadBytes;   // bytes per pixel quad of a gathered plane
 
+// The two horizontally adjacent corners (x0, x0 + 1) of a bilinear sample are adjacent in memory -- also across the row end,
+// where x0 + 1 is the zero pad column, and at x0 = -1, which is the pad column of the previous row.  In the bf16 build the
+// pair is 16 bytes = ONE buffer_load_dwordx4 (dword alignment is all a buffer load needs): half the gather instructions of
+// the fp32 build, which matters because these kernels are bound by the texture-address / L1 rate of their per-lane gathers,
+// not by bytes (dcn_g8: 66 M lane-loads per launch @A).
+#ifdef CRFP_ACT_BF16
+typedef u32x4 pairraw_t;
+__device__ __forceinline__ pairraw_t bload_pair(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CRFP_GATHER_AUX);
+}
+__device__ __forceinline__ f32x4 pair_lo(const pairraw_t& p) { return quad_from_bits(cu32x2{p.x, p.y}); }
+__device__ __forceinline__ f32x4 pair_hi(const pairraw_t& p) { return quad_from_bits(cu32x2{p.z, p.w}); }
+#else
+struct pairraw_t { f32x4 lo, hi; };
+__device__ __forceinline__ pairraw_t bload_pair(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    pairraw_t p;
+    p.lo = bload(r, voff, soff);
+    p.hi = bload(r, voff, soff + 16);
+    return p;
+}
+__device__ __forceinline__ f32x4 pair_lo(const pairraw_t& p) { return p.lo; }
+__device__ __forceinline__ f32x4 pair_hi(const pairraw_t& p) { return p.hi; }
+#endif
+
 __global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restrict__ x, long long xb,
                                                            const float* __restrict__ flow, long long fb,
                                                            float* __restrict__ out, long long ob, int nq, int H,
@@ -134,8 +158,8 @@ __global__ __launch_bounds__(256) void flow_warp_p4_kernel(const float* __restri
     const long long oplane = (long long)H * W * 4;
     for (int q = 0; q < nq; ++q) {
         const int vo = voff + q * plane_b;
-        const f32x4 a = bload(r, vo, 0), b = bload(r, vo, QB), c = bload(r, vo, pitch), d = bload(r, vo, pitch + QB);
-        stq(os + q * oplane, a * w00 + b * w01 + c * w10 + d * w11);
+        const pairraw_t tp = bload_pair(r, vo, 0), bt = bload_pair(r, vo, pitch);
+        stq(os + q * oplane, pair_lo(tp) * w00 + pair_hi(tp) * w01 + pair_lo(bt) * w10 + pair_hi(bt) * w11);
     }
 }
 
@@ -149,17 +173,18 @@ __device__ __forceinline__ void warp_quads(__amdgpu_buffer_rsrc_t r, int voff, i
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += 4) {
         constexpr int B = 4;
-        f32x4 a[B], b[B], c[B], d[B];
+        pairraw_t tp[B], bt[B];
 #pragma unroll
         for (int i = 0; i < B; ++i)
             if (q0 + i < NQ) {
                 const int vo = voff + (q0 + i) * plane_b;
-                a[i] = bload(r, vo, 0); b[i] = bload(r, vo, QB); c[i] = bload(r, vo, pitch); d[i] = bload(r, vo, pitch + QB);
+                tp[i] = bload_pair(r, vo, 0); bt[i] = bload_pair(r, vo, pitch);
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < B; ++i)
-            if (q0 + i < NQ) stq(os + (q0 + i) * oplane, a[i] * w00 + b[i] * w01 + c[i] * w10 + d[i] * w11);
+            if (q0 + i < NQ)
+                stq(os + (q0 + i) * oplane, pair_lo(tp[i]) * w00 + pair_hi(tp[i]) * w01 + pair_lo(bt[i]) * w10 + pair_hi(bt[i]) * w11);
     }
 }
 
@@ -424,8 +449,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void dcn_g8_kernel(const float* __re
 // gathers, and its VALU (~33 us of instruction issue), gather (~32 us of L1 bandwidth: 1.06 GB of 16-B corner reads) and
 // offset traffic (199 MB of HBM) added up instead of overlapping (96 us).
 struct DcnPair {
-    f32x4 q[2][4];   // [position][corner]
-    float w[2][4];   // modulated bilinear weights
+    pairraw_t tp[2], bt[2];   // [position]: top / bottom corner pairs as loaded
+    float w[2][4];            // modulated bilinear weights
 };
 
 struct DcnOff { f32x4 m4, oa, ob; };   // masks of 4 positions, (dy,dx) of positions (0,1) and (2,3)
@@ -449,10 +474,8 @@ __device__ __forceinline__ void dcn_issue_pair(DcnPair& P, __amdgpu_buffer_rsrc_
         const float a = (1.0f - ly) * mmv[pp], b = ly * mmv[pp], hx = 1.0f - lx;
         P.w[pi][0] = a * hx; P.w[pi][1] = a * lx; P.w[pi][2] = b * hx; P.w[pi][3] = b * lx;
         const int vo = ((int)fy * PW + (int)fx) * QB + hbase + gi * plane_b;
-        P.q[pi][0] = bload(rx, vo, 0);
-        P.q[pi][1] = bload(rx, vo, QB);
-        P.q[pi][2] = bload(rx, vo, pitch);
-        P.q[pi][3] = bload(rx, vo, pitch + QB);
+        P.tp[pi] = bload_pair(rx, vo, 0);
+        P.bt[pi] = bload_pair(rx, vo, pitch);
     }
 }
 
@@ -460,10 +483,10 @@ __device__ __forceinline__ void dcn_consume_pair(const DcnPair& P, f32x16& acc, 
     float xs[8];
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
-        f32x4 val = P.q[pi][0] * P.w[pi][0];
-        val = __builtin_elementwise_fma(P.q[pi][1], f32x4{P.w[pi][1], P.w[pi][1], P.w[pi][1], P.w[pi][1]}, val);
-        val = __builtin_elementwise_fma(P.q[pi][2], f32x4{P.w[pi][2], P.w[pi][2], P.w[pi][2], P.w[pi][2]}, val);
-        val = __builtin_elementwise_fma(P.q[pi][3], f32x4{P.w[pi][3], P.w[pi][3], P.w[pi][3], P.w[pi][3]}, val);
+        f32x4 val = pair_lo(P.tp[pi]) * P.w[pi][0];
+        val = __builtin_elementwise_fma(pair_hi(P.tp[pi]), f32x4{P.w[pi][1], P.w[pi][1], P.w[pi][1], P.w[pi][1]}, val);
+        val = __builtin_elementwise_fma(pair_lo(P.bt[pi]), f32x4{P.w[pi][2], P.w[pi][2], P.w[pi][2], P.w[pi][2]}, val);
+        val = __builtin_elementwise_fma(pair_hi(P.bt[pi]), f32x4{P.w[pi][3], P.w[pi][3], P.w[pi][3], P.w[pi][3]}, val);
         xs[4 * pi + 0] = val.x; xs[4 * pi + 1] = val.y; xs[4 * pi + 2] = val.z; xs[4 * pi + 3] = val.w;
     }
     dcn_f16x8 b0, b1;
@@ -681,12 +704,18 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
     const bool regular = iy[1] == iy[0] + 1 && iy[2] == iy[0] + 2 && ix[1] == ix[0] + 1 && ix[2] == ix[0] + 2;
     if (__all(regular)) {
         const int vo = (iy[0] * PW + ix[0]) * QB + guard;
-        f32x4 nb[4][4];
+        pairraw_t nbp[4][2];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) nb[r][c] = bload(rx, vo, r * pitch + c * QB);
-        __builtin_amdgcn_sched_barrier(0);   // all 16 gathers in flight together (hipcc otherwise issues and waits row by row)
+            for (int c = 0; c < 2; ++c) nbp[r][c] = bload_pair(rx, vo, r * pitch + 2 * c * QB);
+        __builtin_amdgcn_sched_barrier(0);   // all gathers in flight together (hipcc otherwise issues and waits row by row)
+        f32x4 nb[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            nb[r][0] = pair_lo(nbp[r][0]); nb[r][1] = pair_hi(nbp[r][0]);
+            nb[r][2] = pair_lo(nbp[r][1]); nb[r][3] = pair_hi(nbp[r][1]);
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -709,8 +738,8 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
                 const int tap = ky * 3 + kx;
                 const float hy = 1.0f - ly[ky], hx = 1.0f - lx[kx];
                 const int vo = (iy[ky] * PW + ix[kx]) * QB + guard;
-                const f32x4 a = bload(rx, vo, 0), b = bload(rx, vo, QB), c = bload(rx, vo, pitch), d = bload(rx, vo, pitch + QB);
-                const f32x4 v = a * (hy * hx) + b * (hy * lx[kx]) + c * (ly[ky] * hx) + d * (ly[ky] * lx[kx]);
+                const pairraw_t tp = bload_pair(rx, vo, 0), bt = bload_pair(rx, vo, pitch);
+                const f32x4 v = pair_lo(tp) * (hy * hx) + pair_hi(tp) * (hy * lx[kx]) + pair_lo(bt) * (ly[ky] * hx) + pair_hi(bt) * (ly[ky] * lx[kx]);
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
                     acc[o] = fmaf(w[(o * 4 + 3) * 9 + tap], v.w,
