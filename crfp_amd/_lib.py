@@ -32,6 +32,10 @@ SIGNATURES = {
     "crfp_conv3x3_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "crfp_conv3x3_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_upsample_bilinear_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_float] * 3 + [C.c_void_p]),
+    "crfp_upsample_bilinear_ac_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_float, C.c_void_p]),
+    "crfp_convkxk_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
+    "crfp_spynet_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "crfp_spynet_forward": (C.c_int, [C.POINTER(C.c_void_p)] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_psnr_partial_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "crfp_avgpool2_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 4 + [C.c_void_p]),
     "crfp_fovea_head_workspace_bytes": (C.c_size_t, [C.c_int] * 3),

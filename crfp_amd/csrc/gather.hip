@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
                                                              const float* __restrict__ offmask, long long omb,
                                                              const float* __restrict__ wpk, const float* __restrict__ bias,
                                                              float* __restrict__ out, long long ob, int H, int W,
-                                                             unsigned* __restrict__ ovf) {
+                                                             unsigned* __restrict__ ovf, int probe) {
     __shared__ f32x4 wl[36 * 64];   // split-fp16 weight image (36 KB), shared by the 4 waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 36 * 64; i += 256) wl[i] = reinterpret_cast<const f32x4*>(wpk)[i];
@@ -517,7 +517,8 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
     const bool valid = px < W && py < H;
     const int cx = min(px, W - 1), cy = min(py, H - 1);
     const long long plane = (long long)H * W * 4;
-    const float* om = offmask + (long long)n * omb + ((long long)cy * W + cx) * 4;
+    // probe == 1 (lab timing experiment, results wrong): every workgroup reads the offsets / masks of the first 4 x 32 pixels
+    const float* om = offmask + (long long)n * omb + (probe == 1 ? ((long long)(cy & 3) * W + (cx & 31)) * 4 : ((long long)cy * W + cx) * 4);
     const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
     const int guard = pitch + QB;  // zeroed guard in front of plane 0 (see flow_warp_p4_kernel)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
         __builtin_amdgcn_sched_barrier(0);                                                                \
     }
 #pragma unroll 1
-    for (int v3 = 0; v3 < 9; v3 += 3) {
+    for (int v3 = 0; v3 < (probe == 2 ? 0 : 9); v3 += 3) {   // probe == 2 (lab): no sampling at all = the fixed cost
         CRFP_DCN_ITER(v3, O0, O1, O2)
         CRFP_DCN_ITER(v3 + 1, O1, O2, O0)
         CRFP_DCN_ITER(v3 + 2, O2, O0, O1)
@@ -631,6 +632,11 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
                   const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16, unsigned* ovf) {
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * ((32 + 32) * sizeof(act_t) + (144 + 72) * 4.0) + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
+    int probe = 0;
+#ifdef CRFP_LAB
+    static const int probe_env = getenv("CRFP_DCN_PROBE") ? atoi(getenv("CRFP_DCN_PROBE")) : 0;
+    probe = probe_env;
+#endif
     // measured 89.1 vs 91.7 us for the software-pipelined kernel (and no gain at all until sched_barrier pinned the gathers
     // ahead of the math): mostly bound by the L1 line rate of the 16-B corner gathers and VALU issue
 #if defined(CRFP_LAB) && !defined(CRFP_ACT_BF16)
@@ -654,10 +660,10 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
 #endif
 #ifdef CRFP_ACT_BF16
     if (!f16) { set_error("dcn_g8: the bf16 build has the split-fp16 GEMM only"); return CRFP_E_UNSUPPORTED; }
-    dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf);
+    dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf, probe);
 #else
     if (f16)
-        dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf);
+        dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf, probe);
     else
         dcn_g8_kernel<4, 2, 4, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
 #endif

@@ -184,15 +184,75 @@ class FNet(nn.Module):
         return ops.upsample_bilinear(o, size=(h, w))
 
 
-class SPyNet(nn.Module):
-    """Placeholder for the reference's SPyNet (model/CRFP.py:554-741).  CRFP_DSV never executes it -- its ``spynet``
-    attribute is an FNet (:1406) -- so there is no HIP path for the 7x7 pyramid convs; constructing it says so instead
-    of silently falling back to PyTorch."""
+class conv(nn.Module):
+    """Reference ``conv`` (model/CRFP.py:145-152): ReLU applied to the INPUT, then nn.Conv2d."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, in_channels, out_channels, kernel_size=7, stride=1, padding=3):
         super().__init__()
-        raise NotImplementedError("SPyNet is dormant on the CRFP_DSV inference path (the flow network is FNet); "
-                                  "crfp_amd provides no kernels for it")
+        if stride != 1 or padding != kernel_size // 2 or kernel_size not in (3, 5, 7):
+            raise NotImplementedError("conv: stride 1, 'same' padding, kernel 3 / 5 / 7 (the reference's SPyNet uses 7)")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding, bias=True)
+        self.act = nn.ReLU()
+
+    def forward(self, x):
+        return ops.convkxk(x, self.conv.weight, self.conv.bias, pre_relu=True)
+
+
+class SPyNetBasicModule(nn.Module):
+    """Reference SPyNetBasicModule (model/CRFP.py:686-741): five ``conv`` 7x7, 8 -> 32 -> 64 -> 32 -> 16 -> 2."""
+
+    def __init__(self):
+        super().__init__()
+        self.basic_module = nn.Sequential(conv(8, 32), conv(32, 64), conv(64, 32), conv(32, 16), conv(16, 2))
+
+    def forward(self, tensor_input):
+        x = tensor_input
+        for m in self.basic_module:
+            x = m(x)
+        return x
+
+
+class SPyNet(nn.Module):
+    """Reference SPyNet (model/CRFP.py:554-684): same ctor, ``basic_module.{0..5}.basic_module.{0..4}.conv`` parameters and
+    ``mean`` / ``std`` buffers; ``forward(ref, supp)`` is one native call (crfp_spynet_forward).  CRFP_DSV itself uses
+    FNet (the SPyNet line of the reference is commented out, :1405); this is the optional flow network."""
+
+    def __init__(self, pretrained, device):
+        super().__init__()
+        self.device = device
+        self.basic_module = nn.ModuleList([SPyNetBasicModule() for _ in range(6)])
+        if isinstance(pretrained, str):
+            sd = self.state_dict()
+            sd.update({k: v for k, v in torch.load(pretrained, map_location="cpu").items()})
+            self.load_state_dict(sd, strict=True)
+        elif pretrained is not None:
+            raise TypeError(f'[pretrained] should be str or None, but got {type(pretrained)}.')
+        self.register_buffer('mean', torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        self.register_buffer('std', torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+
+    def _params(self):
+        return [p for lvl in self.basic_module for m in lvl.basic_module for p in (m.conv.weight, m.conv.bias)]
+
+    @torch.no_grad()
+    def forward(self, ref, supp):
+        return ops.spynet_forward(self._params(), ref, supp)
+
+    @torch.no_grad()
+    def compute_flow(self, ref, supp):
+        """Inputs already a multiple of 32 and normalised by the caller in the reference (:593-664); provided through the
+        per-operator entry points (avg-pool pyramid, align_corners=True flow upsampling, border warp, 7x7 convs)."""
+        n, _, h, w = ref.shape
+        refs, supps = [(ref - self.mean) / self.std], [(supp - self.mean) / self.std]
+        for _ in range(5):
+            refs.append(ops.avgpool2(refs[-1]))
+            supps.append(ops.avgpool2(supps[-1]))
+        refs, supps = refs[::-1], supps[::-1]
+        flow = ref.new_zeros(n, 2, h // 32, w // 32)
+        for level in range(6):
+            flow_up = flow if level == 0 else ops.upsample_bilinear_ac(flow, 2, mul=2.0)
+            warped = flow_warp(supps[level], flow_up.permute(0, 2, 3, 1).contiguous(), padding_mode='border')
+            flow = flow_up + self.basic_module[level](torch.cat([refs[level], warped, flow_up], 1))
+        return flow
 
 
 class CRFP_DSV(nn.Module):

@@ -158,3 +158,48 @@ def fovea_head(state, x_hr, mask, lr, w_tttf, b_tttf, w_last, b_last, y_only=Fal
                                          out.data_ptr(), n, h, w, int(bool(y_only)), ws.data_ptr(), ws.numel(), _stream()),
                    "crfp_fovea_head_f32")
     return new_state, out
+
+
+def upsample_bilinear_ac(x, scale_factor, mul=1.0):
+    """F.interpolate(x, scale_factor=.., mode='bilinear', align_corners=True) * mul (SPyNet's flow upsampling)."""
+    x = _dev(x, "x")
+    n, c, h, w = x.shape
+    oh, ow = int(h * scale_factor), int(w * scale_factor)
+    out = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    with _on(x):
+        _lib.check(_lib.lib().crfp_upsample_bilinear_ac_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, oh, ow, float(mul), _stream()),
+                   "crfp_upsample_bilinear_ac_f32")
+    return out
+
+
+def convkxk(x, weight, bias, pre_relu=False):
+    """k x k stride-1 'same' convolution (k in 3, 5, 7), optional ReLU on the input (reference `conv`, model/CRFP.py:145-152)."""
+    x, weight, bias = _dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias")
+    n, cin, h, w = x.shape
+    cout, cin_w, k, k2 = weight.shape
+    assert cin_w == cin and k == k2
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    with _on(x, weight, bias):
+        _lib.check(_lib.lib().crfp_convkxk_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n, cin, cout, h, w,
+                                               k, int(bool(pre_relu)), _stream()), "crfp_convkxk_f32")
+    return out
+
+
+def spynet_forward(params, ref, supp):
+    """SPyNet.forward(ref, supp) (reference model/CRFP.py:698-741) in one native call; params = the 60 conv tensors in
+    state_dict order."""
+    import ctypes as C
+    ref, supp = _dev(ref, "ref"), _dev(supp, "supp")
+    if len(params) != 60:
+        raise ValueError(f"SPyNet has 60 conv parameters, got {len(params)}")
+    keep = [_dev(p.detach(), "params") for p in params]
+    n, c, h, w = ref.shape
+    assert c == 3 and tuple(supp.shape) == tuple(ref.shape)
+    L = _lib.lib()
+    ptrs = (C.c_void_p * 60)(*[t.data_ptr() for t in keep])
+    ws = _ws(L.crfp_spynet_workspace_bytes(n, h, w), ref.device)
+    flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=ref.device)
+    with _on(ref, supp, *keep):
+        _lib.check(L.crfp_spynet_forward(ptrs, ref.data_ptr(), supp.data_ptr(), flow.data_ptr(), n, h, w, ws.data_ptr(), ws.numel(),
+                                         _stream()), "crfp_spynet_forward")
+    return flow

@@ -97,6 +97,26 @@ def make_state_dict(seed: int = 0, mid: int = 32, y_only: bool = False) -> "Orde
     return sd
 
 
+SPYNET_CHANNELS = (8, 32, 64, 32, 16, 2)   # reference model/CRFP.py:693-734
+
+
+def make_spynet_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded weights for the reference's SPyNet (model/CRFP.py:554-741): keys in state_dict order (buffers ``mean`` /
+    ``std`` first, then ``basic_module.{L}.basic_module.{j}.conv.{weight,bias}``).  Scaled so that every pyramid level
+    adds a flow residual of a fraction of a pixel to a few pixels."""
+    rs = np.random.RandomState(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    sd["mean"] = np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 3, 1, 1)
+    sd["std"] = np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 3, 1, 1)
+    for lvl in range(6):
+        for j in range(5):
+            cin, cout = SPYNET_CHANNELS[j], SPYNET_CHANNELS[j + 1]
+            std = np.sqrt(2.0 / (cin * 49)) * (0.5 if j == 4 else 0.9)
+            sd[f"basic_module.{lvl}.basic_module.{j}.conv.weight"] = (rs.standard_normal((cout, cin, 7, 7)) * std).astype(np.float32)
+            sd[f"basic_module.{lvl}.basic_module.{j}.conv.bias"] = (rs.standard_normal((cout,)) * 0.05).astype(np.float32)
+    return sd
+
+
 def state_dict_digest(sd) -> str:
     h = hashlib.sha256()
     for k in sd:

@@ -29,6 +29,9 @@
  *   crfp_dsv_*                model/CRFP.py:1387-1706 CRFP_DSV (ctor weights, forward) and the
  *                             one-frame-per-call variant model/CRFP_test.py:2114-2478
  *   crfp_psnr_partial_f32     utils.py:166-185,242-254,328-330 (psnr_cuda / bgr2ycbcr(y_only))
+ *   crfp_spynet_forward       model/CRFP.py:554-741 SPyNet.forward (+ SPyNetBasicModule, `conv` :145-152)
+ *   crfp_convkxk_f32          model/CRFP.py:145-152 `conv`: ReLU -> nn.Conv2d(k, stride 1, pad k/2)
+ *   crfp_upsample_bilinear_ac_f32  F.interpolate(..., bilinear, align_corners=True) (model/CRFP.py:647-651)
  */
 #ifndef CRFP_HIP_H
 #define CRFP_HIP_H
@@ -89,6 +92,22 @@ int crfp_conv3x3_f32(const float* x, const float* weight, const float* bias, flo
  * are the source-index scales PyTorch uses (1/scale_factor for nn.Upsample, in/out for size=). */
 int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, int w, int oh, int ow,
                                float scale_h, float scale_w, float mul, void* stream);
+
+/* bilinear resize with align_corners=True (src = dst * (in - 1) / (out - 1)), NCHW f32; out = mul * resize(x). */
+int crfp_upsample_bilinear_ac_f32(const float* x, float* out, int n, int c, int h, int w, int oh, int ow, float mul, void* stream);
+
+/* k x k stride-1 pad-k/2 convolution (k in {3, 5, 7}), NCHW f32, direct fp32 FMA; pre_relu != 0 applies ReLU to the INPUT
+ * (the reference's `conv` module, model/CRFP.py:145-152: self.conv(self.act(x))). */
+int crfp_convkxk_f32(const float* x, const float* weight, const float* bias, float* out, int n, int cin, int cout, int h, int w,
+                     int k, int pre_relu, void* stream);
+
+/* ---- SPyNet.forward(ref, supp) -> flow[n,2,h,w] (model/CRFP.py:698-741), one call.  params: the 60 device pointers of
+ * the reference's state_dict order, basic_module.{L}.basic_module.{j}.conv.{weight,bias} for L = 0..5 (coarsest first),
+ * j = 0..4 (7x7 convs 8->32->64->32->16->2); the mean / std buffers are the ImageNet constants of :586-591. */
+#define CRFP_SPYNET_NUM_PARAMS 60
+size_t crfp_spynet_workspace_bytes(int n, int h, int w);
+int crfp_spynet_forward(const float* const* params, const float* ref, const float* supp, float* flow, int n, int h, int w,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- sum of squared differences for PSNR: acc[0] += sum((a-b)^2) over [n,c,h,w];
  * acc[1] += the same on the luma the reference's eval computes (24.966*c0+128.553*c1+65.481*c2+16,

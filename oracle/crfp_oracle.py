@@ -182,6 +182,37 @@ def fnet(P, pre: str, x1: Tensor, x2: Tensor) -> Tensor:
     return F.interpolate(o, size=(h, w), mode="bilinear", align_corners=False)
 
 
+def spynet(P, ref: Tensor, supp: Tensor, pre: str = "") -> Tensor:
+    """SPyNet.forward(ref, supp) (model/CRFP.py:698-741) with compute_flow (:593-664), SPyNetBasicModule (:686-741) and the
+    ``conv`` module whose ReLU precedes the convolution (:145-152).  P: ``basic_module.{L}.basic_module.{j}.conv.{weight,bias}``."""
+    n, _, h, w = ref.shape
+    w_up = w if w % 32 == 0 else 32 * (w // 32 + 1)                                         # :716-718
+    h_up = h if h % 32 == 0 else 32 * (h // 32 + 1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)                             # :586-591
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    pyr = []
+    for x in (ref, supp):
+        x = F.interpolate(x, size=(h_up, w_up), mode="bilinear", align_corners=False)       # :719-726
+        levels = [(x - mean) / std]                                                         # :620-621
+        for _ in range(5):
+            levels.append(F.avg_pool2d(levels[-1], 2, 2, count_include_pad=False))          # :624-636
+        pyr.append(levels[::-1])
+    flow = ref.new_zeros(n, 2, h_up // 32, w_up // 32)                                      # :641
+    for level in range(6):
+        flow_up = flow if level == 0 else F.interpolate(flow, scale_factor=2, mode="bilinear", align_corners=True) * 2.0  # :643-652
+        warped = flow_warp(pyr[1][level], flow_up.permute(0, 2, 3, 1), padding_mode="border")   # :655-657
+        x = torch.cat([pyr[0][level], warped, flow_up], 1)                                  # :658
+        for j in range(5):                                                                  # :693-734, :152
+            k = f"{pre}basic_module.{level}.basic_module.{j}.conv."
+            x = F.conv2d(F.relu(x), P[k + "weight"], P[k + "bias"], stride=1, padding=3)
+        flow = flow_up + x                                                                  # :660
+    flow = F.interpolate(flow, size=(h, w), mode="bilinear", align_corners=False)           # :728-733
+    flow = flow.clone()
+    flow[:, 0] *= float(w) / float(w_up)                                                    # :736-737
+    flow[:, 1] *= float(h) / float(h_up)
+    return flow
+
+
 def compute_flow(P, lrs: Tensor) -> Tensor:
     """CRFP_DSV.compute_flow (model/CRFP.py:1483-1508): flows_forward[n,t-1,2,h,w] =
     FNet(frame i, frame i-1) for i = 1..t-1 (FNet input order [current | previous])."""

@@ -246,3 +246,32 @@ def test_clip_forward_is_graph_capturable_and_replays_bit_exact():
         g.replay()
         torch.cuda.synchronize()
         assert maxdiff(out, eager[i]) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ SPyNet (a-4)
+def test_spynet_vs_reference_golden(orc):
+    """crfp_spynet_forward (one native call: resize + normalise, 5-level avg-pool pyramid, align_corners=True flow
+    upsampling, border warp, 30 ReLU-before-conv 7x7 convs) against the flow of the imported reference SPyNet, for a size
+    that is resized up to a multiple of 32 and one that is not; the per-operator route (SPyNet.compute_flow) agrees."""
+    from crfp_amd import synth
+    from crfp_amd.model import CRFP
+    g = dict(np.load(os.path.join(GOLDEN, "spynet_small.npz")))
+    sd = synth.make_spynet_state_dict(int(g["weights_seed"]))
+    m = CRFP.SPyNet(None, dev())
+    m.load_state_dict({k: T(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.to(dev()).eval()
+    for tag in "ab":
+        ref, supp = T(g[tag + "_ref"]).to(dev()), T(g[tag + "_supp"]).to(dev())
+        flow = m(ref, supp)
+        assert maxdiff(flow, g[tag + "_flow"]) < 2e-4, tag          # pixels; flows reach ~2 px
+    ref, supp = T(g["b_ref"]).to(dev()), T(g["b_supp"]).to(dev())   # 64 x 96: forward == compute_flow (no resize)
+    assert maxdiff(m.compute_flow(ref, supp), g["b_flow"]) < 2e-4
+    # SPyNetBasicModule alone, signed input: the ReLU sits in front of every conv, the first included (model/CRFP.py:152)
+    assert maxdiff(m.basic_module[3](T(g["bm_x"]).to(dev())), g["bm_y"]) < 1e-4
+    x = T(g["bm_x"]).to(dev())
+    w, b = m.basic_module[3].basic_module[0].conv.weight, m.basic_module[3].basic_module[0].conv.bias
+    from crfp_amd import ops
+    assert maxdiff(ops.convkxk(x, w, b, pre_relu=True), F.conv2d(F.relu(x.cpu()), w.cpu(), b.cpu(), padding=3)) < 2e-5
+    assert maxdiff(ops.convkxk(x, w, b, pre_relu=False), F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=3)) < 2e-5
+    up = ops.upsample_bilinear_ac(x, 2, mul=2.0)
+    assert maxdiff(up, F.interpolate(x.cpu(), scale_factor=2, mode="bilinear", align_corners=True) * 2.0) < 1e-5

@@ -153,3 +153,24 @@ def test_masked_psnr_ssim_against_reference(ops_golden):
     ys, yh = orc.to_y(sr.permute(0, 2, 3, 1)), orc.to_y(hr.permute(0, 2, 3, 1))
     py, sy = orc.calc_psnr_and_ssim(ys, yh, ones)
     assert abs(py - float(g["metric_psnr_y"])) < 1e-4 and abs(sy - float(g["metric_ssim_y"])) < 1e-6
+
+
+def test_spynet_oracle_matches_reference_golden():
+    """oracle.spynet against the flow the imported reference SPyNet produced
+    (tests/golden/make_spynet_golden.py): same ATen ops, so the match is exact; also pins the seeded weight stream."""
+    import os
+    from conftest import GOLDEN
+    from crfp_amd import synth
+    from oracle import crfp_oracle as orc
+    g = dict(np.load(os.path.join(GOLDEN, "spynet_small.npz")))
+    sd = synth.make_spynet_state_dict(int(g["weights_seed"]))
+    assert synth.state_dict_digest(sd) == str(g["weights_sha256"])
+    P = orc.load_numpy_state(sd)
+    for tag in "ab":
+        f = orc.spynet(P, torch.from_numpy(g[tag + "_ref"]), torch.from_numpy(g[tag + "_supp"]))
+        assert float((f - torch.from_numpy(g[tag + "_flow"])).abs().max()) < 1e-6
+    # the mirror holds exactly the reference's state_dict (keys, order, shapes)
+    from crfp_amd.model import CRFP
+    m = CRFP.SPyNet(None, torch.device("cpu"))
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
