@@ -1,0 +1,209 @@
+"""Host-side mirror of the reference's benchmark-only wiring ``model/CRFP_runtime.py::MRCF_simple_v18`` (:8364-8682), the
+model ``test_runtime.py`` builds through ``from model import MRCF_runtime`` (:1,41) and calls as
+``model(lr, fv, warp_size=(WP_h, WP_w))`` (:142).  Same constructor, parameter names and call signature; every
+convolution, warp, DCN and resize runs in libcrfp_hip.so through the per-operator C-ABI (crfp_amd.ops), the remaining
+steps are views / crops / concatenations of device tensors.
+
+How this wiring differs from CRFP_DSV (model/CRFP.py:1387-1706) -- restated from the cited lines:
+  * flow (FNet), warps and all four DCNs only see the top-left ``warp_size`` window (:8487, :8533-8620); the 8x state that
+    is carried to the next frame is that window (:8645);
+  * the 32-channel 2x-resolution "previous" features are ``downsample(state)`` and ``downsample(warp(state))`` (:8533-8535)
+    instead of warp(downsample(state));
+  * levels 0-2 all start from the SAME ``upsample(x_lr)`` features: they only produce the carried 8-channel features
+    and the propagated offset feature (:8549-8599, the prop lines are commented out);
+  * ``ResidualBlocksWithInputConv_v2`` (:511-556): conv1 on the (windowed) first input pasted over conv2 of the
+    (full-frame) second input, then LeakyReLU + one residual block; separate ``forward_resblocks_k_`` for frame 0;
+  * the fovea is a ``fv`` crop fed twice to encoder_hr (:8507) and pasted over the top-left ``fv`` pixels of the state
+    without a mask (:8637-8640); the per-stage timings are printed (:8654-8662).
+"""
+import torch
+import torch.nn as nn
+
+from crfp_amd import ops
+from . import LTE
+from .CRFP import DCN_module, FNet, PixelShufflePack, PixelUnShufflePack_v2, _run, conv3x3, flow_warp
+
+
+class ResidualBlockNoBN(nn.Module):
+    """reference model/CRFP_runtime.py:406-462: in this file the block is a bottleneck, C -> C/2 -> C."""
+
+    def __init__(self, mid_channels=64, res_scale=1.0):
+        super().__init__()
+        self.res_scale = res_scale
+        self.conv1 = nn.Conv2d(mid_channels, mid_channels // 2, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(mid_channels // 2, mid_channels, 3, 1, 1, bias=True)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return x + _run(self.conv2, _run(self.conv1, x, "relu")) * self.res_scale
+
+
+class ResidualBlocksWithInputConv_v2(nn.Module):
+    """reference model/CRFP_runtime.py:511-556 (``_DIV`` = 2).  In that file the plain ``ResidualBlocksWithInputConv``
+    (:464-509) has the same two-input form with a conv2 of in_channels // 3 inputs (``_DIV`` = 3)."""
+    _DIV = 2
+
+    def __init__(self, in_channels, out_channels=64, num_blocks=30):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(in_channels // self._DIV, out_channels, 3, 1, 1, bias=True)
+        self.main = nn.Sequential(nn.LeakyReLU(negative_slope=0.1, inplace=True),
+                                  nn.Sequential(*[ResidualBlockNoBN(mid_channels=out_channels) for _ in range(num_blocks)]))
+
+    def forward(self, feat1, feat2=None):
+        # LeakyReLU commutes with the paste (both are elementwise / positional), so it is fused into the two convolutions
+        if torch.is_tensor(feat2):
+            H, W = feat1.shape[-2:]
+            feat = _run(self.conv2, feat2, "lrelu")
+            feat[:, :, :H, :W] = _run(self.conv1, feat1, "lrelu")
+        else:
+            feat = _run(self.conv1, feat1, "lrelu")
+        for blk in self.main[1]:
+            feat = blk(feat)
+        return feat
+
+
+class ResidualBlocksWithInputConv(ResidualBlocksWithInputConv_v2):
+    """reference model/CRFP_runtime.py:464-509"""
+    _DIV = 3
+
+
+class MRCF_simple_v18(nn.Module):
+    def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, split_ratio=3,
+                 spynet_pretrained=None):
+        super().__init__()
+        if mid_channels % 8 or split_ratio != 3:
+            raise NotImplementedError("runtime variant: mid_channels % 8 == 0 and split_ratio 3 (test_runtime.py:36-41)")
+        self.device = device
+        self.mid_channels, self.last_channels = mid_channels, mid_channels // 8
+        self.dg_num, self.dk, self.max_residue_magnitude = 8, 3, 10
+        self.y_only, self.hr_dcn, self.offset_prop, self.split_ratio = y_only, hr_dcn, offset_prop, split_ratio
+        m, l = mid_channels, mid_channels // 8
+        self.spynet = FNet(in_nc=3)       # spynet_pretrained is accepted and ignored, as in the reference (:8385)
+        self.dcn_0 = DCN_module(m, 8, 3, 10)
+        self.dcn_1 = DCN_module(m, 8, 3, 10, pre_offset=offset_prop, interpolate='none')
+        self.dcn_2 = DCN_module(m, 8, 3, 10, pre_offset=offset_prop, interpolate='none')
+        self.dcn_3 = DCN_module(l, 1, 3, 10, repeat=True, pre_offset=offset_prop, interpolate='pixelshuffle')
+        self.encoder_lr = LTE.LTE_simple_lr(m)
+        self.encoder_hr = LTE.LTE_simple_hr_single(l)
+        self.conv_tttf = conv3x3(l * 2, l)
+        p = (m * split_ratio) // 4
+        self.forward_resblocks_0_ = ResidualBlocksWithInputConv(p, m, 1)
+        self.forward_resblocks_1_ = ResidualBlocksWithInputConv(p, m, 1)
+        self.forward_resblocks_2_ = ResidualBlocksWithInputConv(p, m, 1)
+        self.forward_resblocks_3_ = ResidualBlocksWithInputConv(l, l, 1)
+        self.forward_resblocks_0 = ResidualBlocksWithInputConv_v2(m * 2, m, 1)
+        self.forward_resblocks_1 = ResidualBlocksWithInputConv_v2(m * 2, m, 1)
+        self.forward_resblocks_2 = ResidualBlocksWithInputConv_v2(m * 2, m, 1)
+        self.forward_resblocks_3 = ResidualBlocksWithInputConv_v2(l * 2, l, 1)
+        self.downsample = PixelUnShufflePack_v2(l, m, 4, downsample_kernel=3)
+        self.upsample = PixelShufflePack(m, p, 2, upsample_kernel=3)
+        self.upsample_post = PixelShufflePack(p, l, 4, upsample_kernel=3)
+        self.conv_last = nn.Conv2d(l, 1 if y_only else 3, 3, 1, 1)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+        self.print_timings = True        # the reference prints its stage means on every call (:8654-8662)
+        self.last_timings = {}
+
+    def compute_flow(self, lrs):
+        n, t, c, h, w = lrs.shape
+        lrs_1 = lrs[:, :-1].reshape(-1, c, h, w)
+        lrs_2 = lrs[:, 1:].reshape(-1, c, h, w)
+        return self.spynet(lrs_2.contiguous(), lrs_1.contiguous()).view(n, t - 1, 2, h, w), None
+
+    @torch.no_grad()
+    def forward(self, lrs, fvs, warp_size=(1080, 1920)):
+        WP_h, WP_w = warp_size
+        n, t, c, h, w = lrs.shape
+        lists = {k: [] for k in ("flow", "enc", "dcn", "res", "last")}
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def tic():
+            torch.cuda.synchronize()
+            start.record()
+
+        def toc(key):
+            end.record()
+            torch.cuda.synchronize()
+            lists[key].append(start.elapsed_time(end) / 1000)
+
+        tic()
+        flows_forward, _ = self.compute_flow(lrs[:, :, :, :WP_h // 8, :WP_w // 8].contiguous()) if t > 1 else (None, None)
+        toc("flow")
+
+        tic()
+        lrs_lv0 = lrs.reshape(n * t, c, h, w)
+        _, _, x_lr_lv0 = self.encoder_lr(lrs_lv0, islr=True)
+        B, N, C, Hf, Wf = fvs.shape
+        fv2 = fvs.reshape(B * N, C, Hf, Wf)
+        _, _, x_hr_lv3 = self.encoder_hr(torch.cat((fv2, fv2), dim=1), islr=True)
+        x_lr_lv0 = x_lr_lv0.view(n, t, -1, h, w)
+        x_hr_lv3 = x_hr_lv3.view(n, t, -1, Hf, Wf)
+        toc("enc")
+
+        up2 = lambda f: ops.upsample_bilinear(f, scale_factor=2, mul=2.0)   # noqa: E731  img_upsample_2x(flow) * 2.
+        up8 = lambda f: ops.upsample_bilinear(f, scale_factor=8, mul=8.0)   # noqa: E731
+        sr = self.split_ratio
+        outputs = []
+        feat_prop_lv3 = feat_lv = None
+        for i in range(t):
+            lr_cur = lrs[:, i].contiguous()
+            x_hr_cur = x_hr_lv3[:, i]
+            feat_prop_lv0 = self.upsample(x_lr_lv0[:, i].contiguous())
+            if i > 0:
+                tic()
+                flow = flows_forward[:, i - 1].contiguous()
+                flow_lv3, flow_lv0 = up2(flow), up8(flow)
+                state = feat_prop_lv3                                            # the previous frame's window state
+                state_w = flow_warp(state, flow_lv0.permute(0, 2, 3, 1).contiguous())
+                prev2_w = self.downsample(state_w)
+                prev2 = self.downsample(state)
+                mix = flow_warp(torch.cat(feat_lv, dim=1), flow_lv3.permute(0, 2, 3, 1).contiguous())
+                feat_lv = list(torch.chunk(mix, 3, dim=1))
+                cur_win = feat_prop_lv0[:, :, :WP_h // 4, :WP_w // 4]
+                offset = None
+                for k, (dcn, rb) in enumerate(((self.dcn_0, self.forward_resblocks_0), (self.dcn_1, self.forward_resblocks_1),
+                                               (self.dcn_2, self.forward_resblocks_2))):
+                    feat_temp = torch.cat((cur_win, feat_lv[k]), dim=1)
+                    aligned, offset = dcn(feat_temp, prev2, prev2_w, flow_lv3, offset)
+                    if not self.offset_prop:
+                        offset = None
+                    y = rb(torch.cat([feat_temp, aligned], dim=1), feat_temp)
+                    feat_lv[k] = torch.cat(torch.chunk(y, 4, dim=1)[sr:4], dim=1)[:, :, :WP_h // 4, :WP_w // 4].contiguous()
+                feat_prop_lv0 = torch.nn.functional.leaky_relu(self.upsample_post(feat_prop_lv0), 0.1)
+                win = feat_prop_lv0[:, :, :WP_h, :WP_w].contiguous()
+                aligned, _ = self.dcn_3(win, state, state_w, flow_lv0, offset)
+                feat_prop_lv3 = self.forward_resblocks_3(torch.cat([win, aligned], dim=1), feat_prop_lv0)
+                toc("dcn")
+            else:
+                tic()
+                feat_lv = []
+                for rb in (self.forward_resblocks_0_, self.forward_resblocks_1_, self.forward_resblocks_2_):
+                    ch = torch.chunk(rb(feat_prop_lv0), 4, dim=1)
+                    feat_lv.append(torch.cat(ch[sr:4], dim=1)[:, :, :WP_h // 4, :WP_w // 4].contiguous())
+                    feat_prop_lv0 = torch.cat(ch[:sr], dim=1).contiguous()
+                feat_prop_lv0 = torch.nn.functional.leaky_relu(self.upsample_post(feat_prop_lv0), 0.1)
+                feat_prop_lv3 = self.forward_resblocks_3_(feat_prop_lv0)
+                toc("res")
+            tic()
+            fused = _run(self.conv_tttf, torch.cat([feat_prop_lv3[:, :, :Hf, :Wf], x_hr_cur], dim=1).contiguous())
+            feat_prop_lv3[:, :, :Hf, :Wf] = fused
+            feat_prop_lv3 = torch.nn.functional.leaky_relu(feat_prop_lv3, 0.1)
+            out = _run(self.conv_last, feat_prop_lv3) + ops.upsample_bilinear(lr_cur, scale_factor=8)
+            feat_prop_lv3 = feat_prop_lv3[:, :, :WP_h, :WP_w].contiguous()
+            outputs.append(out)
+            toc("last")
+        mean = lambda v: sum(v) / len(v) if v else 0.0   # noqa: E731
+        self.last_timings = {k: mean(v) for k, v in lists.items()}
+        if self.print_timings:
+            for k in ("flow", "enc", "dcn", "res", "last"):
+                print(self.last_timings[k], k)
+            print(self.last_timings["flow"] + self.last_timings["enc"] + self.last_timings["dcn"] + self.last_timings["last"], 'total')
+        return torch.stack(outputs, dim=1)
+
+    def init_weights(self, pretrained=None, strict=True):
+        if isinstance(pretrained, str):
+            sd = self.state_dict()
+            sd.update(torch.load(pretrained, map_location="cpu"))
+            self.load_state_dict(sd, strict=strict)
+        elif pretrained is not None:
+            raise TypeError(f'"pretrained" must be a str or None. But received {type(pretrained)}.')

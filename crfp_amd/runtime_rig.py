@@ -1,15 +1,17 @@
 """Timing rig with the shape and the arithmetic of the reference's stand-alone speed test (test_runtime.py:81-99,
-128-129,142-186): 1 x 5 frames, LR 135 x 240 -> 1080 x 1920, a 96 x 96 fovea crop, 30 repetitions of which the first
-10 are warm-up, prints the output shape and seconds per frame = time / (repeat - warm_up + 1) / t exactly as the
-reference's last line does (its divisor counts one repetition too many; kept, so the printed number is comparable).
+128-129,142-186): 1 x 5 frames, LR 135 x 240 -> 1080 x 1920, a 96 x 96 fovea crop, a 720 x 720 warp window, 30 repetitions
+of which the first 10 are warm-up; prints the output shape and seconds per frame = time / (repeat - warm_up + 1) / t
+exactly as the reference's last line does (its divisor counts one repetition too many; kept, so the number is comparable).
 
-What it is NOT: the reference's rig drives a benchmark-only wiring (model/CRFP_runtime.py:8364-8682 -- flow and alignment
-restricted to the top-left ``warp_size`` window, encoder_hr on the crop, other residual-block classes) through an import
-that does not exist in the reference repo (``model.MRCF_runtime``).  That wiring is not built here;
-this rig runs the shipped CRFP_DSV path over the WHOLE frame with the crop pasted at the top-left of the window, i.e. it
-does at least the work of the reference's variant.  ``warp_size`` is accepted and only used to place the crop.
+Two variants:
+  regional (default)  what test_runtime.py itself runs: ``MRCF_runtime.MRCF_simple_v18(...)(lr, fv, warp_size=(720, 720))``
+                      = crfp_amd/model/CRFP_runtime.py, the mirror of the reference's benchmark-only wiring
+                      (model/CRFP_runtime.py:8364-8682), composed of per-operator C-ABI calls; it prints the reference's
+                      per-stage means (flow / enc / dcn / res / last / total) on every call.
+  dsv                 the shipped CRFP_DSV engine (one C-ABI call per clip) over the WHOLE frame with the crop pasted into
+                      the warp window -- at least the work of the regional wiring, on the fused path.
 
-    python -m crfp_amd.runtime_rig [--repeat 30 --warm-up 10 --t 5 --hr 1080 1920 --fv 96 --warp 720 720]
+    python -m crfp_amd.runtime_rig [--variant regional|dsv] [--repeat 30 --warm-up 10 --t 5 --hr 1080 1920 --fv 96 --warp 720 720]
 """
 from __future__ import annotations
 
@@ -33,17 +35,28 @@ def build_inputs(lr: torch.Tensor, fv: torch.Tensor, warp_size):
     return lr, fvs, mks
 
 
-def run(repeat_time=30, warm_up=10, t=5, hr=(1080, 1920), fv_size=96, warp_size=(720, 720), device="cuda:0", seed=7):
+def run(repeat_time=30, warm_up=10, t=5, hr=(1080, 1920), fv_size=96, warp_size=(720, 720), device="cuda:0", seed=7,
+        variant="regional", quiet=True):
     from . import synth
-    from .model import CRFP
+    from .model import CRFP, MRCF_runtime
     dev = torch.device(device)
-    model = CRFP.CRFP_DSV(device=dev, mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True)
-    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(seed).items()}, strict=True)
-    model = model.to(dev).eval()
     g = torch.Generator(device="cpu").manual_seed(seed)
     lr = torch.rand(1, t, 3, hr[0] // 8, hr[1] // 8, generator=g).to(dev)
     fv = torch.rand(1, t, 3, fv_size, fv_size, generator=g).to(dev)
-    lrs, fvs, mks = build_inputs(lr, fv, warp_size)
+    if variant == "regional":   # test_runtime.py:41,142
+        net = MRCF_runtime.MRCF_simple_v18(mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True, split_ratio=3,
+                                           spynet_pretrained='pretrained_models/fnet.pth', device=dev)
+        sd = synth.make_state_dict_like({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        net = net.to(dev).eval()
+        net.print_timings = not quiet
+        model = lambda lrs, fvs, mks: net(lrs, fvs, warp_size=warp_size)   # noqa: E731
+        lrs, fvs, mks = lr, fv, None
+    else:
+        net = CRFP.CRFP_DSV(device=dev, mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(seed).items()}, strict=True)
+        model = net.to(dev).eval()
+        lrs, fvs, mks = build_inputs(lr, fv, warp_size)
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     infer_time, y = 0.0, None
     with torch.no_grad():
@@ -67,8 +80,10 @@ def main(argv=None):
     ap.add_argument("--hr", type=int, nargs=2, default=(1080, 1920))
     ap.add_argument("--fv", type=int, default=96)
     ap.add_argument("--warp", type=int, nargs=2, default=(720, 720))
+    ap.add_argument("--variant", choices=("regional", "dsv"), default="regional")
+    ap.add_argument("--stage-prints", action="store_true", help="regional: print the per-stage means on every call, as the reference does")
     a = ap.parse_args(argv)
-    y, s_per_frame = run(a.repeat, a.warm_up, a.t, tuple(a.hr), a.fv, tuple(a.warp))
+    y, s_per_frame = run(a.repeat, a.warm_up, a.t, tuple(a.hr), a.fv, tuple(a.warp), variant=a.variant, quiet=not a.stage_prints)
     print(y.shape, s_per_frame)   # test_runtime.py:186
 
 

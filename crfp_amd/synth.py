@@ -97,6 +97,39 @@ def make_state_dict(seed: int = 0, mid: int = 32, y_only: bool = False) -> "Orde
     return sd
 
 
+def make_state_dict_like(shapes, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded, numerically healthy weights for any conv-only state_dict given as ``{key: shape}`` in state_dict order (used
+    for the regional-DCN runtime wiring, whose key table comes from the module itself): the scaling rules of
+    ``make_state_dict`` applied by key name."""
+    rs = np.random.RandomState(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for key, shape in shapes.items():
+        shape = tuple(int(v) for v in shape)
+        stem = key.rsplit(".", 1)[0]
+        if key.endswith(".bias"):
+            b = rs.standard_normal(shape) * 0.02
+            if stem == "spynet.flow.2":
+                b *= 0.1
+            sd[key] = b.astype(np.float32)
+            continue
+        cout, cin = shape[0], shape[1]
+        w = rs.standard_normal(shape) * (np.sqrt(2.0 / (cin * 9)) * 0.8)
+        if stem.endswith("conv1") or stem.endswith("conv2"):
+            w *= 0.3 if ".main." in stem else 1.0     # residual branches small; the v2 blocks' input convs are full size
+        if stem == "spynet.flow.2":
+            w *= 0.12
+        if stem.endswith("dcn_offset"):
+            w *= 0.8
+        if stem.endswith("dcn_mask"):
+            w *= 1.5
+        if stem.endswith(".dcn"):
+            w *= 0.25
+            c = min(cout, cin)
+            w[np.arange(c), np.arange(c), 1, 1] += 1.0
+        sd[key] = np.ascontiguousarray(w.astype(np.float32))
+    return sd
+
+
 SPYNET_CHANNELS = (8, 32, 64, 32, 16, 2)   # reference model/CRFP.py:693-734
 
 

@@ -338,8 +338,9 @@ def test_batch_of_two_clips(orc):
 def test_runtime_rig_smoke():
     """crfp_amd.runtime_rig (shape and arithmetic of the reference's test_runtime.py) on a small frame."""
     from crfp_amd import runtime_rig
-    y, spf = runtime_rig.run(repeat_time=3, warm_up=1, t=2, hr=(136, 200), fv_size=48, warp_size=(96, 96))
-    assert tuple(y.shape) == (1, 2, 3, 136, 200) and spf > 0 and bool(torch.isfinite(y).all())
+    for variant in ("dsv", "regional"):
+        y, spf = runtime_rig.run(repeat_time=3, warm_up=1, t=2, hr=(136, 200), fv_size=48, warp_size=(96, 96), variant=variant)
+        assert tuple(y.shape) == (1, 2, 3, 136, 200) and spf > 0 and bool(torch.isfinite(y).all()), variant
     lr = torch.zeros(1, 2, 3, 17, 25)
     lrs, fvs, mks = runtime_rig.build_inputs(lr, torch.ones(1, 2, 3, 48, 48), (96, 96))
     assert int(mks.sum()) == 2 * 48 * 48 and float(fvs.sum()) == 2 * 3 * 48 * 48 and bool(mks[0, 0, 0, 24, 24])

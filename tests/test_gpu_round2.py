@@ -275,3 +275,30 @@ def test_spynet_vs_reference_golden(orc):
     assert maxdiff(ops.convkxk(x, w, b, pre_relu=False), F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=3)) < 2e-5
     up = ops.upsample_bilinear_ac(x, 2, mul=2.0)
     assert maxdiff(up, F.interpolate(x.cpu(), scale_factor=2, mode="bilinear", align_corners=True) * 2.0) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ regional-DCN runtime wiring (a-20 / f4)
+def test_runtime_variant_vs_reference_golden(orc, capsys):
+    """``MRCF_runtime.MRCF_simple_v18(...)(lr, fv, warp_size=)`` -- the call test_runtime.py:41,142 makes -- on the HIP
+    operators against the output of the reference class (tests/golden/runtime_small.npz) and, at another geometry, against
+    the oracle twin; it prints the reference's six per-stage lines."""
+    from crfp_amd import synth
+    from crfp_amd.model import MRCF_runtime
+    from oracle import runtime_oracle as ro
+    g = dict(np.load(os.path.join(GOLDEN, "runtime_small.npz")))
+    m = MRCF_runtime.MRCF_simple_v18(mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True, split_ratio=3,
+                                     spynet_pretrained='pretrained_models/fnet.pth', device=dev())
+    sd = synth.make_state_dict_like({k: tuple(v.shape) for k, v in m.state_dict().items()}, int(g["weights_seed"]))
+    m.load_state_dict({k: T(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.to(dev()).eval()
+    out = m(T(g["lrs"]).to(dev()), T(g["fvs"]).to(dev()), warp_size=tuple(int(v) for v in g["warp"]))
+    assert maxdiff(out, g["out"]) < 2e-4
+    printed = capsys.readouterr().out.split()
+    assert printed[1::2] == ["flow", "enc", "dcn", "res", "last", "total"]
+    # another geometry: window = whole frame in y, partial in x; 2 frames
+    lrs = T(synth.make_clip(9, 1, 2, 16, 40, fv_size=32)[0])
+    fvs = torch.rand(1, 2, 3, 48, 48, generator=torch.Generator().manual_seed(1))
+    m.print_timings = False
+    got = m(lrs.to(dev()), fvs.to(dev()), warp_size=(128, 192))
+    ref = ro.runtime_forward(orc.load_numpy_state(sd), lrs, fvs, (128, 192))
+    assert tuple(got.shape) == (1, 2, 3, 128, 320) and maxdiff(got, ref) < 2e-4

@@ -174,3 +174,26 @@ def test_spynet_oracle_matches_reference_golden():
     m = CRFP.SPyNet(None, torch.device("cpu"))
     assert list(m.state_dict().keys()) == list(sd.keys())
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+
+
+def test_runtime_variant_oracle_matches_reference_golden():
+    """oracle.runtime_oracle (the regional-DCN benchmark wiring) against the output of
+    the reference class itself, run on the CPU by tests/golden/make_runtime_golden.py; also pins the mirror's state_dict
+    table (158 keys incl. the two-input residual blocks and their bottleneck residual branch) and the seeded weights."""
+    import os
+    from conftest import GOLDEN
+    from crfp_amd import synth
+    from crfp_amd.model import MRCF_runtime
+    from oracle import crfp_oracle as orc, runtime_oracle as ro
+    g = dict(np.load(os.path.join(GOLDEN, "runtime_small.npz")))
+    m = MRCF_runtime.MRCF_simple_v18(mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True, split_ratio=3,
+                                     spynet_pretrained='pretrained_models/fnet.pth', device=torch.device("cpu"))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert list(shapes) == list(g["keys"]) and [str(s) for s in shapes.values()] == list(g["shapes"])
+    sd = synth.make_state_dict_like(shapes, int(g["weights_seed"]))
+    assert synth.state_dict_digest(sd) == str(g["weights_sha256"])
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    with torch.no_grad():
+        out = ro.runtime_forward(orc.load_numpy_state(sd), torch.from_numpy(g["lrs"]), torch.from_numpy(g["fvs"]),
+                                 tuple(int(v) for v in g["warp"]))
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) < 1e-6
