@@ -146,7 +146,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from crfp_amd import _lib, ops, synth
+    from crfp_amd import _lib, benchutil, ops, synth
     from crfp_amd.engine import DSVEngine
     from crfp_amd.model import CRFP
 
@@ -158,7 +158,7 @@ def main():
     model.storage = storage
     model = model.to(dev).eval()
     # every rank (and every clip of a rank) gets its own clip: independent units, no data-path collective
-    data_np = [synth.make_clip(1234 + rank * clips + c, 1, t, h, w, fv_size=fv, sigma_t=cfg["sigma"]) for c in range(clips)]
+    data_np = [synth.make_clip(seed, 1, t, h, w, fv_size=fv, sigma_t=cfg["sigma"]) for seed in benchutil.rank_clip_seeds(rank, clips)]
     data = [tuple(torch.from_numpy(a).to(dev) for a in d) for d in data_np]
     eng = model.engine()
     n_flight = max(1, min(args.in_flight, clips)) if mode == "clip" else 1
@@ -203,10 +203,7 @@ def main():
             outs = step()
         barrier()
         elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = benchutil.reduce_elapsed(elapsed, dist, dev)
     frames_per_step = t * clips
     assert not eng.overflowed(stream=(mode == "stream")), "numerics guard fired on the benchmark clip"
 
@@ -214,24 +211,23 @@ def main():
     # HR scene inside the fovea window (not a quality figure without trained weights: it exercises the reduction)
     last = outs[-1] if mode == "stream" else outs[-1][0, -1]
     acc = ops.sq_err_sums(last[None].contiguous(), data[-1][1][0, -1][None].contiguous()).clone()
-    vec = torch.cat([acc, torch.tensor([float(frames_per_step)], dtype=torch.float64, device=dev)])
-    if dist is not None:
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    vec = benchutil.reduce_sums(torch.cat([acc, torch.tensor([float(frames_per_step)], dtype=torch.float64, device=dev)]), dist)
+    agg = benchutil.aggregate(world, args.steps, frames_per_step, elapsed)
 
     arithmetic = ("fp32 in / fp32 accumulate / fp32 out; products on the fp16 MFMA via an exact 2-term split (3 MFMAs per MAC, "
                   "error at the fp32 summation-order floor, see `parity`)") if storage == "f32" else (
                   "bf16 activations + recurrent state in HBM, bf16 conv / DCN weights, one bf16 MFMA per MAC, fp32 accumulate; fp32 "
                   "flow / offsets / masks / API tensors (include/crfp_hip.h, 'bf16 storage')")
     result = {
-        "metric": "sr_frames_per_sec", "value": world * args.steps * frames_per_step / elapsed, "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "metric": "sr_frames_per_sec", "value": agg["value"], "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": agg["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if storage == "f32" else "bf16",
         "data": "synthetic",
         "config": {"workload": cfg["name"] + (" [with command-line overrides]" if custom else ""), "baseline_config_index": cfg["index"],
                    "conv_arithmetic": arithmetic, "mode": mode, "frames_per_clip": t, "lr": [h, w], "sr": [8 * h, 8 * w],
                    "fv_size": fv, "sigma_t": cfg["sigma"], "clips_per_gpu_per_step": clips, "clips_in_flight_per_gpu": n_flight,
                    "storage": storage, "parallelism": f"clip-sharded x{world}"},
-        "per_gpu_frames_per_sec": args.steps * frames_per_step / elapsed,
+        "per_gpu_frames_per_sec": agg["per_gpu_frames_per_sec"],
         "frames_per_step_per_gpu": frames_per_step,
     }
 

@@ -59,3 +59,41 @@ def test_two_rank_eval_matches_single_process():
         assert res["frames"] == single["frames"] == 2 * n_clips
         assert abs(res["psnr"] - single["psnr"]) < 1e-12
         assert abs(res["psnr_y"] - single["psnr_y"]) < 1e-12
+
+
+def bench_worker(rank, world, port, q):
+    """bench.py's multi-rank bookkeeping (crfp_amd.benchutil) with the compute stubbed: each rank 'measures' its own
+    elapsed time and squared-error sums; rank results must combine exactly as bench.py reports them."""
+    sys.path.insert(0, ROOT)
+    from crfp_amd import benchutil
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    clips, t, steps = 4, 7, 5
+    seeds = benchutil.rank_clip_seeds(rank, clips)
+    elapsed = benchutil.reduce_elapsed(0.10 + 0.03 * rank, dist)            # the slower rank defines the step
+    vec = benchutil.reduce_sums(torch.tensor([100.0 + rank, 10.0 * (rank + 1), float(t * clips)], dtype=torch.float64), dist)
+    q.put((rank, seeds, elapsed, vec.tolist(), benchutil.aggregate(world, steps, t * clips, elapsed)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_reduction_path_two_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    all_seeds = sum((g[1] for g in got), [])
+    assert len(set(all_seeds)) == 8 and all_seeds == list(range(1234, 1242))      # 2 ranks x 4 clips, all distinct
+    for _, _, elapsed, vec, agg in got:
+        assert abs(elapsed - 0.13) < 1e-12                                          # MAX over ranks
+        assert vec == [201.0, 30.0, 56.0]                                           # SUM over ranks
+        assert abs(agg["value"] - 2 * 5 * 28 / 0.13) < 1e-9 and abs(agg["per_gpu_frames_per_sec"] - 5 * 28 / 0.13) < 1e-9
+        assert abs(agg["ms_per_step"] - 26.0) < 1e-9

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-multi-stream"
+CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-extras ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- $CMD > /dev/null 2> $OUT/mfma.err
 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/lds -- $CMD > /dev/null 2> $OUT/lds.err
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- $CMD > /dev/null 2> $OUT/sq.err
