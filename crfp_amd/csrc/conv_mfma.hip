@@ -881,7 +881,7 @@ __device__ __forceinline__ cu32x2 quad_words(cu32x2 r, int m, bool valid) {
 }
 
 template <int RPW>
-__global__ __launch_bounds__(256, 4) void conv3x3_bf16_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, RPW == 1 ? 4 : 3) void conv3x3_bf16_kernel(const ConvArgs a) {
     constexpr int CT = 1, TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
     constexpr int NEL = LH * LW;                 // halo pixels
     constexpr int NIN = (NEL + 255) / 256;       // halo pixels per thread; each carries the chunk's 4 quads
@@ -1846,6 +1846,8 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
 #endif
     if (split) {
 #ifdef CRFP_ACT_BF16
+        // (8-row tiles, conv3x3_bf16_kernel<2>: 1.25 instead of 1.5 ds_read_b128 per MFMA and half the weight staging, but 450
+        // workgroups on 256 CUs -- measured neutral to -8 % per conv, so 4-row tiles stay)
         conv3x3_bf16_kernel<1><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
 #else
         conv3x3_split_kernel<1, 1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);

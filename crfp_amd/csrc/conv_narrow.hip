@@ -304,6 +304,237 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
 #undef CRFP_NARROW_LOAD
 }
 
+// ---------------------------------------------------------------- two stencils in one pass (A -> B)
+// conv A (KQA input quads -> 4 channels, activation) feeding conv B (that quad -> 4 channels, NE_PLAIN with optional residual
+// or the dcn_3 offset/mask epilogue) without the round trip of A's output through HBM: at 8x resolution every tensor is
+// 59 MB (fp32 @A), a write + a read of it is ~19 us of HBM time, plus one launch and one persistent-loop ramp.  Used where
+// A's output has no other reader: encoder_hr.0 -> .2, dcn_3.conv_fuse -> offset/mask head, res3.conv1 -> conv2(+x).
+// Per 16 x 64 output tile: the (16+4) x (64+4) halo of A's inputs is staged in LDS as before; A is evaluated on the
+// (16+2) x (64+2) region B needs -- 1188 pixels, thread t takes pixels t, t+256, ... (five 4x4x1-MFMA chains per lane; the
+// MFMA form pairs every lane with its own pixel, so any pixel-to-lane map works) -- its activated result goes to a second
+// LDS tile, ZERO where the pixel lies outside the image (B's zero padding pads A's OUTPUT); B then runs exactly like the
+// single-conv kernel out of that tile.  A costs 1.16x its pixels and 9 instead of 4.5 LDS reads per pixel and tap row.
+constexpr int PLW = NTW + 4, PLH = NTH + 4;             // A's input halo
+constexpr int PMW = NTW + 2, PMH = NTH + 2;             // intermediate (A's output) tile
+constexpr int PSTA = (PLH * PLW + 255) / 256;           // 6 halo elements per thread per quad
+constexpr int PNA = (PMH * PMW + 255) / 256;            // 5 intermediate pixels per thread
+
+template <int KQA, int EPIB>
+__global__ __launch_bounds__(256, KQA == 1 ? 3 : 2) void conv3x3_narrow_pair_kernel(const NarrowArgs a, const NarrowArgs b) {
+    __shared__ float4 tileA[KQA][PLH][PLW];
+    __shared__ float4 tileB[PMH][PMW];
+    __shared__ float4 wlA[9 * KQA * 4], wlB[9 * 4];      // MFMA form: [tap][kq][cout] -> float4 over cin comp
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    if (tid < 9 * KQA * 4) {
+        const float4 wv = reinterpret_cast<const float4*>(a.wpk)[tid];
+        float* wf = reinterpret_cast<float*>(wlA) + (tid >> 2) * 16 + (tid & 3);
+        wf[0] = wv.x; wf[4] = wv.y; wf[8] = wv.z; wf[12] = wv.w;
+    }
+    if (tid < 9 * 4) {
+        const float4 wv = reinterpret_cast<const float4*>(b.wpk)[tid];
+        float* wf = reinterpret_cast<float*>(wlB) + (tid >> 2) * 16 + (tid & 3);
+        wf[0] = wv.x; wf[4] = wv.y; wf[8] = wv.z; wf[12] = wv.w;
+    }
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + NTW - 1) / NTW, ntiles = tiles_x * ((H + NTH - 1) / NTH);
+    const char* qbase[KQA];
+    int qpitch[KQA];
+    bool qflow[KQA];
+#pragma unroll
+    for (int k = 0; k < KQA; ++k) {
+        int kql = k, s = 0;
+        while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
+        const ConvSrc src = a.src[s];
+        qflow[k] = src.kind == SRC_FLOW2;
+        qpitch[k] = W + src.pad;
+        qbase[k] = qflow[k] ? reinterpret_cast<const char*>(src.p + (long long)n * src.bstride)
+                            : reinterpret_cast<const char*>(as_act(src.p) + (long long)n * src.bstride + (long long)kql * (H + src.pad) * qpitch[k] * 4);
+    }
+    const float4 biasA = *reinterpret_cast<const float4*>(a.bpk), biasB = *reinterpret_cast<const float4*>(b.bpk);
+    const float slopeA = a.act == CRFP_ACT_RELU ? 0.0f : (a.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const float slopeB = b.act == CRFP_ACT_RELU ? 0.0f : (b.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const int coutB = b.cout;
+    float* const dst = b.dst + (long long)n * b.dst_bstride;
+    act_t* const dsta = as_act(b.dst) + (long long)n * b.dst_bstride;
+    const int dpitch = W + b.dst_pad;
+    const act_t* const resid = b.resid ? as_act(b.resid) + (long long)n * b.resid_bstride : nullptr;
+    const float* const flowp = EPIB == NE_OFFMASK3 ? b.flow + (long long)n * b.flow_bstride : nullptr;
+
+#ifdef CRFP_ACT_BF16
+    typedef cu32x2 rawq_t;
+#else
+    typedef f32x4 rawq_t;
+#endif
+    rawq_t r[KQA][PSTA];
+    bool okr[PSTA];
+#define CRFP_PAIR_LOAD(T)                                                                                 \
+    {                                                                                                     \
+        const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * NTW, y0_ = ty_ * NTH;                \
+        int cgy[PSTA], cgx[PSTA];                                                                         \
+        _Pragma("unroll") for (int t = 0; t < PSTA; ++t) {                                                \
+            const int idx = min(tid + 256 * t, PLH * PLW - 1);                                            \
+            const int rr = idx / PLW, c = idx - rr * PLW;                                                 \
+            const int gy = y0_ + rr - 2, gx = x0_ + c - 2;                                                \
+            okr[t] = tid + 256 * t < PLH * PLW && gy >= 0 && gy < H && gx >= 0 && gx < W;                 \
+            cgy[t] = min(max(gy, 0), H - 1);                                                              \
+            cgx[t] = min(max(gx, 0), W - 1);                                                              \
+        }                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < KQA; ++k) {                                                 \
+            if (qflow[k]) {                                                                               \
+                _Pragma("unroll") for (int t = 0; t < PSTA; ++t)                                          \
+                    r[k][t] = raw_flow(qbase[k] + ((long long)cgy[t] * W + cgx[t]) * 8);                  \
+            } else {                                                                                      \
+                _Pragma("unroll") for (int t = 0; t < PSTA; ++t)                                          \
+                    r[k][t] = *reinterpret_cast<const rawq_t*>(qbase[k] + ((long long)cgy[t] * qpitch[k] + cgx[t]) * kQuadBytes); \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+
+    const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+    const int band0 = xcd * xq + min(xcd, xr), band1 = band0 + xq + (xcd < xr ? 1 : 0);
+    const int t_step = ((int)gridDim.x - xcd + 7) >> 3;
+    int t_cur = band0 + (blockIdx.x >> 3);
+    if (t_cur >= band1) return;
+    CRFP_PAIR_LOAD(t_cur)
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < KQA; ++k)
+#pragma unroll
+            for (int t = 0; t < PSTA; ++t) {
+                const int idx = tid + 256 * t;
+                if (idx < PLH * PLW) reinterpret_cast<f32x4*>(&tileA[k][0][0])[idx] = okr[t] ? raw_to_quad(r[k][t], qflow[k]) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        __syncthreads();
+        const int t_next = t_cur + t_step;
+        if (t_next < band1) CRFP_PAIR_LOAD(t_next)
+        const int tyi = t_cur / tiles_x, x0 = (t_cur - tyi * tiles_x) * NTW, y0 = tyi * NTH;
+
+        // ---- conv A on the (NTH+2) x (NTW+2) region, result -> tileB
+        {
+            f32x4 acc[PNA];
+            int pr[PNA], pc[PNA];
+#pragma unroll
+            for (int i = 0; i < PNA; ++i) {
+                const int idx = min(tid + 256 * i, PMH * PMW - 1);   // surplus lanes recompute the last pixel (their store is skipped)
+                pr[i] = idx / PMW; pc[i] = idx - pr[i] * PMW;
+                acc[i] = f32x4{biasA.x, biasA.y, biasA.z, biasA.w};
+            }
+#pragma unroll 1
+            for (int k = 0; k < KQA; ++k)
+#pragma unroll 1
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 wv = wlA[((ky * 3 + kx) * KQA + k) * 4 + (tx & 3)];
+                        f32x4 u[PNA];
+#pragma unroll
+                        for (int i = 0; i < PNA; ++i) u[i] = reinterpret_cast<const f32x4&>(tileA[k][pr[i] + ky][pc[i] + kx]);
+#pragma unroll
+                        for (int i = 0; i < PNA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, u[i].x, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < PNA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, u[i].y, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < PNA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, u[i].z, acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < PNA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, u[i].w, acc[i], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int i = 0; i < PNA; ++i) {
+                if (tid + 256 * i >= PMH * PMW) continue;
+                const int gy = y0 + pr[i] - 1, gx = x0 + pc[i] - 1;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                f32x4 v;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) v[o] = (in && o < a.cout) ? fmaxf(acc[i][o], slopeA * acc[i][o]) * a.post_scale : 0.0f;
+#ifdef CRFP_ACT_BF16
+                v = quad_from_bits(quad_to_bits(v));   // the intermediate is an activation tensor: rounded as if it had been stored
+#endif
+                reinterpret_cast<f32x4&>(tileB[pr[i]][pc[i]]) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- conv B out of tileB (one input quad), 4 vertically adjacent pixels per thread
+        f32x4 accB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accB[i] = f32x4{biasB.x, biasB.y, biasB.z, biasB.w};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 wv = wlB[(ky * 3 + kx) * 4 + (tx & 3)];
+                f32x4 u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = reinterpret_cast<const f32x4&>(tileB[4 * ty + ky + i][tx + kx]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accB[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, u[i].x, accB[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accB[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, u[i].y, accB[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accB[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, u[i].z, accB[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accB[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, u[i].w, accB[i], 0, 0, 0);
+            }
+        const int x = x0 + tx;
+        if (x < W) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = y0 + 4 * ty + i;
+                if (y >= H) break;
+                const long long pix = (long long)y * W + x, dpix = (long long)y * dpitch + x;
+                if (EPIB == NE_PLAIN) {
+                    float v[4];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) v[o] = o < coutB ? fmaxf(accB[i][o], slopeB * accB[i][o]) * b.post_scale : 0.0f;
+                    if (resid) {
+                        const cf32x4 rv = ldq(resid + pix * 4);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    stq(dsta + dpix * 4, cf32x4{v[0], v[1], v[2], v[3]});
+                } else {   // NE_OFFMASK3
+                    const float2 f = *reinterpret_cast<const float2*>(flowp + pix * 2);
+                    *reinterpret_cast<float4*>(dst + dpix * 4) =
+                        make_float4(tanh10_plus(accB[i][0], 10.0f + f.y), tanh10_plus(accB[i][1], 10.0f + f.x), fast_sigmoid(accB[i][2]), 0.0f);
+                }
+            }
+        }
+        if (t_next >= band1) break;
+        t_cur = t_next;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#undef CRFP_PAIR_LOAD
+}
+
+int launch_narrow_pair(const NarrowArgs& a, const NarrowArgs& b, const char* name, hipStream_t s) {
+    if (a.kq < 1 || a.kq > 3 || a.cout < 1 || a.cout > 4 || b.kq != 1 || b.cout < 1 || b.cout > 4 ||
+        (b.epi != NE_PLAIN && b.epi != NE_OFFMASK3) || a.epi != NE_PLAIN || a.resid || a.act == CRFP_ACT_TANH ||
+        a.act == CRFP_ACT_SIGMOID || b.act == CRFP_ACT_TANH || b.act == CRFP_ACT_SIGMOID || a.H != b.H || a.W != b.W || a.N != b.N) {
+        set_error("conv_narrow_pair %s: unsupported pair (kqA=%d kqB=%d epiA=%d epiB=%d)", name, a.kq, b.kq, a.epi, b.epi);
+        return CRFP_E_UNSUPPORTED;
+    }
+    double in_ch = 0;
+    for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].nch;
+    const double px = (double)a.N * a.H * a.W;
+    const double outb = b.epi == NE_OFFMASK3 ? (3 + 2) * 4.0 : (b.cout + (b.resid ? 4 : 0)) * (double)sizeof(act_t);
+    ProfScope prof(name, s, px * (in_ch * (double)sizeof(act_t) + outb), 2.0 * px * 9.0 * (in_ch * a.cout + 4.0 * b.cout));
+    const int ntl = ((a.W + NTW - 1) / NTW) * ((a.H + NTH - 1) / NTH);
+    const int per_cu = a.kq == 1 ? 3 : 2;
+    const int share = (ntl + 256 * per_cu - 1) / (256 * per_cu);
+    dim3 grid((ntl + share - 1) / share, 1, a.N);
+#define CRFP_PAIR_LAUNCH(KQ_)                                                                          \
+    if (b.epi == NE_PLAIN) conv3x3_narrow_pair_kernel<KQ_, NE_PLAIN><<<grid, 256, 0, s>>>(a, b);       \
+    else conv3x3_narrow_pair_kernel<KQ_, NE_OFFMASK3><<<grid, 256, 0, s>>>(a, b);
+    switch (a.kq) {
+        case 1: CRFP_PAIR_LAUNCH(1) break;
+        case 2: CRFP_PAIR_LAUNCH(2) break;
+        default: CRFP_PAIR_LAUNCH(3) break;
+    }
+#undef CRFP_PAIR_LAUNCH
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
 // wpk[((tap*KQ + kq)*4 + comp)*4 + o] = W[o][cin(kq,comp)][tap]
 __global__ void narrow_pack_kernel(const NarrowArgs a, const float* __restrict__ w, const float* __restrict__ bias,
                                    const float* __restrict__ w2, const float* __restrict__ bias2, int cout_split,

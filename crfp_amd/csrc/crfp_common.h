@@ -302,6 +302,8 @@ size_t narrow_packed_weight_floats(const NarrowArgs& a);
 int launch_narrow_pack(const NarrowArgs& a, const float* w_oihw, const float* bias, const float* w2, const float* bias2,
                        int cout_split, float* wpk, float* bpk, hipStream_t s);
 int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s);
+// a (NE_PLAIN, no residual) feeding b (one input quad = a's output; NE_PLAIN [+ residual] or NE_OFFMASK3) in one pass
+int launch_narrow_pair(const NarrowArgs& a, const NarrowArgs& b, const char* name, hipStream_t s);
 // gather.hip
 // src_pad = 1: x is P4 (padded planes, zero pads): validity logic replaced by clamping + hardware range check
 int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* flow, float* outa, float* outb, int H, int W,

@@ -484,6 +484,24 @@ struct Runner {
         a.ovf = ovf();
         rc = launch_narrow(a, it.name, s);
     }
+    // two stencils in one pass: item idA (its output has no other reader) feeding item idB (conv_narrow.hip, launch_narrow_pair)
+    void narrow_pair(int idA, int idB, const char* name, int H, int W, std::vector<const float*> srcsA, float* dst,
+                     const float* residB = nullptr, const float* flowB = nullptr) {
+        if (rc) return;
+        NarrowArgs a = M.items[idA].nw, b = M.items[idB].nw;
+        for (size_t i = 0; i < srcsA.size(); ++i) { a.src[i].p = srcsA[i]; a.src[i].bstride = 0; a.src[i].pad = 0; }
+        a.N = b.N = 1; a.H = b.H = H; a.W = b.W = W;
+        a.wpk = packed + M.items[idA].off_w; a.bpk = packed + M.items[idA].off_b;
+        b.wpk = packed + M.items[idB].off_w; b.bpk = packed + M.items[idB].off_b;
+        b.dst = dst; b.resid = residB; b.flow = flowB; b.dst_pad = 0;
+        rc = launch_narrow_pair(a, b, name, s);
+    }
+    // which 8x-resolution conv pairs run fused (bit 0: encoder_hr.0->.2, 1: dcn_3 conv_fuse->offset/mask, 2: res3 conv1->conv2,
+    // 3: dcn_3 block.0->.2).  Measured @A fp32, pair vs the two single kernels: res3 47.2 vs 57.8 us (bf16 46.7 vs 56.1);
+    // encoder_hr 71.5 vs 67.6; conv_fuse->offset/mask 80 vs 76.8; dcn_3 block (3 input quads, one workgroup per CU) 126 vs 93.7.
+    // The stencils are bound by 4x4x1-MFMA issue and LDS reads, not by HBM, and the fused form evaluates conv A on 1.16x the
+    // pixels with 9 instead of 4.5 LDS reads per pixel and tap row -- so only the pair whose A has ONE input quad wins.
+    static constexpr int pair_mask() { return 4; }
 #define RUN(expr) do { if (!rc) rc = (expr); } while (0)
 
     // FNet over nb pairs (reference model/CRFP.py:797-814); cur/prev are NCHW 3-channel frames
@@ -550,8 +568,12 @@ struct Runner {
         const long long P8q = (long long)H8 * W8 * 4;
         if (parts & 1) {
             RUN(launch_hr_prep(lr, fv, mk, F(L.xin8[par]), h, w, s));
-            narrow(IT_EH0, H8, W8, {F(L.xin8[par]), adv(F(L.xin8[par]), P8q)}, F(L.eh[par]));
-            narrow(IT_EH1, H8, W8, {F(L.eh[par])}, F(L.x_hr[par]));
+            if (pair_mask() & 1)
+                narrow_pair(IT_EH0, IT_EH1, "conv_narrow_pair:enc_hr", H8, W8, {F(L.xin8[par]), adv(F(L.xin8[par]), P8q)}, F(L.x_hr[par]));
+            else {
+                narrow(IT_EH0, H8, W8, {F(L.xin8[par]), adv(F(L.xin8[par]), P8q)}, F(L.eh[par]));
+                narrow(IT_EH1, H8, W8, {F(L.eh[par])}, F(L.x_hr[par]));
+            }
             if (before_ups && !rc && hipStreamWaitEvent(s, before_ups, 0) != hipSuccess) { set_error("dsv: hipStreamWaitEvent failed"); rc = 1; }
             mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0[par]), 0, 0, 6}}, H2, W2);
         }
@@ -613,10 +635,18 @@ struct Runner {
             }
             mfma(IT_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up), 0, 0, 1}}, H8, W8);
             mfma(IT_POFF, 1, H2, W2, {{offprev, 0}}, {{F(L.poff), 0, 0, 1}}, H8, W8);
-            narrow(IT_D3B0, H8, W8, {F(L.up), F(L.prevhrw), flow8}, F(L.g0));
-            narrow(IT_D3B1, H8, W8, {F(L.g0)}, F(L.g1));
-            narrow(IT_D3FUSE, H8, W8, {F(L.g1), F(L.poff)}, F(L.g2));
-            narrow(IT_D3OM, H8, W8, {F(L.g2)}, F(L.om3), nullptr, flow8);
+            if (pair_mask() & 8)
+                narrow_pair(IT_D3B0, IT_D3B1, "conv_narrow_pair:dcn3.block", H8, W8, {F(L.up), F(L.prevhrw), flow8}, F(L.g1));
+            else {
+                narrow(IT_D3B0, H8, W8, {F(L.up), F(L.prevhrw), flow8}, F(L.g0));
+                narrow(IT_D3B1, H8, W8, {F(L.g0)}, F(L.g1));
+            }
+            if (pair_mask() & 2)
+                narrow_pair(IT_D3FUSE, IT_D3OM, "conv_narrow_pair:dcn3.fuse_offmask", H8, W8, {F(L.g1), F(L.poff)}, F(L.om3), nullptr, flow8);
+            else {
+                narrow(IT_D3FUSE, H8, W8, {F(L.g1), F(L.poff)}, F(L.g2));
+                narrow(IT_D3OM, H8, W8, {F(L.g2)}, F(L.om3), nullptr, flow8);
+            }
             const Item& d3 = M.items[IT_D3W];
             RUN(launch_dcn3(F(L.state_hr), 0, F(L.om3), 0, packed + d3.off_w, packed + d3.off_b, F(L.al3), 0, 1, H8, W8, s));
             if (fg) {           // model/CRFP_test.py:2389
@@ -637,8 +667,12 @@ struct Runner {
             mfma(IT_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up), 0, 0, 1}}, H8, W8);
             narrow(IT_R3_0F, H8, W8, {F(L.up)}, F(L.z0));
         }
-        narrow(IT_R3_1, H8, W8, {F(L.z0)}, F(L.z1));
-        narrow(IT_R3_2, H8, W8, {F(L.z1)}, F(L.feat), F(L.z0));
+        if (pair_mask() & 4)
+            narrow_pair(IT_R3_1, IT_R3_2, "conv_narrow_pair:res3.conv1_conv2_add", H8, W8, {F(L.z0)}, F(L.feat), F(L.z0));
+        else {
+            narrow(IT_R3_1, H8, W8, {F(L.z0)}, F(L.z1));
+            narrow(IT_R3_2, H8, W8, {F(L.z1)}, F(L.feat), F(L.z0));
+        }
         narrow(IT_TTTF, H8, W8, {F(L.feat), F(L.x_hr[par])}, F(L.state_hr), nullptr, nullptr, nullptr, mk, 0, 1);
         // output head: conv_last(state) + x8 bilinear LR.  fp32 build: the base quad hr_prep staged; bf16 build: recomputed from
         // the fp32 LR frame inside the kernel (a bf16 base would cost ~2^-9 of the output range)
