@@ -62,6 +62,32 @@ int crfp_dcnv2_forward_f32(const float* x, const float* offset, const float* mas
     return launch_dcn_generic(x, offset, mask, weight, bias, out, n, cin, cout, h, w, dg, s);
 }
 
+// (cin = cout = 32, dg = 8) with the weights packed once: crfp_dcnv2_g8_pack_f32 -> crfp_dcnv2_g8_packed_f32
+size_t crfp_dcnv2_g8_packed_bytes(void) { return align_up(36 * 2 * 32 * 4 * sizeof(float), 256); }
+
+int crfp_dcnv2_g8_pack_f32(const float* weight, void* packed, size_t packed_bytes, void* stream) {
+    if (!weight || !packed) { set_error("dcnv2_g8_pack: bad argument"); return CRFP_E_BADARG; }
+    if (packed_bytes < crfp_dcnv2_g8_packed_bytes()) { set_error("dcnv2_g8_pack: packed buffer too small"); return CRFP_E_WORKSPACE; }
+    return launch_dcn_g8_pack(weight, (float*)packed, (hipStream_t)stream);
+}
+
+int crfp_dcnv2_g8_packed_f32(const float* x, const float* offset, const float* mask, const void* packed, const float* bias, float* out,
+                             int n, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !offset || !mask || !packed || !bias || !out || n < 1 || h < 1 || w < 1) { set_error("dcnv2_g8_packed: bad argument"); return CRFP_E_BADARG; }
+    if (!workspace || workspace_bytes < crfp_dcnv2_workspace_bytes(n, 32, 32, h, w, 3, 8)) { set_error("dcnv2_g8_packed: workspace too small"); return CRFP_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    float* xq = (float*)(p + p4_guard(w)); p += p4_bytes(n, 32, h, w);
+    float* oq = (float*)p; p += q4_bytes(n, 32, h, w);
+    float* om = (float*)p;
+    if (hipMemsetAsync((char*)xq - p4_guard(w), 0, p4_bytes(n, 32, h, w), s) != hipSuccess) { set_error("dcnv2_g8_packed: memset failed"); return 1; }
+    int rc = launch_nchw_to_q4(x, xq, n, 32, h, w, 1, s);
+    if (!rc) rc = launch_offmask_nchw_to_q4(offset, mask, om, n, 144, 72, h, w, s);
+    if (!rc) rc = launch_dcn_g8(xq, 8LL * (h + 1) * (w + 1) * 4, om, 54LL * h * w * 4, (const float*)packed, bias, oq, 8LL * h * w * 4, n, h, w, s);
+    if (!rc) rc = launch_q4_to_nchw(oq, out, n, 32, h, w, 0, s);
+    return rc;
+}
+
 static ConvArgs api_conv_plan(int cin, int cout, int act, float post_scale) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -91,6 +117,36 @@ size_t crfp_conv3x3_workspace_bytes(int n, int cin, int cout, int h, int w) {
     (void)n; (void)h; (void)w;
     ConvArgs a = api_conv_plan(cin, cout, 0, 1.0f);
     return align_up(conv_packed_weight_floats(a) * sizeof(float), 256) + align_up((size_t)a.ctiles * 32 * sizeof(float), 256);
+}
+
+// Weights packed once (crfp_conv3x3_pack_f32), reused by every crfp_conv3x3_packed_f32 call: the operator without the per-call repack
+size_t crfp_conv3x3_packed_bytes(int cin, int cout) { return crfp_conv3x3_workspace_bytes(1, cin, cout, 1, 1); }
+
+int crfp_conv3x3_pack_f32(const float* weight, const float* bias, int cin, int cout, void* packed, size_t packed_bytes, void* stream) {
+    if (!weight || !packed || cin < 1 || cout < 1) { set_error("conv3x3_pack: bad argument"); return CRFP_E_BADARG; }
+    if (packed_bytes < crfp_conv3x3_packed_bytes(cin, cout)) { set_error("conv3x3_pack: packed buffer too small"); return CRFP_E_WORKSPACE; }
+    ConvArgs a = api_conv_plan(cin, cout, 0, 1.0f);
+    float* wpk = (float*)packed;
+    float* bpk = (float*)((char*)packed + align_up(conv_packed_weight_floats(a) * sizeof(float), 256));
+    return launch_conv_pack(a, weight, bias, nullptr, nullptr, cout, wpk, bpk, (hipStream_t)stream);
+}
+
+int crfp_conv3x3_packed_f32(const float* x, const void* packed, float* out, int n, int cin, int cout, int h, int w, int act,
+                            float post_scale, void* stream) {
+    if (!x || !packed || !out || n < 1 || cin < 1 || cout < 1 || h < 1 || w < 1) { set_error("conv3x3_packed: bad argument"); return CRFP_E_BADARG; }
+    if (act < CRFP_ACT_NONE || act > CRFP_ACT_SIGMOID) { set_error("conv3x3_packed: unknown activation %d", act); return CRFP_E_BADARG; }
+    ConvArgs a = api_conv_plan(cin, cout, act, post_scale);
+    a.src[0].p = x;
+    a.src[0].bstride = (long long)cin * h * w;
+    a.ndst = 1;
+    a.dst[0].p = out;
+    a.dst[0].bstride = (long long)cout * h * w;
+    a.dst[0].q0 = 0;
+    a.dst[0].q1 = (cout + 3) / 4;
+    a.N = n; a.H = h; a.W = w;
+    a.wpk = (const float*)packed;
+    a.bpk = (const float*)((const char*)packed + align_up(conv_packed_weight_floats(a) * sizeof(float), 256));
+    return launch_conv_mfma(a, "conv_mfma:api_nchw", (hipStream_t)stream);
 }
 
 int crfp_conv3x3_f32(const float* x, const float* weight, const float* bias, float* out, int n, int cin, int cout, int h,

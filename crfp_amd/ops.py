@@ -37,6 +37,23 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# packed-weight cache of the per-operator entry points: key = identity + version of the weight / bias storages, so an in-place
+# update (optimizer step, the reference's conv_identify) repacks and an unchanged module pays the repack once
+_PACKED = {}
+
+
+def _packed(kind, tensors, nbytes, pack_fn):
+    key = (kind,) + tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in tensors)
+    buf = _PACKED.get(key)
+    if buf is None:
+        if len(_PACKED) >= 256:
+            _PACKED.clear()
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=tensors[0].device)
+        pack_fn(buf)
+        _PACKED[key] = buf
+    return buf
+
+
 def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_corners=True):
     """Drop-in for the reference's ``flow_warp`` (model/CRFP.py:90-130): x[n,c,h,w], flow[n,h,w,2]."""
     if tuple(x.shape[-2:]) != tuple(flow.shape[1:3]):
@@ -72,6 +89,13 @@ def dcnv2(x, offset, mask, weight, bias, kernel_size=3, padding=1, dilation=1, d
     L = _lib.lib()
     out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
     ws = _ws(L.crfp_dcnv2_workspace_bytes(n, cin, cout, h, w, kernel_size, deformable_groups), x.device)
+    if (cin, cout, deformable_groups, kernel_size, padding, dilation) == (32, 32, 8, 3, 1, 1):   # MFMA fast path, weights packed once
+        with _on(x, offset, mask, weight, bias):
+            pk = _packed("dcn_g8", (weight,), L.crfp_dcnv2_g8_packed_bytes(), lambda b: _lib.check(
+                L.crfp_dcnv2_g8_pack_f32(weight.data_ptr(), b.data_ptr(), b.numel(), _stream()), "crfp_dcnv2_g8_pack_f32"))
+            _lib.check(L.crfp_dcnv2_g8_packed_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), pk.data_ptr(), bias.data_ptr(),
+                                                  out.data_ptr(), n, h, w, ws.data_ptr(), ws.numel(), _stream()), "crfp_dcnv2_g8_packed_f32")
+        return out
     with _on(x, offset, mask, weight, bias):
         _lib.check(L.crfp_dcnv2_forward_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), weight.data_ptr(),
                                             bias.data_ptr(), out.data_ptr(), n, cin, cout, h, w, kernel_size, padding,
@@ -89,6 +113,21 @@ def conv3x3(x, weight, bias=None, act="none", post_scale=1.0):
     if bias is None:
         bias = torch.zeros(cout, dtype=torch.float32, device=x.device)
     bias = _dev(bias, "bias")
+    L = _lib.lib()
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    with _on(x, weight, bias):
+        pk = _packed("conv3x3", (weight, bias), L.crfp_conv3x3_packed_bytes(cin, cout), lambda b: _lib.check(
+            L.crfp_conv3x3_pack_f32(weight.data_ptr(), bias.data_ptr(), cin, cout, b.data_ptr(), b.numel(), _stream()), "crfp_conv3x3_pack_f32"))
+        _lib.check(L.crfp_conv3x3_packed_f32(x.data_ptr(), pk.data_ptr(), out.data_ptr(), n, cin, cout, h, w, ACT[act], float(post_scale),
+                                             _stream()), "crfp_conv3x3_packed_f32")
+    return out
+
+
+def conv3x3_unpacked(x, weight, bias, act="none", post_scale=1.0):
+    """The one-call form (crfp_conv3x3_f32: repacks the weights inside the call) -- what a caller without a cache pays."""
+    x, weight, bias = _dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias")
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
     L = _lib.lib()
     out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
     ws = _ws(L.crfp_conv3x3_workspace_bytes(n, cin, cout, h, w), x.device)

@@ -88,6 +88,18 @@ int crfp_conv3x3_f32(const float* x, const float* weight, const float* bias, flo
                      int cout, int h, int w, int act, float post_scale, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* The same two operators with the weight repack hoisted out of the call (pack once per weight update):
+ *   crfp_conv3x3_pack_f32 -> crfp_conv3x3_packed_f32           (any cin / cout)
+ *   crfp_dcnv2_g8_pack_f32 -> crfp_dcnv2_g8_packed_f32         (cin = cout = 32, deformable_groups = 8, k = 3) */
+size_t crfp_conv3x3_packed_bytes(int cin, int cout);
+int crfp_conv3x3_pack_f32(const float* weight, const float* bias, int cin, int cout, void* packed, size_t packed_bytes, void* stream);
+int crfp_conv3x3_packed_f32(const float* x, const void* packed, float* out, int n, int cin, int cout, int h, int w, int act,
+                            float post_scale, void* stream);
+size_t crfp_dcnv2_g8_packed_bytes(void);
+int crfp_dcnv2_g8_pack_f32(const float* weight, void* packed, size_t packed_bytes, void* stream);
+int crfp_dcnv2_g8_packed_f32(const float* x, const float* offset, const float* mask, const void* packed, const float* bias, float* out,
+                             int n, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- bilinear resize, align_corners=False, NCHW f32; out = mul * resize(x).  scale_h/scale_w
  * are the source-index scales PyTorch uses (1/scale_factor for nn.Upsample, in/out for size=). */
 int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, int w, int oh, int ow,

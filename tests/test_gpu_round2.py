@@ -302,3 +302,26 @@ def test_runtime_variant_vs_reference_golden(orc, capsys):
     got = m(lrs.to(dev()), fvs.to(dev()), warp_size=(128, 192))
     ref = ro.runtime_forward(orc.load_numpy_state(sd), lrs, fvs, (128, 192))
     assert tuple(got.shape) == (1, 2, 3, 128, 320) and maxdiff(got, ref) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------------ pre-packed operator variants
+def test_packed_operator_variants_and_cache_invalidation(orc):
+    """crfp_conv3x3_packed_f32 / crfp_dcnv2_g8_packed_f32 (weights packed once) equal the one-call forms, and the Python-side
+    cache repacks when a weight is mutated IN PLACE (the reference does that: conv_identify, model/CRFP.py:359-370)."""
+    from crfp_amd import ops
+    rs = np.random.RandomState(2)
+    x = T(rs.standard_normal((1, 32, 20, 36)).astype(np.float32)).to(dev())
+    w = T((rs.standard_normal((32, 32, 3, 3)) * 0.1).astype(np.float32)).to(dev())
+    b = T(rs.standard_normal(32).astype(np.float32)).to(dev())
+    a1 = ops.conv3x3(x, w, b, "lrelu")
+    assert maxdiff(a1, ops.conv3x3_unpacked(x, w, b, "lrelu")) == 0.0
+    assert maxdiff(ops.conv3x3(x, w, b, "lrelu"), a1) == 0.0                       # second call: cache hit
+    w.mul_(2.0)                                                                    # in-place update -> new version -> repack
+    a2 = ops.conv3x3(x, w, b, "lrelu")
+    assert maxdiff(a2, F.leaky_relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1), 0.1)) < 3e-5 and maxdiff(a2, a1) > 1e-3
+    off = T(rs.uniform(-4, 4, (1, 144, 20, 36)).astype(np.float32)).to(dev())
+    msk = T(rs.uniform(0, 1, (1, 72, 20, 36)).astype(np.float32)).to(dev())
+    d1 = ops.dcnv2(x, off, msk, w, b, 3, 1, 1, 8)
+    assert maxdiff(d1, orc.dcnv2(x.cpu(), off.cpu(), msk.cpu(), w.cpu(), b.cpu(), 8)) < 5e-5
+    w.zero_()
+    assert maxdiff(ops.dcnv2(x, off, msk, w, b, 3, 1, 1, 8), b.cpu().view(1, 32, 1, 1).expand(1, 32, 20, 36)) < 1e-6
