@@ -854,6 +854,162 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
 #endif
 }
 
+// ---------------------------------------------------------------- f16x3, 8 waves, ONE accumulator ("f16x3s")
+// The 4-wave kernel above needs 164 VGPRs (two fp32 accumulators per pixel tile, hi and lo) = 3 waves per SIMD = 768 workgroup
+// slots, and a 360 x 640 map is 900 tiles: every 32-cout conv ran a full round plus a 17 % one.  Here the
+// whole sum is kept scaled by 2^11 in ONE accumulator:
+//     2^11 * x*w  ~=  x0 * A  +  x0 * B  +  x1s * C,    A = fp16(2^11 w),  B = fp16(2^11 (w - A/2^11)),  C = fp16(w)
+// (x0 = fp16(x), x1s = fp16(2^11 (x - x0)) as before: same three MFMAs per tap, same exact products, same dropped term;
+// the bias enters as 2^11 b and the result leaves through one multiply by 2^-11).  Three weight images instead of two,
+// 32 VGPRs less; with 8 waves per workgroup (8 rows x 64 pixels, one weight image per 8 rows instead of per 4) the kernel
+// fits 128 VGPRs: 2 workgroups = 16 waves per CU, 450 tiles on 512 slots -- one round.  Needs |w| < 32 (A must stay finite).
+constexpr int S8_NT = 512, S8_TH = 8, S8_LH = S8_TH + 2, S8_NEL = S8_LH * LW, S8_NIN = (S8_NEL + S8_NT - 1) / S8_NT;
+constexpr int S8_WPC = 9 * 3 * 64, S8_NWS = (S8_WPC + S8_NT - 1) / S8_NT;
+
+__global__ __launch_bounds__(S8_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_split8_kernel(const ConvArgs a) {
+    __shared__ bf16x8 tile[2][2][S8_NEL];        // [split part][quad pair][halo pixel]   42.2 KB
+    __shared__ bf16x8 wlds[S8_WPC];              // [(tap, image A/B/C)][lane]            27.6 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int ngrp = a.ctiles;
+    const int bwork = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int btile = bwork / ngrp;
+    const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * S8_TH;
+    const int T0 = bwork - btile * ngrp;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+
+    int cgy[S8_NIN], cgx[S8_NIN];
+    bool sval[S8_NIN];
+#pragma unroll
+    for (int t = 0; t < S8_NIN; ++t) {
+        const int idx = min(tid + S8_NT * t, S8_NEL - 1);
+        const int r = idx / LW, c = idx - r * LW;
+        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+        sval[t] = tid + S8_NT * t < S8_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        cgy[t] = min(max(gy, 0), H - 1);
+        cgx[t] = min(max(gx, 0), W - 1);
+    }
+
+    f32x16 acc[1][2];
+    {   // accumulators start at 2^11 * bias
+        const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bq = bp[T0 * 8 + 2 * g + h];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                acc[0][pt][4 * g + 0] = bq.x * F16_RES_SCALE; acc[0][pt][4 * g + 1] = bq.y * F16_RES_SCALE;
+                acc[0][pt][4 * g + 2] = bq.z * F16_RES_SCALE; acc[0][pt][4 * g + 3] = bq.w * F16_RES_SCALE;
+            }
+        }
+    }
+
+    const int nchunks = a.kq >> 2;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit_sa);
+    f32x4 rq0[S8_NIN], rq1[S8_NIN], rq2[S8_NIN], rq3[S8_NIN];
+    bf16x8 rws[S8_NWS];
+    const float* qb0; const float* qb1; const float* qb2; const float* qb3;
+    int qrs0, qrs1, qrs2, qrs3, qcs0, qcs1, qcs2, qcs3, qm0 = 0, qm1 = 0, qm2 = 0, qm3 = 0;
+#define CRFP_QDESC(QB_, QRS, QCS, QM, QI, CH)                                                             \
+    {                                                                                                     \
+        const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
+        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+    }
+#define CRFP_S8_ISSUE(CH)                                                                                 \
+    {                                                                                                     \
+        CRFP_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) CRFP_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                   \
+        CRFP_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) CRFP_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                   \
+        _Pragma("unroll") for (int t = 0; t < S8_NIN; ++t) {                                              \
+            rq0[t] = *reinterpret_cast<const f32x4*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
+            rq1[t] = *reinterpret_cast<const f32x4*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
+            rq2[t] = *reinterpret_cast<const f32x4*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
+            rq3[t] = *reinterpret_cast<const f32x4*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
+        }                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < S8_NWS; ++k) {                                              \
+            const int idx = min(tid + S8_NT * k, S8_WPC - 1);                                             \
+            rws[k] = wp[((long long)T0 * nchunks + (CH)) * S8_WPC + idx];                                 \
+        }                                                                                                 \
+    }
+
+    CRFP_S8_ISSUE(0)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;
+        __syncthreads();
+        if (m0 & 16) {   // SRC_S3 chunk (wave-uniform): already split by its producer -- copy, zero outside the image
+#pragma unroll
+            for (int t = 0; t < S8_NIN; ++t) {
+                const int idx = tid + S8_NT * t;
+                if (idx < S8_NEL) {
+                    const f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    tile[0][0][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq0[t] : z);
+                    tile[0][1][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq1[t] : z);
+                    tile[1][0][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq2[t] : z);
+                    tile[1][1][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq3[t] : z);
+                }
+            }
+        } else if ((m0 & m1 & m2 & m3) == 15) {
+#pragma unroll
+            for (int t = 0; t < S8_NIN; ++t) {
+                const int idx = tid + S8_NT * t;
+                if (idx < S8_NEL) {
+                    const float sc = sval[t] ? F16_RES_SCALE : 0.0f;
+                    const unsigned km = sval[t] ? 0xffffffffu : 0u;
+                    bf16x8 pa, pb;
+                    split_f16x8_fast(rq0[t], rq1[t], sc, km, pa, pb);
+                    tile[0][0][idx] = pa; tile[1][0][idx] = pb;
+                    split_f16x8_fast(rq2[t], rq3[t], sc, km, pa, pb);
+                    tile[0][1][idx] = pa; tile[1][1][idx] = pb;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < S8_NIN; ++t) {
+                const int idx = tid + S8_NT * t;
+                if (idx < S8_NEL) {
+                    bf16x8 pp[2];
+                    split_parts<2>(mask_quad(rq0[t], sval[t] ? m0 : 0), mask_quad(rq1[t], sval[t] ? m1 : 0), pp);
+                    tile[0][0][idx] = pp[0]; tile[1][0][idx] = pp[1];
+                    split_parts<2>(mask_quad(rq2[t], sval[t] ? m2 : 0), mask_quad(rq3[t], sval[t] ? m3 : 0), pp);
+                    tile[0][1][idx] = pp[0]; tile[1][1][idx] = pp[1];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < S8_NWS; ++k) {
+            const int idx = tid + S8_NT * k;
+            if (idx < S8_WPC) wlds[idx] = rws[k];
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) CRFP_S8_ISSUE(ch + 1)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const f16x8 wA = __builtin_bit_cast(f16x8, wlds[(tap * 3 + 0) * 64 + lane]);
+            const f16x8 wB = __builtin_bit_cast(f16x8, wlds[(tap * 3 + 1) * 64 + lane]);
+            const f16x8 wC = __builtin_bit_cast(f16x8, wlds[(tap * 3 + 2) * 64 + lane]);
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int pix = (wave + ky) * LW + pt * 32 + j + kx;
+                const f16x8 b0 = __builtin_bit_cast(f16x8, tile[0][h][pix]);
+                const f16x8 b1 = __builtin_bit_cast(f16x8, tile[1][h][pix]);
+                acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wB, b0, acc[0][pt], 0, 0, 0);
+                acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wC, b1, acc[0][pt], 0, 0, 0);
+                acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wA, b0, acc[0][pt], 0, 0, 0);
+            }
+        }
+    }
+#undef CRFP_S8_ISSUE
+#undef CRFP_QDESC
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][pt][e] *= (1.0f / F16_RES_SCALE);
+    const EpiCtx ec = epi_ctx(a, n);
+    conv_epilogue<1, 2, 1, 2>(ec, acc, T0, tx0, ty0, wave, j, h);
+}
+
 #endif  // !CRFP_ACT_BF16
 
 #ifdef CRFP_ACT_BF16
@@ -1571,7 +1727,14 @@ __global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict
             val = co < cout_split ? w[((long long)co * a.cin_total + ci) * 9 + tap]
                                   : w2[((long long)(co - cout_split) * a.cin_total + ci) * 9 + tap];
         const long long base = (((((long long)T * nchunks + ch) * 9 + tap) * np) * 64 + lane) * 8 + jj;
-        if (np == 1) {   // bf16 build: the weight IS its bf16 rounding
+        if (np == 4) {   // f16x3s: A = fp16(2^11 w), B = fp16(2^11 (w - A / 2^11)), C = fp16(w); image stride as for np == 3
+            const long long b3 = (((((long long)T * nchunks + ch) * 9 + tap) * 3) * 64 + lane) * 8 + jj;
+            const _Float16 pa = (_Float16)(val * 2048.0f);
+            const _Float16 pb = (_Float16)((val - (float)pa * (1.0f / 2048.0f)) * 2048.0f);
+            wsplit[b3] = __builtin_bit_cast(unsigned short, pa);
+            wsplit[b3 + 64 * 8] = __builtin_bit_cast(unsigned short, pb);
+            wsplit[b3 + 2 * 64 * 8] = __builtin_bit_cast(unsigned short, (_Float16)val);
+        } else if (np == 1) {   // bf16 build: the weight IS its bf16 rounding
             wsplit[base] = __builtin_bit_cast(unsigned short, (__bf16)val);
         } else if (np == 3) {
             const __bf16 p0 = (__bf16)val;
@@ -1592,14 +1755,24 @@ __global__ void conv_pack_split_kernel(const ConvArgs a, const float* __restrict
 
 // product build: the fp16 pair image only; lab build: bf16 triple image followed by the fp16 pair image
 #ifdef CRFP_LAB
-size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * (3 + 2) * 64 * 16; }
+size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * (3 + 2 + 3) * 64 * 16; }
 size_t conv_split16_offset_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 3 * 64 * 16; }
 #elif defined(CRFP_ACT_BF16)
 size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 1 * 64 * 16; }   // one bf16 image
 size_t conv_split16_offset_bytes(const ConvArgs&) { return 0; }
 #else
-size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * 2 * 64 * 16; }
+// the fp16 pair image (4-wave kernel), then the three images of the single-accumulator scheme (8-wave kernel)
+size_t conv_split_weight_bytes(const ConvArgs& a) { return (size_t)a.ctiles * (a.kq >> 2) * 9 * (2 + 3) * 64 * 16; }
 size_t conv_split16_offset_bytes(const ConvArgs&) { return 0; }
+#endif
+#ifndef CRFP_ACT_BF16
+static size_t conv_split_sa_offset_bytes(const ConvArgs& a) {
+#ifdef CRFP_LAB
+    return (size_t)a.ctiles * (a.kq >> 2) * 9 * 5 * 64 * 16;
+#else
+    return (size_t)a.ctiles * (a.kq >> 2) * 9 * 2 * 64 * 16;
+#endif
+}
 #endif
 
 int launch_conv_pack_split(const ConvArgs& a, const float* w, const float* w2, int cout_split, void* wsplit,
@@ -1614,6 +1787,11 @@ int launch_conv_pack_split(const ConvArgs& a, const float* w, const float* w2, i
     conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout,
                                                   (unsigned short*)((char*)wsplit + conv_split16_offset_bytes(a)), kActBf16 ? 1 : 2);
     CRFP_CHECK_LAUNCH();
+#ifndef CRFP_ACT_BF16
+    conv_pack_split_kernel<<<blocks, 256, 0, s>>>(a, w, w2, w2 ? cout_split : a.cout,
+                                                  (unsigned short*)((char*)wsplit + conv_split_sa_offset_bytes(a)), 4);
+    CRFP_CHECK_LAUNCH();
+#endif
     return 0;
 }
 
@@ -1701,6 +1879,8 @@ bool conv_s3_supported() {
     return ok;
 }
 
+static bool uses_s3_dst_only_4wave(const ConvArgs&) { return false; }   // the shared epilogue writes S3 images from either kernel
+
 int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     if (a.kq & 1 || a.kq < 2 || a.ctiles < 1 || a.nsrc < 1 || a.nsrc > CRFP_MAX_SRC) {
         set_error("conv_mfma %s: bad plan (kq=%d ctiles=%d nsrc=%d)", name, a.kq, a.ctiles, a.nsrc);
@@ -1746,6 +1926,9 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     am.stamps = (stamp_ptr && stamp_name && !strcmp(stamp_name, name)) ? stamp_ptr : nullptr;
 #endif
     am.wsplit16 = a.wsplit ? (const char*)a.wsplit + conv_split16_offset_bytes(a) : nullptr;
+#ifndef CRFP_ACT_BF16
+    am.wsplit_sa = a.wsplit ? (const char*)a.wsplit + conv_split_sa_offset_bytes(a) : nullptr;
+#endif
     if (env_strict || a.strict) am.ovf = nullptr;   // nothing downstream turns this output into an fp16 operand
     if (a.kq <= CRFP_MAX_KQ) {  // per-quad load descriptors (wave-uniform in the kernel: one s_load per quad)
         int q = 0;
@@ -1850,7 +2033,14 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // workgroups on 256 CUs -- measured neutral to -8 % per conv, so 4-row tiles stay)
         conv3x3_bf16_kernel<1><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
 #else
-        conv3x3_split_kernel<1, 1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
+        // 8-wave single-accumulator kernel for the convs with one cout tile (the 32-cout layers: one round of 450 workgroups
+        // instead of 1.17 rounds of 900; same-box: conv1 26.4 -> 24.6 us, conv2 28.7 -> 26.1, block0 46.0 -> 43.2, main0 40.0 ->
+        // 38.0, clip -1.5 %); with several cout tiles the 4-wave kernel stays (offset/mask head 114.0 vs 117.7 us)
+        if (a.ctiles == 1 && !uses_s3_dst_only_4wave(a)) {
+            const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + S8_TH - 1) / S8_TH);
+            conv3x3_split8_kernel<<<dim3(tiles8 * a.ctiles, 1, a.N), S8_NT, 0, s>>>(am);
+        } else
+            conv3x3_split_kernel<1, 1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
 #endif
     } else if (ct2) {
         conv3x3_mfma_kernel<2, 1><<<dim3(tiles * (a.ctiles / 2), 1, a.N), 256, 0, s>>>(a);

@@ -146,6 +146,7 @@ struct ConvArgs {
     const float* wpk;   // packed weights (see pack_index)
     const void* wsplit; // split-bf16 packed weights (3 bf16 images) or null -> fp32 MFMA path
     const void* wsplit16; // split-fp16 packed weights (2 fp16 images, second scaled by 2^11); set by the launcher
+    const void* wsplit_sa; // single-accumulator split-fp16 weights (3 fp16 images A / B / C, conv3x3_split8_kernel); set by the launcher
     long long* stamps;  // diagnostic builds only: per-block phase cycle sums (null in production)
     QuadDesc qd[CRFP_MAX_KQ];
     const float* bpk;   // packed bias [ctiles*32]
