@@ -37,20 +37,31 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-# packed-weight cache of the per-operator entry points: key = identity + version of the weight / bias storages, so an in-place
-# update (optimizer step, the reference's conv_identify) repacks and an unchanged module pays the repack once
-_PACKED = {}
+# Packed-weight cache of the per-operator entry points.  The packed buffer hangs on the weight tensor OBJECT (it dies with
+# it -- a cache keyed by data_ptr would hand a recycled address the previous owner's weights) and is valid while the
+# in-place version counters of the weight and of the companion tensors (bias) are unchanged: an optimizer step or the
+# reference's conv_identify (model/CRFP.py:359-370) repacks, an untouched module pays the repack once.
+import weakref
 
 
 def _packed(kind, tensors, nbytes, pack_fn):
-    key = (kind,) + tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in tensors)
-    buf = _PACKED.get(key)
-    if buf is None:
-        if len(_PACKED) >= 256:
-            _PACKED.clear()
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=tensors[0].device)
-        pack_fn(buf)
-        _PACKED[key] = buf
+    owner = tensors[0]
+    slot = getattr(owner, "_crfp_packed", None)
+    if slot is None:
+        slot = {}
+        try:
+            owner._crfp_packed = slot
+        except AttributeError:     # not attachable: pack every time
+            slot = None
+    ent = slot.get(kind) if slot is not None else None
+    if ent is not None:
+        refs, versions, buf = ent
+        if all(r() is t for r, t in zip(refs, tensors)) and versions == tuple(t._version for t in tensors) and buf.device == owner.device:
+            return buf
+    buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=owner.device)
+    pack_fn(buf)
+    if slot is not None:
+        slot[kind] = (tuple(weakref.ref(t) for t in tensors), tuple(t._version for t in tensors), buf)
     return buf
 
 

@@ -59,6 +59,10 @@ def _twin(orc, sd, lrs, fvs, mks, y_only=False):
 
 def _check_frame_stats(got, twin, ref32, what):
     mx, mean, psnr = _stats(got, twin)
+    if ref32 is None:   # big geometries: the fp32 oracle is skipped (CPU time); absolute caps only
+        print(f"{what}: HIP-bf16 vs twin max {mx:.2e} mean {mean:.2e} PSNR {psnr:.1f} dB")
+        assert torch.isfinite(got).all() and mean <= 3e-4 and mx <= 2e-2 and psnr >= 65.0, (mx, mean, psnr)
+        return
     mx32, mean32, psnr32 = _stats(got, ref32)
     tmx, tmean, tpsnr = _stats(twin, ref32)
     print(f"{what}: HIP-bf16 vs twin max {mx:.2e} mean {mean:.2e} PSNR {psnr:.1f} dB | vs fp32 oracle max {mx32:.2e} mean {mean32:.2e} "
@@ -153,8 +157,7 @@ def test_bf16_config5_geometry_vs_twin(orc):
     d = dev()
     out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
     twin = _twin(orc, sd, lrs, fvs, mks)
-    ref32 = orc.crfp_dsv_forward(orc.load_numpy_state(sd), T(lrs), T(fvs), T(mks))
-    _check_frame_stats(out, twin, ref32, "config 5 geometry, 2 frames")
+    _check_frame_stats(out, twin, None, "config 5 geometry, 2 frames")
 
 
 def test_bf16_stream_100_calls_sigma50_vs_twin(orc):

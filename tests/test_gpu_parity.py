@@ -293,9 +293,8 @@ def test_alternate_kernel_paths(env):
     assert float(_golden_check(env).split()[1]) < 2e-4
 
 
-@pytest.mark.parametrize("env", [{"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "1"}, {"CRFP_CONV_MODE": "f32", "CRFP_CONV_CT": "1"},
-                                 {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SPLIT_PIPE": "1"}, {"CRFP_CONV_MODE": "bf16x6"},
-                                 {"CRFP_CONV_MODE": "bf16x6", "CRFP_SPLIT_IS": "0"}, {"CRFP_CONV_S3": "0"}, {}])
+@pytest.mark.parametrize("env", [{"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "1"}, {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SPLIT_PIPE": "1"},
+                                 {"CRFP_CONV_MODE": "bf16x6"}])
 def test_lab_kernel_paths(env):
     """The lab library (-DCRFP_LAB: every conv main loop that was tried -- split-bf16 single-role / input-stationary /
     warp-specialised / pipelined, 4- and 8-row tiles) stays correct, so the A/B numbers in DESIGN.md remain reproducible."""
