@@ -2030,7 +2030,8 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     if (split) {
 #ifdef CRFP_ACT_BF16
         // (8-row tiles, conv3x3_bf16_kernel<2>: 1.25 instead of 1.5 ds_read_b128 per MFMA and half the weight staging, but 450
-        // workgroups on 256 CUs -- measured neutral to -8 % per conv, so 4-row tiles stay)
+        // workgroups on 256 CUs -- measured neutral to -8 % per conv, so 4-row tiles stay.  A register prefetch two chunks deep
+        // (126 VGPRs, still 4 workgroups per CU) was also slower: 32->32 conv 15.2 -> 16.3 us, offset / mask head 70.8 -> 74.0.)
         conv3x3_bf16_kernel<1><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
 #else
         // 8-wave single-accumulator kernel for the convs with one cout tile (the 32-cout layers: one round of 450 workgroups
