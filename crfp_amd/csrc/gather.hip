@@ -675,10 +675,31 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
 // shared by the 9 taps (dcn_3 of CRFP_DSV at 8x resolution; the reference tiles the 2+1 channels 9x,
 // model/CRFP.py:341-347 -- here they stay compact: offmask3 quad = (dy, dx, mask, -)).
 // HBM-bound: 16 B in (gathered) + 16 B offmask + 16 B out per pixel.
+// lds_max > 0: LDS staging of the reference-feature window (north star).  The workgroup (4 rows x 64 pixels) takes the
+// min / max of its sampling rows and columns (LDS atomics), and when the window [ymin, ymax] x [xmin, xmax] holds at most
+// lds_max elements it is loaded once, coalesced, into LDS and the 16 (36 at clamped borders) corner reads of every pixel come
+// from there instead of going through the texture addresser one lane at a time; a larger window (offsets that scatter the
+// tile's samples) falls back to the direct gathers below.  Same arithmetic either way: bit-identical results.
+#ifdef CRFP_ACT_BF16
+typedef cu32x2 winel_t;
+__device__ __forceinline__ f32x4 win_quad(const winel_t& e) { return quad_from_bits(e); }
+__device__ __forceinline__ winel_t win_load(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __builtin_bit_cast(cu32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, CRFP_GATHER_AUX));
+}
+#else
+typedef f32x4 winel_t;
+__device__ __forceinline__ f32x4 win_quad(const winel_t& e) { return e; }
+__device__ __forceinline__ winel_t win_load(__amdgpu_buffer_rsrc_t r, int voff) { return bload(r, voff, 0); }
+#endif
+constexpr int DCN3_WIN = 40960 / (int)sizeof(winel_t);   // 40 KB window: 2560 fp32 / 5120 bf16 elements
+
 __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, long long xb,
                                                    const float* __restrict__ offmask3, long long omb,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                   float* __restrict__ out, long long ob, int H, int W) {
+                                                   float* __restrict__ out, long long ob, int H, int W, int lds_max) {
+    extern __shared__ __attribute__((aligned(16))) char dcn3_dyn_lds[];   // the window: allocated at launch only when lds_max > 0
+    winel_t* const win = reinterpret_cast<winel_t*>(dcn3_dyn_lds);
+    __shared__ int bnd[4];   // ymin, ymax, xmin, xmax of the tile's corner rows / columns
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int n = blockIdx.z;
@@ -708,7 +729,76 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
     // per tap, so the 36 bilinear corners are a 4x4 neighbourhood -> 16 loads instead of 36.  The
     // fractional parts stay per row / column (float rounding of y-1+ky+dy differs per ky).
     const bool regular = iy[1] == iy[0] + 1 && iy[2] == iy[0] + 2 && ix[1] == ix[0] + 1 && ix[2] == ix[0] + 2;
-    if (__all(regular)) {
+    bool use_lds = false;
+    int ymin = 0, xmin = 0, ww = 1;
+    if (lds_max > 0) {   // kernel-uniform
+        if (threadIdx.x == 0) { bnd[0] = 0x7fffffff; bnd[1] = -0x7fffffff; bnd[2] = 0x7fffffff; bnd[3] = -0x7fffffff; }
+        __syncthreads();
+        // wave-level min / max first (one LDS atomic per wave and bound instead of one per lane)
+        int a0 = iy[0], a1 = iy[2] + 1, a2 = ix[0], a3 = ix[2] + 1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a0 = min(a0, __shfl_xor(a0, o)); a1 = max(a1, __shfl_xor(a1, o));
+            a2 = min(a2, __shfl_xor(a2, o)); a3 = max(a3, __shfl_xor(a3, o));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&bnd[0], a0); atomicMax(&bnd[1], a1); atomicMin(&bnd[2], a2); atomicMax(&bnd[3], a3); }
+        __syncthreads();
+        ymin = bnd[0]; xmin = bnd[2];
+        const int wh = bnd[1] - ymin + 1;
+        ww = bnd[3] - xmin + 1;
+        use_lds = wh * ww <= min(lds_max, DCN3_WIN);
+        if (use_lds) {
+            const int nel = wh * ww;
+            const float rww = 1.0f / (float)ww;
+            for (int idx = threadIdx.x; idx < nel; idx += 256) {
+                int r = (int)((float)idx * rww);          // idx / ww for idx < 2^13: fix the float estimate by one step
+                r -= (r * ww > idx); r += ((r + 1) * ww <= idx);
+                const int c = idx - r * ww;
+                win[idx] = win_load(rx, ((ymin + r) * PW + (xmin + c)) * QB + guard);
+            }
+            __syncthreads();
+        }
+    }
+    if (use_lds) {
+        if (__all(regular)) {
+            const int base = (iy[0] - ymin) * ww + (ix[0] - xmin);
+            f32x4 nb[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nb[r][c] = win_quad(win[base + r * ww + c]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int tap = ky * 3 + kx;
+                    const float hy = 1.0f - ly[ky], hx = 1.0f - lx[kx];
+                    const f32x4 v = nb[ky][kx] * (hy * hx) + nb[ky][kx + 1] * (hy * lx[kx]) + nb[ky + 1][kx] * (ly[ky] * hx) +
+                                    nb[ky + 1][kx + 1] * (ly[ky] * lx[kx]);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        acc[o] = fmaf(w[(o * 4 + 3) * 9 + tap], v.w,
+                                      fmaf(w[(o * 4 + 2) * 9 + tap], v.z,
+                                           fmaf(w[(o * 4 + 1) * 9 + tap], v.y, fmaf(w[(o * 4 + 0) * 9 + tap], v.x, acc[o]))));
+                }
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int tap = ky * 3 + kx;
+                    const float hy = 1.0f - ly[ky], hx = 1.0f - lx[kx];
+                    const int base = (iy[ky] - ymin) * ww + (ix[kx] - xmin);
+                    const f32x4 v = win_quad(win[base]) * (hy * hx) + win_quad(win[base + 1]) * (hy * lx[kx]) +
+                                    win_quad(win[base + ww]) * (ly[ky] * hx) + win_quad(win[base + ww + 1]) * (ly[ky] * lx[kx]);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        acc[o] = fmaf(w[(o * 4 + 3) * 9 + tap], v.w,
+                                      fmaf(w[(o * 4 + 2) * 9 + tap], v.z,
+                                           fmaf(w[(o * 4 + 1) * 9 + tap], v.y, fmaf(w[(o * 4 + 0) * 9 + tap], v.x, acc[o]))));
+                }
+        }
+    } else if (__all(regular)) {
         const int vo = (iy[0] * PW + ix[0]) * QB + guard;
         pairraw_t nbp[4][2];
 #pragma unroll
@@ -765,7 +855,18 @@ int launch_dcn3(const float* x, long long xb, const float* offmask3, long long o
     // figure (4 in + 2 off + 1 mask + 4 out floats per pixel) that this kernel actually needs
     ProfScope prof("dcnv2_shared_c4", s, px * ((4 + 4) * sizeof(act_t) + (2 + 1) * 4.0), px * (2.0 * 4 * 4 * 9 + 36 * 7));
     dim3 grid((W + 63) / 64, (H + 3) / 4, N);
-    dcn3_kernel<<<grid, 256, 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W);
+    // LDS staging of the sampling window (the north star's design) is built in and bit-identical, but it LOSES on MI355X: @A
+    // fp32, stress weights (residuals over the whole +-10 px) 98.7-106 us against 77.7 us for the direct gathers, whatever the
+    // window budget (700 / 1200 / 2560 elements); SURVEY-8d weights (offset_std 0.02, residuals of a few px) 96.3-100.1 against
+    // 73.1 us.  The min / max reduction, two barriers, the staging loop and 40 KB of LDS per workgroup cost more than the 16
+    // per-lane gathers they replace -- the kernel is bound by VALU issue (~400 instructions per pixel: 9 bilinear taps x 4
+    // channels + the 4x4 channel mix), not by the texture path.  Lab library: CRFP_DCN3_LDS=<max window elements>.
+    int lds_max = 0;
+#ifdef CRFP_LAB
+    static const int lds_env = getenv("CRFP_DCN3_LDS") ? atoi(getenv("CRFP_DCN3_LDS")) : 0;
+    lds_max = lds_env;
+#endif
+    dcn3_kernel<<<grid, 256, lds_max > 0 ? DCN3_WIN * sizeof(winel_t) : 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W, lds_max);
     CRFP_CHECK_LAUNCH();
     return 0;
 }

@@ -5,9 +5,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from crfp_amd import _lib, synth
 from crfp_amd.model import CRFP
-ap = argparse.ArgumentParser(); ap.add_argument("--storage", default="f32"); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--storage", default="f32")
+ap.add_argument("--offset-std", type=float, default=None, help="0.02 = SURVEY 8d weights (small residual offsets)")
+a = ap.parse_args()
 dev = torch.device("cuda:0")
-sd = synth.make_state_dict(7)
+sd = synth.make_state_dict(7, offset_std=a.offset_std)
 m = CRFP.CRFP_DSV(device=dev, mid_channels=32)
 m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
 m.storage = a.storage
