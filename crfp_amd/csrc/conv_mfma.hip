@@ -2045,6 +2045,11 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
 #endif
     } else if (ct2) {
         conv3x3_mfma_kernel<2, 1><<<dim3(tiles * (a.ctiles / 2), 1, a.N), 256, 0, s>>>(a);
+    } else if ((long long)tiles * a.ctiles * a.N < 512) {
+        // few 8-row tiles (the LR-resolution convs of a single streamed frame: 115 workgroups for 180 x 320): 4-row tiles spread the
+        // same latency-bound work over twice as many CUs
+        const int tiles4 = ((a.W + TW - 1) / TW) * ((a.H + 3) / 4);
+        conv3x3_mfma_kernel<1, 1><<<dim3(tiles4 * a.ctiles, 1, a.N), 256, 0, s>>>(a);
     } else {
         conv3x3_mfma_kernel<1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(a);
     }
