@@ -42,7 +42,7 @@ constexpr int TW = 64, LW = TW + 2;
 // otherwise.  |error| < 3e-7 absolute on both, i.e. < 3e-6 px on the +-10 px DCN offsets.
 __device__ __forceinline__ float fast_tanh(float v) {
     const float e = __expf(-2.0f * fabsf(v));          // in (0, 1]: no overflow
-    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(t, v);
 }
 

@@ -107,7 +107,9 @@ enum StoreMode : int {
     ST_Q4 = 0,      // Q4 destination(s), optional channel-quad ranges to different tensors
     ST_PS = 1,      // pixel_shuffle(r) fused into the store, Q4 destination at (H*r, W*r)
     ST_NCHW = 2,    // NCHW planes
-    ST_OFFMASK = 3  // DCN offset/mask epilogue: quads < n_off_quads: 10*tanh + flow(y,x); rest: sigmoid
+    ST_OFFMASK = 3, // DCN offset/mask epilogue: quads < n_off_quads: 10*tanh + flow(y,x); rest: sigmoid
+    ST_DCNFUSE = 4  // pack-only mode: the 216 offset / mask rows in the register order of dcn_fused_kernel (gather.hip) -- each
+                    // lane half receives (dy, dx, mask) of its 36 sampling positions as accumulator slot 3*p + c of 7 x 16
 };
 
 struct ConvSrc {
@@ -185,6 +187,13 @@ __host__ __device__ inline int conv_row_to_cout(int row, int cout, int store, in
         const int co = 4 * Q + rr;
         return co < co_n ? co * r2 + s : -1;
     }
+    if (store == ST_DCNFUSE) {   // MFMA row 8q + 4h + r of cout tile T = accumulator register 4q + r of lane half h
+        const int T = row >> 5, r = row & 31, h = (r >> 2) & 1;
+        const int s = 16 * T + 4 * (r >> 3) + (r & 3);       // slot: position p = s / 3 of the half, component s % 3
+        if (s >= 108) return -1;
+        const int p = s / 3, c = s - 3 * p, P = 36 * h + p;  // P = deformable group * 9 + tap
+        return c == 2 ? 144 + P : 2 * P + c;                 // reference channel order [offset (dy, dx) x 72 | mask x 72]
+    }
     return row < cout ? row : -1;
 }
 
@@ -194,6 +203,7 @@ __host__ __device__ inline int conv_packed_rows(int cout, int store, int ps_r) {
         const int r2 = ps_r * ps_r, co_n = cout / r2;
         return ((co_n + 3) / 4) * r2 * 4;
     }
+    if (store == ST_DCNFUSE) return 224;
     return cout;
 }
 
@@ -258,11 +268,11 @@ struct NarrowArgs {
 };
 
 // Activations of the offset/mask heads (DCN modules, model/CRFP.py:338-340): hardware exp2/rcp, ~1 ulp each.
-__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 // 10*tanh(v) + f as (10 + f) - 20 / (1 + e^(2v)), c10f = 10 + f: mul, exp, add, rcp, fma.  e^(2v) = inf / 0 at the ends
 // gives f + 10 / f - 10 exactly; absolute error ~2e-6 px.
 __device__ __forceinline__ float tanh10_plus(float v, float c10f) {
-    const float r = __frcp_rn(1.0f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f));
+    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f));
     return __builtin_fmaf(r, -20.0f, c10f);
 }
 
@@ -296,6 +306,7 @@ int launch_conv_pack(const ConvArgs& a, const float* w_oihw, const float* bias, 
                      int cout_split, float* wpk, float* bpk, hipStream_t s);
 int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s);
 size_t conv_split_weight_bytes(const ConvArgs& a);
+size_t conv_split16_offset_bytes(const ConvArgs& a);   // offset of the fp16 pair (bf16 build: the bf16) image inside the split weight block
 int launch_conv_pack_split(const ConvArgs& a, const float* w_oihw, const float* w2, int cout_split, void* wsplit,
                            hipStream_t s);
 // conv_narrow.hip
@@ -316,6 +327,26 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
                   unsigned* ovf = nullptr);
 int launch_dcn_g8_pack(const float* w_oihw, float* wpk, hipStream_t s, bool f16 = false);  // fp32 [36][2][32][4] or split-fp16 image
 bool dcn_g8_use_f16();   // engine: split-fp16 DCN GEMM unless CRFP_DCN_MODE=f32
+// offset / mask conv (32 -> 216, model/CRFP.py:337-340) + dcn_g8 in ONE kernel: the 199 MB offset / mask tensor never exists
+struct DcnFuseArgs {
+    const float* feat;      // the DCN offset feature (32 channels): SRC_S3 image in the fp32 build, bf16 Q4 in the bf16 build
+    long long feat_b;       // floats (fp32 build) / elements (bf16 build) between batch items
+    const float* flow;      // [H][W][2] (x, y) added to the offsets as (y, x)
+    long long flow_b;
+    const void* wconv;      // offset / mask conv packed with ST_DCNFUSE rows: fp16 pair image (fp32 build) / bf16 image
+    const float* bconv;     // its 224 packed biases
+    const float* x;         // P4 features to sample (32 channels = 8 deformable groups)
+    long long xb;
+    const float* wdcn;      // split-fp16 DCN weight image (launch_dcn_g8_pack(f16 = true))
+    const float* bdcn;
+    float* out;             // aligned features, Q4
+    long long ob;
+    int N, H, W;
+    unsigned* ovf;
+    int probe;              // lab library only: timing experiments
+};
+bool dcn_fused_enabled();   // default on; CRFP_DCN_FUSED=0 keeps the two-kernel path
+int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s);
 int launch_dcn3(const float* x, long long xb, const float* offmask3, long long omb, const float* w_oihw,
                 const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
 int launch_dcn_generic(const float* x, const float* offset, const float* mask, const float* w, const float* b,

@@ -78,13 +78,13 @@ struct Item {
 enum ItemId {
     IT_F0 = 0,  // .. IT_F0+13 : FNet
     IT_ENC_LR0 = 14, IT_ENC_LR1, IT_UPS, IT_DOWN,
-    IT_LVL0,  // per level 9 items: FUSE, DB0, DB1, OM, DCNW, RB0, RB0F, RB1, RB2
-    IT_UPP = IT_LVL0 + 27, IT_POFF,
+    IT_LVL0,  // per level 10 items: FUSE, DB0, DB1, OM, DCNW, RB0, RB0F, RB1, RB2, OMF
+    IT_UPP = IT_LVL0 + 30, IT_POFF,
     IT_EH0, IT_EH1, IT_D3B0, IT_D3B1, IT_D3FUSE, IT_D3OM, IT_D3W, IT_R3_0, IT_R3_0F, IT_R3_1, IT_R3_2, IT_TTTF,
     IT_LAST, IT_COUNT
 };
-enum { L_FUSE = 0, L_DB0, L_DB1, L_OM, L_DCNW, L_RB0, L_RB0F, L_RB1, L_RB2 };
-static inline int it_lvl(int lvl, int which) { return IT_LVL0 + 9 * lvl + which; }
+enum { L_FUSE = 0, L_DB0, L_DB1, L_OM, L_DCNW, L_RB0, L_RB0F, L_RB1, L_RB2, L_OMF };
+static inline int it_lvl(int lvl, int which) { return IT_LVL0 + 10 * lvl + which; }
 
 struct SrcSpec { int kind, nch; };
 
@@ -204,6 +204,9 @@ struct Model {
             add_mfma(it_lvl(l, L_OM), "conv_mfma:dcn.offset_mask", ci_dcn(l, 3), ci_dcn(l, 4), {{FS, 32}}, ST_OFFMASK, 0,
                      CRFP_ACT_NONE);
             items[it_lvl(l, L_OM)].c.n_off_quads = 36;
+            // the same head packed in the register order of dcn_fused_kernel (offset / mask conv + dcn_g8 in one launch)
+            add_mfma(it_lvl(l, L_OMF), "conv_mfma:dcn.offset_mask_fused", ci_dcn(l, 3), ci_dcn(l, 4), {{FS, 32}}, ST_DCNFUSE, 0,
+                     CRFP_ACT_NONE);
             Item& dw = items[it_lvl(l, L_DCNW)];
             dw.type = T_DCN8;
             dw.name = "dcn_g8_weights";
@@ -614,11 +617,23 @@ struct Runner {
                     if (s3) mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, 0);
                     else mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {{f, 0, 0, 8}});
                 }
-                mfma(it_lvl(l, L_OM), 1, H2, W2, {{f, 0}}, {{F(L.offmask), 0, 0, 54}}, 0, 0, nullptr, 0, flow2, 0);
                 const Item& dw = M.items[it_lvl(l, L_DCNW)];
                 const bool f16 = !strict && dcn_g8_use_f16();
-                RUN(launch_dcn_g8(F(L.prev2), 0, F(L.offmask), 0, packed + dw.off_w + (f16 ? 36 * 2 * 32 * 4 : 0), packed + dw.off_b,
-                                  F(L.aligned), 0, 1, H2, W2, s, f16, ovf()));
+                if (s3 && f16 && dcn_fused_enabled()) {   // offset / mask head + dcn_g8 in one launch: offsets stay in registers
+                    const Item& om = M.items[it_lvl(l, L_OMF)];
+                    DcnFuseArgs fa;
+                    memset(&fa, 0, sizeof(fa));
+                    fa.feat = f; fa.feat_b = 0; fa.flow = flow2; fa.flow_b = 0;
+                    fa.wconv = (const char*)(packed + om.off_s) + conv_split16_offset_bytes(om.c); fa.bconv = packed + om.off_b;
+                    fa.x = F(L.prev2); fa.xb = 0;
+                    fa.wdcn = packed + dw.off_w + 36 * 2 * 32 * 4; fa.bdcn = packed + dw.off_b;
+                    fa.out = F(L.aligned); fa.ob = 0; fa.N = 1; fa.H = H2; fa.W = W2; fa.ovf = ovf();
+                    RUN(launch_dcn_fused(fa, s));
+                } else {
+                    mfma(it_lvl(l, L_OM), 1, H2, W2, {{f, 0}}, {{F(L.offmask), 0, 0, 54}}, 0, 0, nullptr, 0, flow2, 0);
+                    RUN(launch_dcn_g8(F(L.prev2), 0, F(L.offmask), 0, packed + dw.off_w + (f16 ? 36 * 2 * 32 * 4 : 0), packed + dw.off_b,
+                                      F(L.aligned), 0, 1, H2, W2, s, f16, ovf()));
+                }
                 if (fg && l > 0) {  // model/CRFP_test.py:2361,2375: resblock input * fg (x0.25) for levels 1, 2
                     RUN(launch_scale_q4(prop, 0, F(L.sc_prop), 6, H2, W2, F(L.fg2), nullptr, s));
                     RUN(launch_scale_q4(cw, 0, F(L.sc_cw), 2, H2, W2, F(L.fg2), nullptr, s));

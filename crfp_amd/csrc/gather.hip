@@ -8,6 +8,7 @@
 // 1-KiB row segments that the CU's L1 serves 3 times out of 4; HBM sees each input line once.
 #include "crfp_common.h"
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 
 #include <cstdlib>
@@ -455,28 +456,33 @@ struct DcnPair {
 
 struct DcnOff { f32x4 m4, oa, ob; };   // masks of 4 positions, (dy,dx) of positions (0,1) and (2,3)
 
+// one sampling position (p36 = 9 * group-in-half + tap, compile-time) into slot pi of P: coordinates, modulated bilinear weights,
+// the two 2-corner gathers
+__device__ __forceinline__ void dcn_issue_one(DcnPair& P, int pi, __amdgpu_buffer_rsrc_t rx, float dy, float dx, float mm, int p36,
+                                              float fy0, float fx0, float fH, float fW, int PW, int pitch, int plane_b, int hbase) {
+    const int gi = p36 / 9, tap = p36 - 9 * gi, ky = tap / 3, kx = tap - 3 * ky;
+    // (float)(cy-1) + (float)ky is exact, so this equals the reference's (float)(y - pad + ky) + dy
+    float sy = (fy0 + (float)ky) + dy;
+    float sx = (fx0 + (float)kx) + dx;
+    sy = fminf(fmaxf(sy, -1.0f), fH);
+    sx = fminf(fmaxf(sx, -1.0f), fW);
+    const float fy = floorf(sy), fx = floorf(sx);
+    const float ly = sy - fy, lx = sx - fx;
+    const float a = (1.0f - ly) * mm, b = ly * mm, hx = 1.0f - lx;
+    P.w[pi][0] = a * hx; P.w[pi][1] = a * lx; P.w[pi][2] = b * hx; P.w[pi][3] = b * lx;
+    const int vo = ((int)fy * PW + (int)fx) * QB + hbase + gi * plane_b;
+    P.tp[pi] = bload_pair(rx, vo, 0);
+    P.bt[pi] = bload_pair(rx, vo, pitch);
+}
+
 __device__ __forceinline__ void dcn_issue_pair(DcnPair& P, __amdgpu_buffer_rsrc_t rx, const DcnOff& O, int hb, int v, float fy0,
                                                float fx0, float fH, float fW, int PW, int pitch, int plane_b, int hbase) {
     const float dyv[4] = {O.oa.x, O.oa.z, O.ob.x, O.ob.z};
     const float dxv[4] = {O.oa.y, O.oa.w, O.ob.y, O.ob.w};
     const float mmv[4] = {O.m4.x, O.m4.y, O.m4.z, O.m4.w};
 #pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-        const int pp = hb + pi;
-        const int p36 = 4 * v + pp, gi = p36 / 9, tap = p36 - 9 * gi, ky = tap / 3, kx = tap - 3 * ky;
-        // (float)(cy-1) + (float)ky is exact, so this equals the reference's (float)(y - pad + ky) + dy
-        float sy = (fy0 + (float)ky) + dyv[pp];
-        float sx = (fx0 + (float)kx) + dxv[pp];
-        sy = fminf(fmaxf(sy, -1.0f), fH);
-        sx = fminf(fmaxf(sx, -1.0f), fW);
-        const float fy = floorf(sy), fx = floorf(sx);
-        const float ly = sy - fy, lx = sx - fx;
-        const float a = (1.0f - ly) * mmv[pp], b = ly * mmv[pp], hx = 1.0f - lx;
-        P.w[pi][0] = a * hx; P.w[pi][1] = a * lx; P.w[pi][2] = b * hx; P.w[pi][3] = b * lx;
-        const int vo = ((int)fy * PW + (int)fx) * QB + hbase + gi * plane_b;
-        P.tp[pi] = bload_pair(rx, vo, 0);
-        P.bt[pi] = bload_pair(rx, vo, pitch);
-    }
+    for (int pi = 0; pi < 2; ++pi)
+        dcn_issue_one(P, pi, rx, dyv[hb + pi], dxv[hb + pi], mmv[hb + pi], 4 * v + hb + pi, fy0, fx0, fH, fW, PW, pitch, plane_b, hbase);
 }
 
 __device__ __forceinline__ void dcn_consume_pair(const DcnPair& P, f32x16& acc, f32x16& acl, const f32x4* wl, int u, int lane) {
@@ -581,6 +587,245 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
     }
     if (ovf && !(vmax < 65504.0f)) atomicOr(ovf, 1u);
 }
+
+
+#ifndef CRFP_ACT_BF16
+// ---------------------------------------------------------------- offset / mask conv + dcn_g8 in one kernel (engine, f16x3)
+// The 32 -> 216 offset / mask head (model/CRFP.py:337-340) used to write 199 MB of offsets and masks that dcn_g8 read straight
+// back (28 % of the clip for the pair).  The conv's accumulator layout already is the sampler's: lane = pixel, lane half =
+// 4 deformable groups.  With the cout rows packed in ST_DCNFUSE order (crfp_common.h) every lane half receives the (dy, dx,
+// mask) of its 36 sampling positions as accumulator slot 3 p + c of 7 cout tiles x 16 registers, in the order the sampler
+// consumes them; the values go from the conv's registers through tanh / sigmoid into the coordinate arithmetic and never
+// touch memory.  Workgroup = 4 rows x 32 pixels (4 waves, as dcn_g8_pipe_kernel); the offset feature's SRC_S3 halo tile
+// (6 x 34 pixels, both fp16 parts of all 32 channels) and the DCN weight image stay in LDS for the workgroup's life, the conv
+// weights stream through one 18 KB stage per (cout tile, 16-channel chunk) (registers -> LDS, next stage's loads in flight
+// under the MFMAs).  After cout tile T the sampling pairs it completed run (2-3 of the 18); the last pair's gathers stay in
+// flight under tile T+1's MFMAs.  Same arithmetic in the same order as conv3x3_split_kernel<1,1,2> + dcn_g8_pipe_kernel: the
+// results are bit-identical to the two-kernel path.  LDS 81 408 B: two workgroups per CU.
+constexpr int DF_LW = 34, DF_NEL = 6 * DF_LW;        // halo tile of a 4 x 32-pixel workgroup
+constexpr int DF_NIN = (8 * DF_NEL + 255) / 256;     // 16-byte tile elements per thread
+constexpr int DF_WST = 9 * 2 * 64;                   // one (cout tile, chunk) stage of the fp16 pair image, 16-byte elements
+constexpr int DF_NWS = (DF_WST + 255) / 256;
+
+__device__ __forceinline__ void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(256, 2) void dcn_fused_kernel(const DcnFuseArgs a) {
+    __shared__ f32x4 tile[8][DF_NEL];   // [part * 4 + 8-channel group][halo pixel]: x0 planes, then x1s planes
+    __shared__ f32x4 wst[DF_WST];
+    __shared__ f32x4 wl[36 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 4, n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int px = tx0 + j, py = ty0 + wave;
+    const bool valid = px < W && py < H;
+    const int cx = min(px, W - 1), cy = min(py, H - 1);
+
+    const f32x4* __restrict__ s3 = reinterpret_cast<const f32x4*>(a.feat + (long long)n * a.feat_b);
+    f32x4 rt[DF_NIN];
+    bool tv[DF_NIN];
+#pragma unroll
+    for (int t = 0; t < DF_NIN; ++t) {
+        const int idx = tid + 256 * t, idc = min(idx, 8 * DF_NEL - 1);
+        const int pl = idc / DF_NEL, pix = idc - pl * DF_NEL, r = pix / DF_LW, c = pix - r * DF_LW;
+        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+        tv[t] = idx < 8 * DF_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        rt[t] = s3[((long long)pl * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1)];
+    }
+    const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(a.wconv);
+    f32x4 rws[DF_NWS];
+#define DF_WLOAD(ST)                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) rws[k] = wc[(ST) * DF_WST + min(tid + 256 * k, DF_WST - 1)];
+    DF_WLOAD(0)
+    for (int i = tid; i < 36 * 64; i += 256) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
+    const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
+    const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
+#pragma unroll
+    for (int t = 0; t < DF_NIN; ++t) {
+        const int idx = tid + 256 * t;
+        if (idx < 8 * DF_NEL) (&tile[0][0])[idx] = tv[t] ? rt[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+
+    // sampler set-up (dcn_g8_pipe_kernel)
+    const long long plane = (long long)H * W * 4;
+    const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
+    const int guard = pitch + QB;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (char*)const_cast<act_t*>(as_act(a.x) + (long long)n * a.xb) - guard, 0, 8 * plane_b + guard, 0x00020000);
+    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
+    const int hbase = 4 * h * plane_b + guard;
+    float bv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bv[k] = a.bconv[min(64 * k + lane, 223)];
+
+    f32x16 acc, acl, ca, cl;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acl[e] = 0.0f; }
+#ifdef CRFP_LAB
+    const int DF_PROBE = a.probe;   // timing experiments (results wrong), bits: 1 = no sampling, 2 = no conv MFMAs, 4 = no barriers / weight streaming after stage 0, 8 = barriers but no weight streaming
+#else
+    constexpr int DF_PROBE = 0;
+#endif
+#ifdef CRFP_LAB
+    const float pz = (DF_PROBE & 16) ? 0.0f : 1.0f;   // 16: zero offsets = regular, coalesced sampling positions
+#else
+    constexpr float pz = 1.0f;
+#endif
+    float ov[108];   // activated (dy, dx, mask) of position p at 3 p + c; every index below is a compile-time constant
+    DcnPair Q0, Q1;
+
+    // one (cout tile, chunk) stage = DF_BEGIN (weights registers -> LDS, next stage's loads) + 9 taps x 3 MFMAs (DF_TAPS)
+#define DF_BEGIN(T, CH)                                                                                   \
+    {                                                                                                     \
+        const bool first_ = 2 * (T) + (CH) == 0;                                                          \
+        if (first_ || !(DF_PROBE & 4)) df_lds_barrier();   /* every wave is done with the previous stage's weights */ \
+        if (first_ || !(DF_PROBE & 12))                                                                   \
+        _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) {                                              \
+            const int idx = tid + 256 * k;                                                                \
+            if (idx < DF_WST) wst[idx] = rws[k];                                                          \
+        }                                                                                                 \
+        if (first_ || !(DF_PROBE & 4)) df_lds_barrier();                                                  \
+        if (2 * (T) + (CH) + 1 < 14 && !(DF_PROBE & 12)) { DF_WLOAD(2 * (T) + (CH) + 1) }                 \
+        __builtin_amdgcn_sched_barrier(0);   /* the next stage's loads leave before this stage's MFMAs */  \
+    }
+#define DF_TAPS(CH, TA, TB)                                                                               \
+    if (!(DF_PROBE & 2))                                                                                  \
+    _Pragma("unroll") for (int tap = (TA); tap < (TB); ++tap) {                                           \
+        const int ky = tap / 3, kx = tap - 3 * ky;                                                        \
+        const dcn_f16x8 w0 = __builtin_bit_cast(dcn_f16x8, wst[(tap * 2) * 64 + lane]);                   \
+        const dcn_f16x8 w1 = __builtin_bit_cast(dcn_f16x8, wst[(tap * 2 + 1) * 64 + lane]);               \
+        const int pix = (wave + ky) * DF_LW + j + kx;                                                     \
+        const dcn_f16x8 b0 = __builtin_bit_cast(dcn_f16x8, tile[2 * (CH) + h][pix]);                      \
+        const dcn_f16x8 b1 = __builtin_bit_cast(dcn_f16x8, tile[4 + 2 * (CH) + h][pix]);                  \
+        cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, cl, 0, 0, 0);                                 \
+        ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, ca, 0, 0, 0);                                 \
+        cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, cl, 0, 0, 0);                                 \
+    }
+    // the accumulators of cout tile T start at its bias, as in the two-kernel path: the 224 packed biases sit in 4 VGPRs
+    // (lane L holds rows L, 64 + L, ...) and each value arrives through v_readlane -- scalar loads here cost a cache-miss
+    // round trip per cout tile and quad (28 per wave, a third of the kernel's fixed cost when measured), per-lane vector
+    // loads would drain the gathers in flight
+#define DF_BIAS(T)                                                                                        \
+    {                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
+            const int r0 = 32 * (T) + 8 * (e >> 2) + (e & 3), r1 = r0 + 4;                                \
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv[r0 >> 6]), r0 & 63)); \
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv[r1 >> 6]), r1 & 63)); \
+            ca[e] = h ? s1 : s0;                                                                          \
+            cl[e] = 0.0f;                                                                                 \
+        }                                                                                                 \
+    }
+    // end of cout tile T: the raw sums go to ov[] (the accumulators are free for tile T + 1); 10 tanh + flow / sigmoid follow
+    // in place, inside the first taps of tile T + 1
+#define DF_RAW(T)                                                                                         \
+    {                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
+            const int sl = 16 * (T) + e;                                                                  \
+            if (sl < 108) {                                                                               \
+                ca[e] += cl[e] * (1.0f / 2048.0f);                                                        \
+                ov[sl] = ca[e];                                                                           \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#define DF_TRANS(T)                                                                                       \
+    {                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
+            const int sl = 16 * (T) + e;                                                                  \
+            if (sl < 108)                                                                                 \
+                ov[sl] = sl % 3 == 0 ? tanh10_plus(ov[sl], cfy) : (sl % 3 == 1 ? tanh10_plus(ov[sl], cfx) : fast_sigmoid(ov[sl])); \
+        }                                                                                                 \
+    }
+#define DF_SB __builtin_amdgcn_sched_barrier(0);
+#define DF_I(U, P)                                                                                        \
+    if (!(DF_PROBE & 1)) {                                                                                \
+        dcn_issue_one(P, 0, rx, ov[6 * (U)] * pz, ov[6 * (U) + 1] * pz, ov[6 * (U) + 2], 2 * (U), fy0, fx0, fH, fW, PW, pitch, plane_b, hbase); \
+        dcn_issue_one(P, 1, rx, ov[6 * (U) + 3] * pz, ov[6 * (U) + 4] * pz, ov[6 * (U) + 5], 2 * (U) + 1, fy0, fx0, fH, fW, PW, pitch, plane_b, hbase); \
+    }
+#define DF_C(U, P)                                                                                        \
+    if (!(DF_PROBE & 1)) { dcn_consume_pair(P, acc, acl, wl, U, lane); }
+    // Cout tile T completes the sampling pairs up to (16 T + 10) / 6: 1, 4, 7, 9, 12, 15, 17.  The pairs of tile T are sampled
+    // INSIDE the two stages of tile T + 1, between its taps: the MFMA runs 32 clocks in its own pipe while the wave issues the
+    // sampler's VALU work (coordinates, weights, bilinear FMAs, fp16 split: as many issue clocks per pixel as the MFMAs take),
+    // and a pair's gathers fly under the MFMAs issued before its consumption.  Pair u lives in Q[u & 1]; I(u) follows C(u - 2).
+    DF_BIAS(0)
+    DF_BEGIN(0, 0) DF_TAPS(0, 0, 9)
+    DF_BEGIN(0, 1) DF_TAPS(1, 0, 9) DF_RAW(0)
+    DF_BIAS(1)
+    DF_BEGIN(1, 0) DF_TAPS(0, 0, 3) DF_TRANS(0) DF_SB DF_TAPS(0, 3, 6) DF_I(0, Q0) DF_SB DF_TAPS(0, 6, 9) DF_I(1, Q1) DF_SB
+    DF_BEGIN(1, 1) DF_TAPS(1, 0, 4) DF_SB DF_C(0, Q0) DF_SB DF_TAPS(1, 4, 9) DF_SB DF_C(1, Q1) DF_SB DF_RAW(1)
+    DF_BIAS(2)
+    DF_BEGIN(2, 0) DF_TAPS(0, 0, 3) DF_TRANS(1) DF_SB DF_TAPS(0, 3, 6) DF_I(2, Q0) DF_SB DF_TAPS(0, 6, 9) DF_I(3, Q1) DF_SB
+    DF_BEGIN(2, 1) DF_TAPS(1, 0, 3) DF_SB DF_C(2, Q0) DF_SB DF_TAPS(1, 3, 6) DF_SB DF_C(3, Q1) DF_SB DF_TAPS(1, 6, 9) DF_I(4, Q0) DF_SB DF_RAW(2)
+    DF_BIAS(3)
+    DF_BEGIN(3, 0) DF_TAPS(0, 0, 2) DF_TRANS(2) DF_SB DF_TAPS(0, 2, 4) DF_I(5, Q1) DF_SB DF_TAPS(0, 4, 7) DF_SB DF_C(4, Q0) DF_SB DF_TAPS(0, 7, 9) DF_I(6, Q0) DF_SB
+    DF_BEGIN(3, 1) DF_TAPS(1, 0, 3) DF_SB DF_C(5, Q1) DF_SB DF_TAPS(1, 3, 6) DF_SB DF_C(6, Q0) DF_SB DF_TAPS(1, 6, 9) DF_I(7, Q1) DF_SB DF_RAW(3)
+    DF_BIAS(4)
+    DF_BEGIN(4, 0) DF_TAPS(0, 0, 2) DF_TRANS(3) DF_SB DF_TAPS(0, 2, 4) DF_SB DF_C(7, Q1) DF_SB DF_TAPS(0, 4, 7) DF_I(8, Q0) DF_SB DF_TAPS(0, 7, 9) DF_I(9, Q1) DF_SB
+    DF_BEGIN(4, 1) DF_TAPS(1, 0, 4) DF_SB DF_C(8, Q0) DF_SB DF_TAPS(1, 4, 9) DF_SB DF_C(9, Q1) DF_SB DF_RAW(4)
+    DF_BIAS(5)
+    DF_BEGIN(5, 0) DF_TAPS(0, 0, 3) DF_TRANS(4) DF_SB DF_TAPS(0, 3, 6) DF_I(10, Q0) DF_SB DF_TAPS(0, 6, 9) DF_I(11, Q1) DF_SB
+    DF_BEGIN(5, 1) DF_TAPS(1, 0, 3) DF_SB DF_C(10, Q0) DF_SB DF_TAPS(1, 3, 6) DF_SB DF_C(11, Q1) DF_SB DF_TAPS(1, 6, 9) DF_I(12, Q0) DF_SB DF_RAW(5)
+    DF_BIAS(6)
+    DF_BEGIN(6, 0) DF_TAPS(0, 0, 2) DF_TRANS(5) DF_SB DF_TAPS(0, 2, 4) DF_I(13, Q1) DF_SB DF_TAPS(0, 4, 7) DF_SB DF_C(12, Q0) DF_SB DF_TAPS(0, 7, 9) DF_I(14, Q0) DF_SB
+    DF_BEGIN(6, 1) DF_TAPS(1, 0, 3) DF_SB DF_C(13, Q1) DF_SB DF_TAPS(1, 3, 6) DF_SB DF_C(14, Q0) DF_SB DF_TAPS(1, 6, 9) DF_I(15, Q1) DF_SB DF_RAW(6)
+    DF_TRANS(6) DF_I(16, Q0) DF_SB DF_C(15, Q1) DF_SB DF_I(17, Q1) DF_SB DF_C(16, Q0) DF_SB DF_C(17, Q1)
+#undef DF_C
+#undef DF_I
+#undef DF_TAPS
+#undef DF_BEGIN
+#undef DF_SB
+#undef DF_TRANS
+#undef DF_RAW
+#undef DF_BIAS
+#undef DF_WLOAD
+    if (!valid) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
+    act_t* o = as_act(a.out) + (long long)n * a.ob + ((long long)py * W + px) * 4;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cq = 2 * g + h;
+        const float4 bb = *reinterpret_cast<const float4*>(a.bdcn + 4 * cq);
+        const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
+    }
+    if (a.ovf && !(vmax < 65504.0f)) atomicOr(a.ovf, 1u);
+}
+
+bool dcn_fused_enabled() {
+    static const bool on = !(getenv("CRFP_DCN_FUSED") && atoi(getenv("CRFP_DCN_FUSED")) == 0);
+    return on;
+}
+
+int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
+    const double px = (double)a.N * a.H * a.W;
+    ProfScope prof("offset_mask_conv+dcnv2_g8_fused", s, px * (32 * 4.0 + 8.0 + (32 + 32) * sizeof(act_t)),
+                   2.0 * px * 32 * 216 * 9 + 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
+#ifdef CRFP_LAB
+    static const int probe_env = getenv("CRFP_DCN_FUSE_PROBE") ? atoi(getenv("CRFP_DCN_FUSE_PROBE")) : 0;
+    DcnFuseArgs b = a;
+    b.probe = probe_env;
+    static bool once = false;
+    if (!once && getenv("CRFP_DCN_FUSE_OCC")) {
+        once = true;
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dcn_fused_kernel, 256, 0);
+        fprintf(stderr, "dcn_fused_kernel: %d workgroups per CU (hip error %d)\n", nb, (int)e);
+    }
+    dcn_fused_kernel<<<dim3((a.W + 31) / 32, (a.H + 3) / 4, a.N), 256, 0, s>>>(b);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+#endif
+    dcn_fused_kernel<<<dim3((a.W + 31) / 32, (a.H + 3) / 4, a.N), 256, 0, s>>>(a);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+#else
+bool dcn_fused_enabled() { return false; }
+int launch_dcn_fused(const DcnFuseArgs&, hipStream_t) { set_error("dcn_fused: not built for bf16 storage"); return CRFP_E_UNSUPPORTED; }
+#endif
 
 // wpk[((p36*2 + half)*32 + row)*4 + i] = W[row][4*(4*half + p36/9) + i][p36 % 9]
 #ifndef CRFP_ACT_BF16

@@ -13,6 +13,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the torch-CPU oracle: one thread per core this process may really use (the GPU box shows 256 host cores to a 16-core
+    # allotment; torch's default of one thread per visible core makes the small oracle convs several times slower)
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -286,7 +286,7 @@ def _golden_check(env, lab=False, want="MAXDIFF"):
 
 
 @pytest.mark.parametrize("env", [{"CRFP_PRECISION": "f32"}, {"CRFP_CONV_MODE": "f32"}, {"CRFP_DCN_MODE": "f32"},
-                                 {"CRFP_SIDE_STREAM": "0"}])
+                                 {"CRFP_SIDE_STREAM": "0"}, {"CRFP_DCN_FUSED": "0"}])
 def test_alternate_kernel_paths(env):
     """The process-wide switches the product library reads (strict fp32 MFMA for convs and / or the DCN GEMM, single-stream
     schedule) give the same clip within the parity tolerance."""
@@ -351,6 +351,13 @@ def test_producer_split_is_bit_identical():
     digests = [_golden_check({"CRFP_CONV_S3": s3}, lab=True, want="DIGEST") for s3 in ("1", "0")]
     assert digests[0] == digests[1]
     assert _golden_check({}, want="DIGEST") == digests[0]      # and the product library computes exactly the same clip
+
+
+def test_fused_offset_conv_dcn_is_bit_identical():
+    """dcn_fused_kernel (offset / mask head + dcn_g8 in one launch, the offsets never leave the registers) applies
+    the arithmetic of the two-kernel path in the same order: not one bit of the clip may differ (20x36 clip: partial tiles in x
+    and y at 2x resolution)."""
+    assert _golden_check({}, want="DIGEST") == _golden_check({"CRFP_DCN_FUSED": "0"}, want="DIGEST")
 
 
 def test_config_b_geometry_vs_oracle(orc):
