@@ -619,7 +619,7 @@ struct Runner {
                 }
                 const Item& dw = M.items[it_lvl(l, L_DCNW)];
                 const bool f16 = !strict && dcn_g8_use_f16();
-                if (s3 && f16 && dcn_fused_enabled()) {   // offset / mask head + dcn_g8 in one launch: offsets stay in registers
+                if ((s3 || kActBf16) && f16 && dcn_fused_enabled()) {   // offset / mask head + dcn_g8 in one launch: offsets stay in registers
                     const Item& om = M.items[it_lvl(l, L_OMF)];
                     DcnFuseArgs fa;
                     memset(&fa, 0, sizeof(fa));

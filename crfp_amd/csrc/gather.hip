@@ -823,8 +823,189 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     return 0;
 }
 #else
-bool dcn_fused_enabled() { return false; }
-int launch_dcn_fused(const DcnFuseArgs&, hipStream_t) { set_error("dcn_fused: not built for bf16 storage"); return CRFP_E_UNSUPPORTED; }
+// ---------------------------------------------------------------- the same fusion for bf16 storage
+// The offset feature arrives as bf16 Q4 (8-byte quads): its halo tile is copied into LDS as 16-byte elements of 8 channels
+// (13 KB), the head's bf16 weights stream one WHOLE cout tile per stage (both 16-channel chunks, 18 KB, one barrier pair per
+// 18 MFMAs), one v_mfma_f32_32x32x16_bf16 per (tap, chunk) into ONE accumulator that starts at the bias -- the arithmetic of
+// conv3x3_bf16_kernel in the same order, so the clip is bit-identical to the two-kernel path here too.  A corner pair of the
+// sampler is one dwordx4 (24 registers per sampling pair), so three pairs are in flight instead of two.  LDS 68 352 B, two
+// workgroups per CU.
+constexpr int DF_LW = 34, DF_NEL = 6 * DF_LW;
+constexpr int DF_NIN = (8 * DF_NEL + 255) / 256;     // 8-byte quads of the tile per thread
+constexpr int DF_WST = 2 * 9 * 64;                   // one cout tile of the bf16 image, 16-byte elements
+constexpr int DF_NWS = (DF_WST + 255) / 256;
+typedef __bf16 df_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(256, 2) void dcn_fused_kernel(const DcnFuseArgs a) {
+    __shared__ cu32x2 tile[4][DF_NEL][2];   // [8-channel group][halo pixel][quad of the pair]
+    __shared__ f32x4 wst[DF_WST];
+    __shared__ f32x4 wl[36 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 4, n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int px = tx0 + j, py = ty0 + wave;
+    const bool valid = px < W && py < H;
+    const int cx = min(px, W - 1), cy = min(py, H - 1);
+
+    const cu32x2* __restrict__ fq = reinterpret_cast<const cu32x2*>(as_act(a.feat) + (long long)n * a.feat_b);
+    cu32x2 rt[DF_NIN];
+    bool tv[DF_NIN];
+#pragma unroll
+    for (int t = 0; t < DF_NIN; ++t) {
+        const int idx = tid + 256 * t, idc = min(idx, 8 * DF_NEL - 1);
+        const int q = idc / DF_NEL, pix = idc - q * DF_NEL, r = pix / DF_LW, c = pix - r * DF_LW;
+        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+        tv[t] = idx < 8 * DF_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        rt[t] = fq[((long long)q * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1)];
+    }
+    const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(a.wconv);
+    f32x4 rws[DF_NWS];
+#define DF_WLOAD(ST)                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) rws[k] = wc[(ST) * DF_WST + min(tid + 256 * k, DF_WST - 1)];
+    DF_WLOAD(0)
+    for (int i = tid; i < 36 * 64; i += 256) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
+    const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
+    const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
+#pragma unroll
+    for (int t = 0; t < DF_NIN; ++t) {
+        const int idx = tid + 256 * t;
+        if (idx < 8 * DF_NEL) {
+            const int q = idx / DF_NEL, pix = idx - q * DF_NEL;
+            tile[q >> 1][pix][q & 1] = tv[t] ? rt[t] : cu32x2{0u, 0u};
+        }
+    }
+
+    const long long plane = (long long)H * W * 4;
+    const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
+    const int guard = pitch + QB;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (char*)const_cast<act_t*>(as_act(a.x) + (long long)n * a.xb) - guard, 0, 8 * plane_b + guard, 0x00020000);
+    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
+    const int hbase = 4 * h * plane_b + guard;
+    float bv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bv[k] = a.bconv[min(64 * k + lane, 223)];
+
+    f32x16 acc, acl, ca;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acl[e] = 0.0f; }
+    float ov[108];
+    DcnPair Q0, Q1, Q2;
+
+#define DF_BEGIN(T)                                                                                       \
+    {                                                                                                     \
+        df_lds_barrier();                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) {                                              \
+            const int idx = tid + 256 * k;                                                                \
+            if (idx < DF_WST) wst[idx] = rws[k];                                                          \
+        }                                                                                                 \
+        df_lds_barrier();                                                                                 \
+        if ((T) + 1 < 7) { DF_WLOAD((T) + 1) }                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+    // MFMAs MA .. MB-1 of the cout tile's 18 (chunk-major, then taps: the K order of conv3x3_bf16_kernel)
+#define DF_M(MA, MB)                                                                                      \
+    _Pragma("unroll") for (int m = (MA); m < (MB); ++m) {                                                 \
+        const int ch = m / 9, tap = m - 9 * ch, ky = tap / 3, kx = tap - 3 * ky;                          \
+        const df_bf16x8 w0 = __builtin_bit_cast(df_bf16x8, wst[m * 64 + lane]);                           \
+        const int pix = (wave + ky) * DF_LW + j + kx;                                                     \
+        const df_bf16x8 b0 = __builtin_bit_cast(df_bf16x8, *reinterpret_cast<const f32x4*>(&tile[2 * ch + h][pix][0])); \
+        ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, ca, 0, 0, 0);                                \
+    }
+#define DF_BIAS(T)                                                                                        \
+    {                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
+            const int r0 = 32 * (T) + 8 * (e >> 2) + (e & 3), r1 = r0 + 4;                                \
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv[r0 >> 6]), r0 & 63)); \
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv[r1 >> 6]), r1 & 63)); \
+            ca[e] = h ? s1 : s0;                                                                          \
+        }                                                                                                 \
+    }
+#define DF_RAW(T)                                                                                         \
+    {                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
+            const int sl = 16 * (T) + e;                                                                  \
+            if (sl < 108) ov[sl] = ca[e];                                                                 \
+        }                                                                                                 \
+    }
+#define DF_TRANS(T)                                                                                       \
+    {                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
+            const int sl = 16 * (T) + e;                                                                  \
+            if (sl < 108)                                                                                 \
+                ov[sl] = sl % 3 == 0 ? tanh10_plus(ov[sl], cfy) : (sl % 3 == 1 ? tanh10_plus(ov[sl], cfx) : fast_sigmoid(ov[sl])); \
+        }                                                                                                 \
+    }
+#define DF_SB __builtin_amdgcn_sched_barrier(0);
+#define DF_I(U, P)                                                                                        \
+    {                                                                                                     \
+        dcn_issue_one(P, 0, rx, ov[6 * (U)], ov[6 * (U) + 1], ov[6 * (U) + 2], 2 * (U), fy0, fx0, fH, fW, PW, pitch, plane_b, hbase); \
+        dcn_issue_one(P, 1, rx, ov[6 * (U) + 3], ov[6 * (U) + 4], ov[6 * (U) + 5], 2 * (U) + 1, fy0, fx0, fH, fW, PW, pitch, plane_b, hbase); \
+    }
+#define DF_C(U, P) { dcn_consume_pair(P, acc, acl, wl, U, lane); }
+    // cout tile T completes the sampling pairs up to (16 T + 10) / 6: 1, 4, 7, 9, 12, 15, 17; they are sampled inside tile T + 1.
+    // Pair u lives in Q[u % 3]; I(u) follows C(u - 3).
+    DF_BIAS(0)
+    DF_BEGIN(0) DF_M(0, 18) DF_RAW(0)
+    DF_BIAS(1)
+    DF_BEGIN(1) DF_M(0, 6) DF_TRANS(0) DF_SB DF_M(6, 12) DF_I(0, Q0) DF_SB DF_M(12, 18) DF_I(1, Q1) DF_SB DF_RAW(1)
+    DF_BIAS(2)
+    DF_BEGIN(2) DF_M(0, 4) DF_TRANS(1) DF_SB DF_M(4, 8) DF_I(2, Q2) DF_SB DF_M(8, 12) DF_SB DF_C(0, Q0) DF_SB DF_M(12, 15) DF_I(3, Q0) DF_SB
+                DF_M(15, 18) DF_SB DF_C(1, Q1) DF_SB DF_I(4, Q1) DF_SB DF_RAW(2)
+    DF_BIAS(3)
+    DF_BEGIN(3) DF_M(0, 3) DF_TRANS(2) DF_SB DF_M(3, 6) DF_SB DF_C(2, Q2) DF_SB DF_M(6, 9) DF_I(5, Q2) DF_SB DF_M(9, 12) DF_SB DF_C(3, Q0) DF_SB
+                DF_M(12, 15) DF_I(6, Q0) DF_SB DF_M(15, 18) DF_SB DF_C(4, Q1) DF_SB DF_I(7, Q1) DF_SB DF_RAW(3)
+    DF_BIAS(4)
+    DF_BEGIN(4) DF_M(0, 4) DF_TRANS(3) DF_SB DF_M(4, 8) DF_SB DF_C(5, Q2) DF_SB DF_M(8, 12) DF_I(8, Q2) DF_SB DF_M(12, 15) DF_SB DF_C(6, Q0) DF_SB
+                DF_M(15, 18) DF_I(9, Q0) DF_SB DF_C(7, Q1) DF_SB DF_RAW(4)
+    DF_BIAS(5)
+    DF_BEGIN(5) DF_M(0, 4) DF_TRANS(4) DF_SB DF_M(4, 8) DF_I(10, Q1) DF_SB DF_M(8, 12) DF_SB DF_C(8, Q2) DF_SB DF_M(12, 15) DF_I(11, Q2) DF_SB
+                DF_M(15, 18) DF_SB DF_C(9, Q0) DF_SB DF_I(12, Q0) DF_SB DF_RAW(5)
+    DF_BIAS(6)
+    DF_BEGIN(6) DF_M(0, 3) DF_TRANS(5) DF_SB DF_M(3, 6) DF_SB DF_C(10, Q1) DF_SB DF_M(6, 9) DF_I(13, Q1) DF_SB DF_M(9, 12) DF_SB DF_C(11, Q2) DF_SB
+                DF_M(12, 15) DF_I(14, Q2) DF_SB DF_M(15, 18) DF_SB DF_C(12, Q0) DF_SB DF_I(15, Q0) DF_SB DF_RAW(6)
+    DF_TRANS(6) DF_SB DF_C(13, Q1) DF_SB DF_I(16, Q1) DF_SB DF_C(14, Q2) DF_SB DF_I(17, Q2) DF_SB DF_C(15, Q0) DF_SB DF_C(16, Q1) DF_SB DF_C(17, Q2)
+#undef DF_C
+#undef DF_I
+#undef DF_SB
+#undef DF_TRANS
+#undef DF_RAW
+#undef DF_BIAS
+#undef DF_M
+#undef DF_BEGIN
+#undef DF_WLOAD
+    if (!valid) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
+    act_t* o = as_act(a.out) + (long long)n * a.ob + ((long long)py * W + px) * 4;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cq = 2 * g + h;
+        const float4 bb = *reinterpret_cast<const float4*>(a.bdcn + 4 * cq);
+        const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
+    }
+    if (a.ovf && !(vmax < 65504.0f)) atomicOr(a.ovf, 1u);
+}
+
+bool dcn_fused_enabled() {
+    static const bool on = !(getenv("CRFP_DCN_FUSED") && atoi(getenv("CRFP_DCN_FUSED")) == 0);
+    return on;
+}
+
+int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
+    const double px = (double)a.N * a.H * a.W;
+    ProfScope prof("offset_mask_conv+dcnv2_g8_fused", s, px * (8.0 + (32 + 32 + 32) * sizeof(act_t)),
+                   2.0 * px * 32 * 216 * 9 + 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
+    dcn_fused_kernel<<<dim3((a.W + 31) / 32, (a.H + 3) / 4, a.N), 256, 0, s>>>(a);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
 #endif
 
 // wpk[((p36*2 + half)*32 + row)*4 + i] = W[row][4*(4*half + p36/9) + i][p36 % 9]

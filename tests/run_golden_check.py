@@ -18,6 +18,8 @@ dev = torch.device("cuda:0")
 m = CRFP.CRFP_DSV(device=dev, mid_channels=32)
 m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
 m = m.to(dev).eval()
+if os.environ.get("CRFP_CHECK_STORAGE"):   # bf16: MAXDIFF is then the bf16 rounding noise, DIGEST still identifies the clip
+    m.storage = os.environ["CRFP_CHECK_STORAGE"]
 out = m(lrs=torch.from_numpy(lrs).to(dev), fvs=torch.from_numpy(fvs).to(dev), mks=torch.from_numpy(mks).to(dev)).cpu().numpy()
 print("MAXDIFF %.6e" % float(np.abs(out - g["out"]).max()))
 import hashlib  # noqa: E402

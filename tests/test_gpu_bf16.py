@@ -194,3 +194,12 @@ def test_bf16_stream_100_calls_sigma50_vs_twin(orc):
     print("bf16 stream drift, mean|HIP - twin| per 10 calls:", " ".join(f"{v:.2e}" for v in curve), "| max over all:", f"{max(maxs):.2e}")
     assert max(means) <= 5e-4 and max(maxs) <= 5e-2
     assert np.mean(means[50:]) <= 2.0 * np.mean(means[5:50]) + 1e-6
+
+
+def test_bf16_fused_offset_conv_dcn_is_bit_identical():
+    """The bf16 build's dcn_fused_kernel against its two-kernel path (conv3x3_bf16_kernel + dcn_g8_pipe_kernel): same
+    arithmetic in the same order, so the clips must agree bit for bit."""
+    from test_gpu_parity import _golden_check
+    a = _golden_check({"CRFP_CHECK_STORAGE": "bf16"}, want="DIGEST")
+    b = _golden_check({"CRFP_CHECK_STORAGE": "bf16", "CRFP_DCN_FUSED": "0"}, want="DIGEST")
+    assert a == b
