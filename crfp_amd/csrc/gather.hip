@@ -464,13 +464,14 @@ __device__ __forceinline__ void dcn_issue_one(DcnPair& P, int pi, __amdgpu_buffe
     // (float)(cy-1) + (float)ky is exact, so this equals the reference's (float)(y - pad + ky) + dy
     float sy = (fy0 + (float)ky) + dy;
     float sx = (fx0 + (float)kx) + dx;
-    sy = fminf(fmaxf(sy, -1.0f), fH);
-    sx = fminf(fmaxf(sx, -1.0f), fW);
+    sy = __builtin_amdgcn_fmed3f(sy, -1.0f, fH);   // = min(max(sy, -1), H) in one instruction (the offsets are finite)
+    sx = __builtin_amdgcn_fmed3f(sx, -1.0f, fW);
     const float fy = floorf(sy), fx = floorf(sx);
     const float ly = sy - fy, lx = sx - fx;
     const float a = (1.0f - ly) * mm, b = ly * mm, hx = 1.0f - lx;
     P.w[pi][0] = a * hx; P.w[pi][1] = a * lx; P.w[pi][2] = b * hx; P.w[pi][3] = b * lx;
-    const int vo = ((int)fy * PW + (int)fx) * QB + hbase + gi * plane_b;
+    // element index fy * PW + fx in float (exact below 2^24: a 2x-resolution plane has < 2^22 elements), one conversion
+    const int vo = (int)__builtin_fmaf(fy, (float)PW, fx) * QB + hbase + gi * plane_b;
     P.tp[pi] = bload_pair(rx, vo, 0);
     P.bt[pi] = bload_pair(rx, vo, pitch);
 }
@@ -495,13 +496,24 @@ __device__ __forceinline__ void dcn_consume_pair(const DcnPair& P, f32x16& acc, 
         val = __builtin_elementwise_fma(pair_hi(P.bt[pi]), f32x4{P.w[pi][3], P.w[pi][3], P.w[pi][3], P.w[pi][3]}, val);
         xs[4 * pi + 0] = val.x; xs[4 * pi + 1] = val.y; xs[4 * pi + 2] = val.z; xs[4 * pi + 3] = val.w;
     }
-    dcn_f16x8 b0, b1;
+    // the exact two-term split in its 3-op-per-value form (conv_mfma.hip split_f16x8_fast): one v_cvt_pk_f16_f32 per pair of
+    // values, x - x0 as one v_fma_mix_f32, the scaled residuals through a second pack -- the same values as the scalar form
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    u4_t hi4, lo4;
+    float negone = -1.0f;
+    asm("" : "+v"(negone));   // opaque: keeps fma(x0, -1, x) one v_fma_mix_f32
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const _Float16 hh = (_Float16)xs[i];
-        b0[i] = hh;
-        b1[i] = (_Float16)((xs[i] - (float)hh) * 2048.0f);
+    for (int i = 0; i < 4; ++i) {
+        const h2_t h2 = __builtin_convertvector(f2_t{xs[2 * i], xs[2 * i + 1]}, h2_t);
+        const float r0 = __builtin_fmaf((float)h2[0], negone, xs[2 * i]);
+        const float r1 = __builtin_fmaf((float)h2[1], negone, xs[2 * i + 1]);
+        const h2_t l2 = __builtin_convertvector(f2_t{r0 * 2048.0f, r1 * 2048.0f}, h2_t);
+        hi4[i] = __builtin_bit_cast(unsigned, h2);
+        lo4[i] = __builtin_bit_cast(unsigned, l2);
     }
+    const dcn_f16x8 b0 = __builtin_bit_cast(dcn_f16x8, hi4), b1 = __builtin_bit_cast(dcn_f16x8, lo4);
     const dcn_f16x8 w0 = __builtin_bit_cast(dcn_f16x8, wl[(2 * u) * 64 + lane]);
     const dcn_f16x8 w1 = __builtin_bit_cast(dcn_f16x8, wl[(2 * u + 1) * 64 + lane]);
     acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, acl, 0, 0, 0);
@@ -800,6 +812,7 @@ bool dcn_fused_enabled() {
 }
 
 int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
+    if ((long long)(a.H + 1) * (a.W + 1) >= (1ll << 24)) { set_error("dcn_g8: plane of %d x %d exceeds the sampler's 2^24-element index range", a.H, a.W); return CRFP_E_UNSUPPORTED; }
     const double px = (double)a.N * a.H * a.W;
     ProfScope prof("offset_mask_conv+dcnv2_g8_fused", s, px * (32 * 4.0 + 8.0 + (32 + 32) * sizeof(act_t)),
                    2.0 * px * 32 * 216 * 9 + 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
@@ -999,6 +1012,7 @@ bool dcn_fused_enabled() {
 }
 
 int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
+    if ((long long)(a.H + 1) * (a.W + 1) >= (1ll << 24)) { set_error("dcn_g8: plane of %d x %d exceeds the sampler's 2^24-element index range", a.H, a.W); return CRFP_E_UNSUPPORTED; }
     const double px = (double)a.N * a.H * a.W;
     ProfScope prof("offset_mask_conv+dcnv2_g8_fused", s, px * (8.0 + (32 + 32 + 32) * sizeof(act_t)),
                    2.0 * px * 32 * 216 * 9 + 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
@@ -1056,6 +1070,7 @@ int launch_dcn_g8_pack(const float* w, float* wpk, hipStream_t s, bool f16) {
 
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
                   const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16, unsigned* ovf) {
+    if ((long long)(H + 1) * (W + 1) >= (1ll << 24)) { set_error("dcn_g8: plane of %d x %d exceeds the sampler's 2^24-element index range", H, W); return CRFP_E_UNSUPPORTED; }
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * ((32 + 32) * sizeof(act_t) + (144 + 72) * 4.0) + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
     int probe = 0;
