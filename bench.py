@@ -75,7 +75,7 @@ ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_mfma_kernel",
                  "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel",),
                  "flow_warp_q4_c4": ("flow_warp_p4_kernel",), "flow_warp_q4_c32": ("flow_warp_p4_kernel",),
                  "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "flow_warp_q4_c32+c24": ("flow_warp_p4_dual_kernel",),
-                 "hr_prep_up8_blend": ("hr_prep_kernel",)}
+                 "hr_prep_up8_blend": ("hr_prep_kernel",), "offset_mask_conv+dcnv2_g8_fused": ("dcn_fused_kernel",)}
 
 
 def pmc_traffic(family: str, storage: str):
@@ -285,6 +285,23 @@ def main():
                                   "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"], storage),
                                   "avg_launch_us": dom["avg_us"],
                                   "algorithmic_bytes_per_launch": domf["bytes"] / domf["launches"]}
+        fz = fam.get("offset_mask_conv+dcnv2_g8_fused")
+        if fz:
+            # the 32 -> 216 offset / mask head and dcn_g8 as ONE kernel (gather.hip dcn_fused_kernel): the offsets and masks
+            # (216 fp32 channels written and read back by the two-kernel path) never reach HBM
+            fs = fz["ms"] * 1e-3
+            peak = MFMA16_PEAK_TFLOPS if storage == "bf16" else SPLIT_F16_EQUIV_PEAK_TFLOPS
+            px2 = (2 * h) * (2 * w)
+            result["dcn_fused"] = {"kernel": "offset_mask_conv+dcnv2_g8_fused", "bound": "mfma", "launches_per_step": fz["launches"] / psteps,
+                                   "avg_us": 1e3 * fz["ms"] / fz["launches"], "achieved": fz["flops"] / fs / 1e12, "peak": peak,
+                                   "unit": "TFLOP/s", "frac": fz["flops"] / fs / 1e12 / peak,
+                                   "algorithmic_GBps": fz["bytes"] / fs / 1e9,
+                                   "traffic": pmc_traffic("offset_mask_conv+dcnv2_g8_fused", storage),
+                                   "hbm_bytes_not_moved_per_launch": 2.0 * px2 * 216 * 4,
+                                   "note": "offset / mask head + dcn_g8 in one launch, bit-identical to the two-kernel path "
+                                           "(CRFP_DCN_FUSED=0 restores it: conv_mfma:dcn.offset_mask + dcnv2_g8_c32); flops = conv + DCN GEMM + "
+                                           "bilinear; this kernel is bound by MFMA + VALU issue, which overlap only ~27 % on MI355X "
+                                           "(profiles/r02_mfma_valu_overlap_microtest.txt)"}
         gat = {n: f for n, f in fam.items() if n.startswith("flow_warp") or n.startswith("dcnv2")}
         if gat:
             gb = sum(f["bytes"] for f in gat.values()); gs = sum(f["ms"] for f in gat.values()) * 1e-3
@@ -300,7 +317,9 @@ def main():
                                                      "frac": f["bytes"] / (f["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                      "traffic": pmc_traffic(n, storage)} for n, f in gat.items()},
                                   "note": "dcn_3 priced at its compact 2+1 offset/mask channels, not the 9x-replicated API tensors; "
-                                          "bf16 storage: feature bytes halve, offsets / masks / flow stay fp32"}
+                                          "bf16 storage: feature bytes halve, offsets / masks / flow stay fp32"
+                                          + ("; dcn_g8 (dcn_0/1/2) runs inside the fused kernel reported under dcn_fused and is not "
+                                             "part of this figure" if fz else "")}
 
     extras = rank == 0 and world == 1 and not args.no_extras
     if extras and mode == "clip" and storage == "f32":

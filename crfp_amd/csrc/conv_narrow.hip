@@ -36,10 +36,17 @@ __device__ __forceinline__ float n_act(float v, int act) {
 #define CRFP_NARROW_KY_UNROLL 3
 #endif
 #ifndef CRFP_NARROW_OCC1
+#ifdef CRFP_ACT_BF16
+#define CRFP_NARROW_OCC1 5   // bf16 build (bf16-MFMA form): 9.5 KB of LDS per input quad, 100 / 140 / 160 VGPRs
+#else
 #define CRFP_NARROW_OCC1 4   // workgroups per CU (launch bound and persistent grid) for KQ = 1
+#endif
 #endif
 #ifndef CRFP_NARROW_OCC2
 #define CRFP_NARROW_OCC2 3   // ... for KQ = 2 (KQ = 3: 2, LDS-bound)
+#endif
+#ifndef CRFP_NARROW_OCC3
+#define CRFP_NARROW_OCC3 2   // (bf16 build: 3 fits at 160 VGPRs but measured slower, dcn3.block0 43.0 -> 45.6 us)
 #endif
 #ifndef CRFP_NARROW_MFMA
 #define CRFP_NARROW_MFMA 1
@@ -50,6 +57,15 @@ constexpr int NST = (NLH * NLW + 255) / 256;  // 5 halo elements per thread per 
 // raw halo element as it sits in the prefetch registers -> fp32 quad for the LDS tile
 #ifdef CRFP_ACT_BF16
 __device__ __forceinline__ cu32x2 raw_flow(const char* p) { return *reinterpret_cast<const cu32x2*>(p); }
+// fp32 (dx, dy) of a flow element -> bf16 quad (dx_hi, dy_hi, dx_lo, dy_lo): hi + lo carries 16 mantissa bits
+__device__ __forceinline__ cu32x2 flow_words(cu32x2 r) {
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    const cf32x2 fl = __builtin_bit_cast(cf32x2, r);
+    const b2_t hi = __builtin_convertvector(fl, b2_t);
+    const cf32x2 back = __builtin_convertvector(hi, cf32x2);
+    const b2_t lo = __builtin_convertvector(cf32x2{fl.x - back.x, fl.y - back.y}, b2_t);
+    return cu32x2{__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo)};
+}
 __device__ __forceinline__ f32x4 raw_to_quad(cu32x2 r, bool flow) {
     const cf32x2 fl = __builtin_bit_cast(cf32x2, r);   // whole-pair cast (see quad_words in conv_mfma.hip)
     return flow ? f32x4{fl.x, fl.y, 0.0f, 0.0f} : quad_from_bits(r);
@@ -74,11 +90,16 @@ __device__ __forceinline__ void narrow_src_index(int dst, float scale, int in_si
 }
 
 template <int KQ, int EPI>
-__global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_NARROW_OCC2 : 2)) void conv3x3_narrow_kernel(const NarrowArgs a) {
+__global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_NARROW_OCC2 : CRFP_NARROW_OCC3)) void conv3x3_narrow_kernel(const NarrowArgs a) {
+#ifdef CRFP_ACT_BF16
+    __shared__ cu32x2 tile[KQ][NLH][NLW];   // bf16 quads as they sit in HBM (8 bytes)
+#else
     __shared__ float4 tile[KQ][NLH][NLW];
     __shared__ float4 wl[9 * KQ * 4];  // FMA form: [tap][kq][cin comp] -> float4 over cout (broadcast reads)
                                        // MFMA form: [tap][kq][cout] -> float4 over cin comp (lane reads row cout = lane & 3)
+#endif
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+#ifndef CRFP_ACT_BF16
     if (tid < 9 * KQ * 4) {
         const float4 wv = reinterpret_cast<const float4*>(a.wpk)[tid];   // packed: (tap, kq, cin comp) -> 4 couts
         if (CRFP_NARROW_MFMA) {
@@ -88,6 +109,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
             wl[tid] = wv;
         }
     }
+#endif
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + NTW - 1) / NTW, ntiles = tiles_x * ((H + NTH - 1) / NTH);
@@ -106,6 +128,45 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         qbase[k] = qflow[k] ? reinterpret_cast<const char*>(src.p + (long long)n * src.bstride)
                             : reinterpret_cast<const char*>(as_act(src.p) + (long long)n * src.bstride + (long long)kql * (H + src.pad) * qpitch[k] * 4);
     }
+#ifdef CRFP_ACT_BF16
+    // bf16 storage: the channel mixing runs on v_mfma_f32_16x16x32_bf16 in a block-diagonal arrangement.  Lane l = 16 g + n
+    // supplies, as B column n / K group g, 8 bf16 of ITS OWN pixel (two taps x 4 channels, straight from the bf16 LDS tile);
+    // A row 4 g' + c carries the weights of cout c in K group g' only.  D row 4 g + c, column n -- the registers of lane
+    // 16 g + n -- is then the tap pair's contribution to the 4 couts of that lane's pixel: 64 pixels x 8 K x 4 couts per
+    // 16-cycle MFMA, 5 MFMAs per input quad and output row where the fp32 4x4x1 form issued 36 of 8 cycles (same products:
+    // bf16 activations x bf16 weights are exact in fp32; fp32 accumulate).  The A fragments (20 VGPRs per input quad) are
+    // built once per workgroup.  A flow source keeps fp32 accuracy as (dx_hi, dy_hi, dx_lo, dy_lo) against (w_dx, w_dy, w_dx, w_dy).
+    typedef __bf16 nb16x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 nb16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
+    nb16x8 aw[KQ][5];
+    {
+        const int lane = tid & 63, c = lane & 3;
+        const bool diag = (lane >> 4) == ((lane & 15) >> 2);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+                nu32x4 wds;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int tap = 2 * st + hf;
+                    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (tap < 9) {
+#pragma unroll
+                        for (int comp = 0; comp < 4; ++comp) {
+                            const int cc = qflow[k] ? (comp & 1) : comp;
+                            const float wv = a.wpk[((tap * KQ + k) * 4 + cc) * 4 + c];   // already a bf16 value (narrow_pack_kernel)
+                            v[comp] = diag ? wv : 0.0f;
+                        }
+                    }
+                    wds[2 * hf] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v[0], v[1]}, nb16x2));
+                    wds[2 * hf + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v[2], v[3]}, nb16x2));
+                }
+                aw[k][st] = __builtin_bit_cast(nb16x8, wds);
+            }
+    }
+#endif
     const float4 bias = *reinterpret_cast<const float4*>(a.bpk);
     const int cout = a.cout, act = a.act;
     // NONE / RELU / LRELU(0.1) as max(v, slope*v) with slope 1 / 0 / 0.1 (exact); tanh / sigmoid take the slow branch
@@ -174,7 +235,11 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
 #pragma unroll
             for (int t = 0; t < NST; ++t) {
                 const int idx = tid + 256 * t;
+#ifdef CRFP_ACT_BF16
+                if (idx < NLH * NLW) (&tile[k][0][0])[idx] = okr[t] ? (qflow[k] ? flow_words(r[k][t]) : r[k][t]) : cu32x2{0u, 0u};
+#else
                 if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[k][0][0])[idx] = okr[t] ? raw_to_quad(r[k][t], qflow[k]) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#endif
             }
         __syncthreads();
         const int t_next = t_cur + t_step;
@@ -183,6 +248,20 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{bias.x, bias.y, bias.z, bias.w};
+#ifdef CRFP_ACT_BF16
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int st = 0; st < 5; ++st) {
+                    const int t0 = 2 * st, t1 = 2 * st + 1;
+                    const cu32x2 q0 = tile[k][4 * ty + i + t0 / 3][tx + t0 % 3];
+                    const cu32x2 q1 = t1 < 9 ? tile[k][4 * ty + i + t1 / 3][tx + t1 % 3] : cu32x2{0u, 0u};
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[k][st], __builtin_bit_cast(nb16x8, nu32x4{q0.x, q0.y, q1.x, q1.y}),
+                                                                     acc[i], 0, 0, 0);
+                }
+#else
         // The k loop is deliberately NOT unrolled (hipcc otherwise hoists every quad's reads).  ky is: with the MFMA form
         // a quad needs 18 halo + 9 weight ds_read_b128 (27 instead of 45 when the rows shared by the ky are re-read) and
         // stays at 108 / 128 / 149 VGPRs for KQ = 1 / 2 / 3 (+0.7 % clip); the FMA form spilled when ky was unrolled.
@@ -224,6 +303,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                 }
             }
         }
+#endif
 
         const int tyi = t_cur / tiles_x, x = (t_cur - tyi * tiles_x) * NTW + tx, y0 = tyi * NTH;
         if (x < W) {
@@ -251,7 +331,11 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                     }
                     stq(dsta + dpix * 4, cf32x4{v[0], v[1], v[2], v[3]});
                 } else if (EPI == NE_BLEND) {
+#ifdef CRFP_ACT_BF16
+                    const cf32x4 centre = quad_from_bits(tile[0][4 * ty + i + 1][tx + 1]);
+#else
                     const float4 centre = tile[0][4 * ty + i + 1][tx + 1];
+#endif
                     const bool m = mask[pix] != 0;
                     float v[4] = {m ? acc[i][0] : centre.x, m ? acc[i][1] : centre.y, m ? acc[i][2] : centre.z,
                                   m ? acc[i][3] : centre.w};
@@ -598,7 +682,7 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
 #else
     constexpr int per_cu_env = 0;
 #endif
-    const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? CRFP_NARROW_OCC1 : (a.kq == 2 ? CRFP_NARROW_OCC2 : 2));
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? CRFP_NARROW_OCC1 : (a.kq == 2 ? CRFP_NARROW_OCC2 : CRFP_NARROW_OCC3));
     const int share = (ntl + 256 * per_cu - 1) / (256 * per_cu);
     dim3 grid((ntl + share - 1) / share, 1, a.N);
 #define CRFP_NARROW_LAUNCH(KQ_)                                                                    \

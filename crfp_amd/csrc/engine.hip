@@ -504,7 +504,9 @@ struct Runner {
     // encoder_hr 71.5 vs 67.6; conv_fuse->offset/mask 80 vs 76.8; dcn_3 block (3 input quads, one workgroup per CU) 126 vs 93.7.
     // The stencils are bound by 4x4x1-MFMA issue and LDS reads, not by HBM, and the fused form evaluates conv A on 1.16x the
     // pixels with 9 instead of 4.5 LDS reads per pixel and tap row -- so only the pair whose A has ONE input quad wins.
-    static constexpr int pair_mask() { return 4; }
+    // narrow conv pairs fused into one launch: res3.conv1 -> conv2(+x) wins in the fp32 build; in the bf16 build the
+    // single convs run on the bf16 MFMA and two of them beat the pair kernel (41 vs 47.5 us)
+    static constexpr int pair_mask() { return kActBf16 ? 0 : 4; }
 #define RUN(expr) do { if (!rc) rc = (expr); } while (0)
 
     // FNet over nb pairs (reference model/CRFP.py:797-814); cur/prev are NCHW 3-channel frames
