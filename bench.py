@@ -78,17 +78,18 @@ ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_mfma_kernel",
                  "hr_prep_up8_blend": ("hr_prep_kernel",), "offset_mask_conv+dcnv2_g8_fused": ("dcn_fused_kernel",)}
 
 
-def pmc_traffic(family: str, storage: str):
+def pmc_traffic(family: str, storage: str, lr=(180, 320)):
     """{"bytes_per_launch", "source", "measured_in_run": False} from the committed rocprofv3 PMC summary (2 x FETCH_SIZE +
     WRITE_SIZE per MI355X_MICROARCH.md, separate --pmc passes, tools/collect_profiles.sh) of the same workload; None when
     no summary exists for this storage mode.  It is a constant as far as this run is concerned -- hence the tag."""
     fname = "pmc_summary_latest.json" if storage == "f32" else "pmc_summary_latest_bf16.json"
     path = os.path.join(ROOT, "profiles", fname)
-    if not os.path.exists(path) or family not in ROCPROF_NAMES:
-        return None
+    if not os.path.exists(path) or family not in ROCPROF_NAMES or tuple(lr) != (180, 320):
+        return None   # the committed counter passes ran the 180x320 geometry; bytes per launch do not transfer to another one
     tot = calls = 0.0
     for r in json.load(open(path)):
-        if any(r["kernel"].startswith(n) for n in ROCPROF_NAMES[family]) and r.get("hbm_MB_per_launch_corrected") is not None:
+        kname = r["kernel"].split("::")[-1]   # crfp:: / crfp_bf16:: prefixes
+        if any(kname.startswith(n) for n in ROCPROF_NAMES[family]) and r.get("hbm_MB_per_launch_corrected") is not None:
             tot += r["hbm_MB_per_launch_corrected"] * 1e6 * r["calls"]
             calls += r["calls"]
     if not calls:
@@ -276,13 +277,13 @@ def main():
                         "dense fp16 / 3; see profiles/*_mfma_lds_util.txt for the MFMA / LDS pipe counters")
             result["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["TFLOPs"],
                                   "peak": peak, "unit": "TFLOP/s", "frac": dom["TFLOPs"] / peak,
-                                  "traffic": pmc_traffic(dom["kernel"], storage), "avg_launch_us": dom["avg_us"],
+                                  "traffic": pmc_traffic(dom["kernel"], storage, (h, w)), "avg_launch_us": dom["avg_us"],
                                   "algorithmic_flops_per_launch": domf["flops"] / domf["launches"],
                                   "frac_of_fp32_mfma_peak": dom["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
                                   "conv_scheme": scheme, "note": note}
         else:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"], storage),
+                                  "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"], storage, (h, w)),
                                   "avg_launch_us": dom["avg_us"],
                                   "algorithmic_bytes_per_launch": domf["bytes"] / domf["launches"]}
         fz = fam.get("offset_mask_conv+dcnv2_g8_fused")
@@ -296,7 +297,7 @@ def main():
                                    "avg_us": 1e3 * fz["ms"] / fz["launches"], "achieved": fz["flops"] / fs / 1e12, "peak": peak,
                                    "unit": "TFLOP/s", "frac": fz["flops"] / fs / 1e12 / peak,
                                    "algorithmic_GBps": fz["bytes"] / fs / 1e9,
-                                   "traffic": pmc_traffic("offset_mask_conv+dcnv2_g8_fused", storage),
+                                   "traffic": pmc_traffic("offset_mask_conv+dcnv2_g8_fused", storage, (h, w)),
                                    "hbm_bytes_not_moved_per_launch": 2.0 * px2 * 216 * 4,
                                    "note": "offset / mask head + dcn_g8 in one launch, bit-identical to the two-kernel path "
                                            "(CRFP_DCN_FUSED=0 restores it: conv_mfma:dcn.offset_mask + dcnv2_g8_c32); flops = conv + DCN GEMM + "
@@ -315,7 +316,7 @@ def main():
                                   "ms_per_step": 1e3 * gs / psteps,
                                   "per_kernel": {n: {"avg_us": 1e3 * f["ms"] / f["launches"], "GBps": f["bytes"] / (f["ms"] * 1e-3) / 1e9,
                                                      "frac": f["bytes"] / (f["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                     "traffic": pmc_traffic(n, storage)} for n, f in gat.items()},
+                                                     "traffic": pmc_traffic(n, storage, (h, w))} for n, f in gat.items()},
                                   "note": "dcn_3 priced at its compact 2+1 offset/mask channels, not the 9x-replicated API tensors; "
                                           "bf16 storage: feature bytes halve, offsets / masks / flow stay fp32"
                                           + ("; dcn_g8 (dcn_0/1/2) runs inside the fused kernel reported under dcn_fused and is not "
