@@ -203,6 +203,29 @@ def test_gaze_rig_masks_and_trajectory():
     assert int(m["outskirt"].sum()) > 0 and not bool((m["outskirt"] & m["mk"]).any())
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_gaze_rig_masks_match_the_reference_loop(tag):
+    """crfp_amd.gaze against masks produced by EXECUTING the reference's per-frame loop (test_video.py:303-375 through
+    tests/golden/make_gaze_golden.py): trajectory, window origin, mk / fovea / outskirt ring / three-frame past union / regional box,
+    with and without regional DCN and a late fovea start -- bit for bit."""
+    from crfp_amd import gaze
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gaze_masks.npz"))
+    kw = {k: g[f"{tag}_{k}"].item() for k in ("seed", "N", "H", "W", "fv_size", "sigma", "regional_dcn", "rg", "fv_start")}
+    N, H, W = kw["N"], kw["H"], kw["W"]
+    xs, ys = gaze.gaze_trajectory(N, H, W, kw["sigma"], np.random.RandomState(kw["seed"]))
+    masks = gaze.RegionMasks(H, W, kw["fv_size"], torch.device("cpu"), fv_start=kw["fv_start"], regional_dcn=bool(kw["regional_dcn"]),
+                             rg_h=kw["rg"], rg_w=kw["rg"])
+    unpack = lambda name, n: np.unpackbits(g[f"{tag}_{name}"][n], axis=-1)[:, :W].astype(bool)
+    for n in range(N):
+        cy, cx = gaze.window_origin(xs[n], ys[n], kw["fv_size"], H, W)
+        assert (cy, cx) == tuple(g[f"{tag}_cur"][n]), n
+        f = masks.frame(n, cy, cx)
+        for name in ("mk", "fovea", "outskirt", "fg"):
+            assert np.array_equal(f[name].reshape(H, W).numpy(), unpack(name, n)), (name, n)
+        past = np.zeros((H, W), bool) if f["past"] is None else f["past"].reshape(H, W).numpy()
+        assert np.array_equal(past, unpack("past", n)), ("past", n)
+
+
 def test_product_library_carries_no_lab_kernels():
     """The experiments that lose to the default conv main loop (pipelined / input-stationary / warp-specialised / bf16x6)
     and the s_memtime stamp code are compiled only into the lab library (`make lab`, -DCRFP_LAB)."""
