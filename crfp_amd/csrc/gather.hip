@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
 // flight under tile T+1's MFMAs.  Same arithmetic in the same order as conv3x3_split_kernel<1,1,2> + dcn_g8_pipe_kernel: the
 // results are bit-identical to the two-kernel path.  LDS 81 408 B (NW = 4, two workgroups per CU) / 117 248 B (NW = 8, shipped).
 constexpr int DF_LW = 34;
-constexpr int DF_WST = 9 * 2 * 64;                   // one (cout tile, chunk) stage of the fp16 pair image, 16-byte elements
+constexpr int DF_WCH = 9 * 2 * 64;                   // one (cout tile, chunk) of the fp16 pair image, 16-byte elements
 
 __device__ __forceinline__ void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -625,8 +625,10 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(const DcnFuseArgs a) {
     constexpr int NT = 64 * NW, DF_NEL = (NW + 2) * DF_LW;   // halo tile of an NW x 32-pixel workgroup
     constexpr int DF_NIN = (8 * DF_NEL + NT - 1) / NT;       // 16-byte tile elements per thread
-    constexpr int DF_NWS = (DF_WST + NT - 1) / NT;
     constexpr bool DB = NW == 8;
+    constexpr int CPS = DB ? 2 : 1;                          // chunks per weight stage: NW = 8 stages a whole cout tile (7 barriers per workgroup)
+    constexpr int DF_WST = CPS * DF_WCH, NSTG = 14 / CPS;
+    constexpr int DF_NWS = (DF_WST + NT - 1) / NT;
     __shared__ f32x4 tile[8][DF_NEL];   // [part * 4 + 8-channel group][halo pixel]: x0 planes, then x1s planes
     __shared__ f32x4 wst[DB ? 2 : 1][DF_WST];
     __shared__ f32x4 wl[36 * 64];
@@ -703,17 +705,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     // double buffer: one barrier (stage s complete in buffer s & 1 and everyone done with stage s - 1), then the registers
     // (stage s + 1) go to the other buffer and stage s + 2's loads leave
 #define DF_BEGIN(T, CH)                                                                                   \
-    {                                                                                                     \
-        constexpr int s_ = 2 * (T) + (CH);                                                                \
+    if (CPS == 2 && (CH) == 1) {                                                                          \
+        wcur = &wst[(T) & 1][DF_WCH];                                                                     \
+    } else {                                                                                              \
+        constexpr int s_ = (2 * (T) + (CH)) / CPS;                                                        \
         const bool first_ = s_ == 0;                                                                      \
         if (first_ || !(DF_PROBE & 4)) df_lds_barrier();                                                  \
         if (DB) {                                                                                         \
-            if (s_ + 1 < 14) { DF_WRITE((s_ + 1) & 1) }                                                   \
-            if (s_ + 2 < 14) { DF_WLOAD(s_ + 2) }                                                         \
+            if (s_ + 1 < NSTG) { DF_WRITE((s_ + 1) & 1) }                                                 \
+            if (s_ + 2 < NSTG) { DF_WLOAD(s_ + 2) }                                                       \
         } else {                                                                                          \
             if (first_ || !(DF_PROBE & 12)) { DF_WRITE(0) }                                               \
             if (first_ || !(DF_PROBE & 4)) df_lds_barrier();                                              \
-            if (s_ + 1 < 14 && !(DF_PROBE & 12)) { DF_WLOAD(s_ + 1) }                                     \
+            if (s_ + 1 < NSTG && !(DF_PROBE & 12)) { DF_WLOAD(s_ + 1) }                                   \
         }                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);   /* the next stage's loads leave before this stage's MFMAs */  \
         wcur = &wst[DB ? (s_ & 1) : 0][0];                                                                \
