@@ -632,6 +632,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     __shared__ f32x4 tile[8][DF_NEL];   // [part * 4 + 8-channel group][halo pixel]: x0 planes, then x1s planes
     __shared__ f32x4 wst[DB ? 2 : 1][DF_WST];
     __shared__ f32x4 wl[36 * 64];
+    __shared__ f32x4 bl[DB ? 56 : 1];   // the head's 224 packed biases (NW = 8: LDS has room; NW = 4 keeps them in 4 VGPRs)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * NW, n = blockIdx.z;
@@ -673,9 +674,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         (char*)const_cast<act_t*>(as_act(a.x) + (long long)n * a.xb) - guard, 0, 8 * plane_b + guard, 0x00020000);
     const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
     const int hbase = 4 * h * plane_b + guard;
-    float bv[4];
+    float bv[4];   // NW = 4: no LDS left for the bias table
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bv[k] = a.bconv[min(64 * k + lane, 223)];
+    for (int k = 0; k < 4; ++k) bv[k] = DB ? 0.0f : a.bconv[min(64 * k + lane, 223)];
+    if (DB && tid < 56) bl[tid] = reinterpret_cast<const f32x4*>(a.bconv)[tid];
 
     f32x16 acc, acl, ca, cl;
 #pragma unroll
@@ -740,7 +742,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     // round trip per cout tile and quad (28 per wave, a third of the kernel's fixed cost when measured), per-lane vector
     // loads would drain the gathers in flight
 #define DF_BIAS(T)                                                                                        \
-    {                                                                                                     \
+    if (DB) {   /* four ds_read_b128 of the lane half's quads (lgkmcnt: the gathers in flight are not waited for) */ \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+            const f32x4 bq = bl[(T) * 8 + 2 * q + h];                                                     \
+            ca[4 * q] = bq.x; ca[4 * q + 1] = bq.y; ca[4 * q + 2] = bq.z; ca[4 * q + 3] = bq.w;           \
+        }                                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) cl[e] = 0.0f;                                      \
+    } else {                                                                                              \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
             const int r0 = 32 * (T) + 8 * (e >> 2) + (e & 3), r1 = r0 + 4;                                \
             const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv[r0 >> 6]), r0 & 63)); \
@@ -781,8 +789,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     // INSIDE the two stages of tile T + 1, between its taps: the MFMA runs 32 clocks in its own pipe while the wave issues the
     // sampler's VALU work (coordinates, weights, bilinear FMAs, fp16 split: as many issue clocks per pixel as the MFMAs take),
     // and a pair's gathers fly under the MFMAs issued before its consumption.  Pair u lives in Q[u & 1]; I(u) follows C(u - 2).
-    DF_BIAS(0)
-    DF_BEGIN(0, 0) DF_TAPS(0, 0, 9)
+    DF_BEGIN(0, 0) DF_BIAS(0) DF_TAPS(0, 0, 9)   // (the bias table in LDS is complete behind the first barrier)
     DF_BEGIN(0, 1) DF_TAPS(1, 0, 9) DF_RAW(0)
     DF_BIAS(1)
     DF_BEGIN(1, 0) DF_TAPS(0, 0, 3) DF_TRANS(0) DF_SB DF_TAPS(0, 3, 6) DF_I(0, Q0) DF_SB DF_TAPS(0, 6, 9) DF_I(1, Q1) DF_SB
@@ -886,6 +893,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     __shared__ cu32x2 tile[4][DF_NEL][2];   // [8-channel group][halo pixel][quad of the pair]
     __shared__ f32x4 wst[DB ? 2 : 1][DF_WST];
     __shared__ f32x4 wl[36 * 64];
+    __shared__ f32x4 bl[DB ? 56 : 1];   // the head's 224 packed biases (NW = 8: LDS has room; NW = 4 keeps them in 4 VGPRs)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * NW, n = blockIdx.z;
@@ -931,7 +939,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     const int hbase = 4 * h * plane_b + guard;
     float bv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bv[k] = a.bconv[min(64 * k + lane, 223)];
+    for (int k = 0; k < 4; ++k) bv[k] = DB ? 0.0f : a.bconv[min(64 * k + lane, 223)];
+    if (DB && tid < 56) bl[tid] = reinterpret_cast<const f32x4*>(a.bconv)[tid];
 
     f32x16 acc, acl, ca;
 #pragma unroll
@@ -973,7 +982,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, ca, 0, 0, 0);                                \
     }
 #define DF_BIAS(T)                                                                                        \
-    {                                                                                                     \
+    if (DB) {                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+            const f32x4 bq = bl[(T) * 8 + 2 * q + h];                                                     \
+            ca[4 * q] = bq.x; ca[4 * q + 1] = bq.y; ca[4 * q + 2] = bq.z; ca[4 * q + 3] = bq.w;           \
+        }                                                                                                 \
+    } else {                                                                                              \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
             const int r0 = 32 * (T) + 8 * (e >> 2) + (e & 3), r1 = r0 + 4;                                \
             const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv[r0 >> 6]), r0 & 63)); \
@@ -1005,8 +1019,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #define DF_C(U, P) { dcn_consume_pair(P, acc, acl, wl, U, lane); }
     // cout tile T completes the sampling pairs up to (16 T + 10) / 6: 1, 4, 7, 9, 12, 15, 17; they are sampled inside tile T + 1.
     // Pair u lives in Q[u % 3]; I(u) follows C(u - 3).
-    DF_BIAS(0)
-    DF_BEGIN(0) DF_M(0, 18) DF_RAW(0)
+    DF_BEGIN(0) DF_BIAS(0) DF_M(0, 18) DF_RAW(0)   // (the bias table in LDS is complete behind the first barrier)
     DF_BIAS(1)
     DF_BEGIN(1) DF_M(0, 6) DF_TRANS(0) DF_SB DF_M(6, 12) DF_I(0, Q0) DF_SB DF_M(12, 18) DF_I(1, Q1) DF_SB DF_RAW(1)
     DF_BIAS(2)
