@@ -764,8 +764,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                  \
             const int sl = 16 * (T) + e;                                                                  \
             if (sl < 108) {                                                                               \
-                ca[e] += cl[e] * (1.0f / 2048.0f);                                                        \
-                ov[sl] = ca[e];                                                                           \
+                /* = ca + cl * 2^-11 as the two-kernel path forms it (the product is exact), in one instruction */ \
+                ov[sl] = __builtin_fmaf(cl[e], 1.0f / 2048.0f, ca[e]);                                    \
             }                                                                                             \
         }                                                                                                 \
     }
