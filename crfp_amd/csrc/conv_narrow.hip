@@ -191,6 +191,11 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
 #else
     typedef f32x4 rawq_t;
 #endif
+#ifdef CRFP_LAB
+    const int NPROBE = a.rsv;   // lab timing experiments (results wrong), bits: 1 = no MFMA loop, 2 = no stores, 4 = no global loads
+#else
+    constexpr int NPROBE = 0;
+#endif
     rawq_t r[KQ][NST];
     bool okr[NST];   // halo element of the tile held in r[] lies inside the image
     // Every load of a tile is issued before anything consumes it, UNCONDITIONALLY at clamped coordinates: a predicated
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
             cgy[t] = min(max(gy, 0), H - 1);                                                              \
             cgx[t] = min(max(gx, 0), W - 1);                                                              \
         }                                                                                                 \
+        if (!(NPROBE & 4))                                                                                \
         _Pragma("unroll") for (int k = 0; k < KQ; ++k) {                                                  \
             if (qflow[k]) {   /* wave-uniform */                                                          \
                 _Pragma("unroll") for (int t = 0; t < NST; ++t)                                           \
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         // a quad needs 18 halo + 9 weight ds_read_b128 (27 instead of 45 when the rows shared by the ky are re-read) and
         // stays at 108 / 128 / 149 VGPRs for KQ = 1 / 2 / 3 (+0.7 % clip); the FMA form spilled when ky was unrolled.
 #pragma unroll 1
-        for (int k = 0; k < KQ; ++k) {
+        for (int k = 0; k < ((NPROBE & 1) ? 0 : KQ); ++k) {
 #pragma unroll (CRFP_NARROW_KY_UNROLL)
             for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
 #endif
 
         const int tyi = t_cur / tiles_x, x = (t_cur - tyi * tiles_x) * NTW + tx, y0 = tyi * NTH;
-        if (x < W) {
+        if (x < W && !(NPROBE & 2)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int y = y0 + 4 * ty + i;
@@ -660,6 +666,8 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     static const char* stamp_name = getenv("CRFP_STAMP_NAME");
     static long long* stamp_ptr = getenv("CRFP_STAMP_PTR") ? (long long*)strtoull(getenv("CRFP_STAMP_PTR"), nullptr, 0) : nullptr;
     a.stamps = (stamp_ptr && stamp_name && !strcmp(stamp_name, name)) ? stamp_ptr : nullptr;
+    static const int nprobe = getenv("CRFP_NARROW_PROBE") ? atoi(getenv("CRFP_NARROW_PROBE")) : 0;
+    a.rsv = nprobe;
 #endif
     if (a.kq < 1 || a.kq > 3 || a.cout < 1 || a.cout > 4) {
         set_error("conv_narrow %s: unsupported kq=%d cout=%d", name, a.kq, a.cout);
