@@ -173,6 +173,120 @@ int crfp_conv3x3_f32(const float* x, const float* weight, const float* bias, flo
     return launch_conv_mfma(a, "conv_mfma:api_nchw", s);
 }
 
+// ---- the conv operator with everything SURVEY 8(b) lists for it: up to two inputs (a fused torch.cat), optional residual, activation,
+// load through pixel_unshuffle(4), store plain into a channel slice of a wider tensor or through pixel_shuffle(r).
+static ConvArgs api_conv_ex_plan(int cin, int cin2, int cout, int act, float post_scale, int unshuffle_r, int shuffle_r) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    int kq = 0;
+    a.nsrc = 0;
+    ConvSrc& s0 = a.src[a.nsrc++];
+    s0.kind = unshuffle_r == 4 ? SRC_UNSHUF4 : SRC_NCHW;
+    s0.nch = cin;
+    s0.nq = unshuffle_r == 4 ? 16 * ((cin / 16 + 3) / 4) : (cin + 3) / 4;   // SRC_UNSHUF4: 16 sub-positions per hi-res quad
+    s0.cbase = 0;
+    kq += s0.nq;
+    if (cin2 > 0) {
+        ConvSrc& s1 = a.src[a.nsrc++];
+        s1.kind = SRC_NCHW; s1.nch = cin2; s1.nq = (cin2 + 3) / 4; s1.cbase = cin;
+        kq += s1.nq;
+    }
+    if (kq & 1) {
+        ConvSrc& z = a.src[a.nsrc++];
+        z.kind = SRC_ZERO; z.nch = 1; z.nq = 1; z.cbase = cin + cin2;
+        kq += 1;
+    }
+    a.kq = kq;
+    a.cin_total = cin + cin2;
+    a.cout = cout;
+    a.store = shuffle_r > 1 ? ST_PS : ST_NCHW;
+    a.ps_r = shuffle_r > 1 ? shuffle_r : 0;
+    a.act = act;
+    a.post_scale = post_scale;
+    a.ctiles = (conv_packed_rows(cout, a.store, a.ps_r) + 31) / 32;
+    return a;
+}
+
+static bool conv_ex_args_ok(int cin, int cin2, int cout, int act, int unshuffle_r, int shuffle_r, bool has_resid) {
+    if (cin < 1 || cin2 < 0 || cout < 1) { set_error("conv3x3_ex: bad channel counts (%d, %d -> %d)", cin, cin2, cout); return false; }
+    if (act < CRFP_ACT_NONE || act > CRFP_ACT_SIGMOID) { set_error("conv3x3_ex: unknown activation %d", act); return false; }
+    if (unshuffle_r != 0 && unshuffle_r != 1 && unshuffle_r != 4) { set_error("conv3x3_ex: pixel_unshuffle load supports r = 4 (got %d)", unshuffle_r); return false; }
+    if (unshuffle_r == 4 && (cin2 > 0 || cin % 16)) { set_error("conv3x3_ex: pixel_unshuffle(4) load takes one input with cin %% 16 == 0"); return false; }
+    if (shuffle_r != 0 && shuffle_r != 1 && shuffle_r != 2 && shuffle_r != 4) { set_error("conv3x3_ex: pixel_shuffle store supports r in {2, 4} (got %d)", shuffle_r); return false; }
+    if (shuffle_r > 1 && (cout % (shuffle_r * shuffle_r) || has_resid || act == CRFP_ACT_TANH || act == CRFP_ACT_SIGMOID)) {
+        set_error("conv3x3_ex: pixel_shuffle store needs cout %% r^2 == 0, no residual, activation none / relu / lrelu");
+        return false;
+    }
+    return true;
+}
+
+size_t crfp_conv3x3_ex_workspace_bytes(int n, int cin, int cin2, int cout, int h, int w, int unshuffle_r, int shuffle_r, int has_residual) {
+    if (n < 1 || h < 1 || w < 1 || !conv_ex_args_ok(cin, cin2, cout, CRFP_ACT_NONE, unshuffle_r, shuffle_r, false)) return 0;
+    const ConvArgs a = api_conv_ex_plan(cin, cin2, cout, 0, 1.0f, unshuffle_r, shuffle_r);
+    size_t b = align_up(conv_packed_weight_floats(a) * sizeof(float), 256) + align_up((size_t)a.ctiles * 32 * sizeof(float), 256);
+    if (unshuffle_r == 4) b += q4_bytes(n, cin / 16, 4 * h, 4 * w);
+    if (has_residual) b += q4_bytes(n, cout, h, w);
+    if (shuffle_r > 1) b += q4_bytes(n, cout / (shuffle_r * shuffle_r), h * shuffle_r, w * shuffle_r);
+    return b;
+}
+
+/* x: [n, cin, h, w]  (unshuffle_r = 4: [n, cin / 16, 4h, 4w], read as pixel_unshuffle(x, 4));  x2: optional [n, cin2, h, w];
+ * weight [cout, cin + cin2, 3, 3];  residual: optional [n, cout, h, w], added after activation and post_scale;
+ * out: [n, out_ctotal, h, w], channels [out_c0, out_c0 + cout) written (shuffle_r > 1: [n, cout / r^2, h r, w r], whole). */
+int crfp_conv3x3_ex_f32(const float* x, int cin, const float* x2, int cin2, const float* weight, const float* bias, const float* residual,
+                        float* out, int n, int cout, int h, int w, int act, float post_scale, int unshuffle_r, int shuffle_r,
+                        int out_c0, int out_ctotal, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !weight || !out || n < 1 || h < 1 || w < 1 || (cin2 > 0 && !x2)) { set_error("conv3x3_ex: bad argument"); return CRFP_E_BADARG; }
+    if (!conv_ex_args_ok(cin, cin2, cout, act, unshuffle_r, shuffle_r, residual != nullptr)) return CRFP_E_UNSUPPORTED;
+    if (shuffle_r <= 1 && (out_c0 < 0 || out_ctotal < out_c0 + cout)) { set_error("conv3x3_ex: channel slice [%d, %d) outside %d channels", out_c0, out_c0 + cout, out_ctotal); return CRFP_E_BADARG; }
+    if (!workspace || workspace_bytes < crfp_conv3x3_ex_workspace_bytes(n, cin, cin2, cout, h, w, unshuffle_r, shuffle_r, residual != nullptr)) {
+        set_error("conv3x3_ex: workspace too small");
+        return CRFP_E_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ConvArgs a = api_conv_ex_plan(cin, cin2, cout, act, post_scale, unshuffle_r, shuffle_r);
+    char* p = (char*)workspace;
+    float* wpk = (float*)p; p += align_up(conv_packed_weight_floats(a) * sizeof(float), 256);
+    float* bpk = (float*)p; p += align_up((size_t)a.ctiles * 32 * sizeof(float), 256);
+    int rc = launch_conv_pack(a, weight, bias, nullptr, nullptr, cout, wpk, bpk, s);
+    if (rc) return rc;
+    if (unshuffle_r == 4) {   // the hi-res tensor as Q4, read through SRC_UNSHUF4
+        float* xq = (float*)p; p += q4_bytes(n, cin / 16, 4 * h, 4 * w);
+        rc = launch_nchw_to_q4(x, xq, n, cin / 16, 4 * h, 4 * w, 0, s);
+        if (rc) return rc;
+        a.src[0].p = xq;
+        a.src[0].bstride = (long long)((cin / 16 + 3) / 4) * (4 * h) * (4 * w) * 4;
+    } else {
+        a.src[0].p = x;
+        a.src[0].bstride = (long long)cin * h * w;
+    }
+    if (cin2 > 0) { a.src[1].p = x2; a.src[1].bstride = (long long)cin2 * h * w; }
+    if (residual) {
+        float* rq = (float*)p; p += q4_bytes(n, cout, h, w);
+        rc = launch_nchw_to_q4(residual, rq, n, cout, h, w, 0, s);
+        if (rc) return rc;
+        a.resid = rq;
+        a.resid_bstride = (long long)((cout + 3) / 4) * h * w * 4;
+    }
+    a.N = n; a.H = h; a.W = w;
+    a.wpk = wpk; a.bpk = bpk;
+    a.ndst = 1;
+    if (shuffle_r > 1) {
+        const int co = cout / (shuffle_r * shuffle_r), H2 = h * shuffle_r, W2 = w * shuffle_r;
+        float* oq = (float*)p;
+        a.dst[0].p = oq; a.dst[0].bstride = (long long)((co + 3) / 4) * H2 * W2 * 4; a.dst[0].q0 = 0; a.dst[0].q1 = (co + 3) / 4;
+        a.dstH = H2; a.dstW = W2;
+        rc = launch_conv_mfma(a, "conv_mfma:api_ex_ps", s);
+        if (!rc) rc = launch_q4_to_nchw(oq, out, n, co, H2, W2, 0, s);
+        return rc;
+    }
+    a.dst[0].p = out + (long long)out_c0 * h * w;
+    a.dst[0].bstride = (long long)out_ctotal * h * w;
+    a.dst[0].q0 = 0;
+    a.dst[0].q1 = (cout + 3) / 4;
+    return launch_conv_mfma(a, "conv_mfma:api_ex", s);
+}
+
 int crfp_upsample_bilinear_f32(const float* x, float* out, int n, int c, int h, int w, int oh, int ow, float scale_h,
                                float scale_w, float mul, void* stream) {
     if (!x || !out || n < 1 || c < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) { set_error("upsample: bad argument"); return CRFP_E_BADARG; }

@@ -134,6 +134,53 @@ def conv3x3(x, weight, bias=None, act="none", post_scale=1.0):
     return out
 
 
+def conv3x3_ex(x, weight, bias=None, x2=None, residual=None, act="none", post_scale=1.0, unshuffle=0, shuffle=0, out=None, out_c0=0):
+    """crfp_conv3x3_ex_f32: conv3x3(cat([x, x2], 1)) + bias -> activation -> * post_scale (+ residual), with the reference's layout steps
+    fused: ``unshuffle=4`` reads x [n, c, 4h, 4w] as pixel_unshuffle(x, 4) (model/CRFP.py:28-42), ``shuffle=r`` stores pixel_shuffle(., r)
+    (:184-193), ``out`` / ``out_c0`` write the result into channels [out_c0, out_c0 + cout) of an existing [n, C, h, w] tensor."""
+    x, weight = _dev(x, "x"), _dev(weight, "weight")
+    n = x.shape[0]
+    if unshuffle == 4:
+        cin, h, w = 16 * x.shape[1], x.shape[2] // 4, x.shape[3] // 4
+        assert x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0, "conv3x3_ex: pixel_unshuffle(4) needs H, W divisible by 4"
+    else:
+        cin, h, w = x.shape[1], x.shape[2], x.shape[3]
+    cin2 = 0
+    if x2 is not None:
+        x2 = _dev(x2, "x2")
+        cin2 = x2.shape[1]
+        assert tuple(x2.shape) == (n, cin2, h, w), "conv3x3_ex: x2 must match x in n, h, w"
+    cout = weight.shape[0]
+    assert tuple(weight.shape) == (cout, cin + cin2, 3, 3), "conv3x3_ex: weight must be [cout, cin + cin2, 3, 3]"
+    bias = torch.zeros(cout, dtype=torch.float32, device=x.device) if bias is None else _dev(bias, "bias")
+    if residual is not None:
+        residual = _dev(residual, "residual")
+        assert tuple(residual.shape) == (n, cout, h, w), "conv3x3_ex: residual must be [n, cout, h, w]"
+    r = int(shuffle) if shuffle and shuffle > 1 else 0
+    if r:
+        assert out is None, "conv3x3_ex: a pixel-shuffle store writes its own tensor"
+        out = torch.empty((n, cout // (r * r), h * r, w * r), dtype=torch.float32, device=x.device)
+        ctot = cout
+    elif out is None:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+        ctot = cout
+    else:
+        out = _dev(out, "out")
+        assert out.shape[0] == n and tuple(out.shape[2:]) == (h, w), "conv3x3_ex: out must be [n, C, h, w]"
+        ctot = out.shape[1]
+    L = _lib.lib()
+    with _on(x, weight, bias):
+        nb = L.crfp_conv3x3_ex_workspace_bytes(n, cin, cin2, cout, h, w, int(unshuffle), r, int(residual is not None))
+        if nb == 0:
+            _lib.check(-3, "crfp_conv3x3_ex_workspace_bytes")
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        _lib.check(L.crfp_conv3x3_ex_f32(x.data_ptr(), cin, x2.data_ptr() if x2 is not None else None, cin2, weight.data_ptr(), bias.data_ptr(),
+                                         residual.data_ptr() if residual is not None else None, out.data_ptr(), n, cout, h, w, ACT[act],
+                                         float(post_scale), int(unshuffle), r, int(out_c0), int(ctot), ws.data_ptr(), nb, _stream()),
+                   "crfp_conv3x3_ex_f32")
+    return out
+
+
 def conv3x3_unpacked(x, weight, bias, act="none", post_scale=1.0):
     """The one-call form (crfp_conv3x3_f32: repacks the weights inside the call) -- what a caller without a cache pays."""
     x, weight, bias = _dev(x, "x"), _dev(weight, "weight"), _dev(bias, "bias")

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define CRFP_VERSION 200 /* major*10000 + minor*100 + patch */
+#define CRFP_VERSION 201 /* major*10000 + minor*100 + patch */
 
 /* error codes (negative) */
 #define CRFP_E_BADARG (-1)      /* null pointer / non-positive size / unsupported combination */
@@ -87,6 +87,16 @@ size_t crfp_conv3x3_workspace_bytes(int n, int cin, int cout, int h, int w);
 int crfp_conv3x3_f32(const float* x, const float* weight, const float* bias, float* out, int n, int cin,
                      int cout, int h, int w, int act, float post_scale, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* ---- the conv operator in full: up to two inputs (= conv(torch.cat([x, x2], 1)), e.g. model/CRFP.py:331,1589), optional
+ * residual added after activation (model/CRFP.py:48-50 ResidualBlockNoBN), load through pixel_unshuffle(4) (PixelUnShufflePack_v2,
+ * model/CRFP.py:28-42: x is [n, cin/16, 4h, 4w]), store into the channel slice [out_c0, out_c0 + cout) of an [n, out_ctotal, h, w]
+ * tensor (a fused torch.cat on the output side) or through pixel_shuffle(r), r in {2, 4} (PixelShufflePack, model/CRFP.py:184-193:
+ * out is [n, cout/r^2, h r, w r]; no residual, activation none / relu / lrelu).  Pass 0 / 1 for "no shuffle".  fp32 MFMA. */
+size_t crfp_conv3x3_ex_workspace_bytes(int n, int cin, int cin2, int cout, int h, int w, int unshuffle_r, int shuffle_r, int has_residual);
+int crfp_conv3x3_ex_f32(const float* x, int cin, const float* x2, int cin2, const float* weight, const float* bias, const float* residual,
+                        float* out, int n, int cout, int h, int w, int act, float post_scale, int unshuffle_r, int shuffle_r,
+                        int out_c0, int out_ctotal, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same two operators with the weight repack hoisted out of the call (pack once per weight update):
  *   crfp_conv3x3_pack_f32 -> crfp_conv3x3_packed_f32           (any cin / cout)

@@ -42,7 +42,7 @@ def _nograd():
 
 def test_library_loaded_and_version():
     from crfp_amd import _lib
-    assert _lib.lib().crfp_version() == 200
+    assert _lib.lib().crfp_version() == 201
     assert os.path.exists(_lib.LIB_PATH)
 
 

@@ -325,3 +325,50 @@ def test_packed_operator_variants_and_cache_invalidation(orc):
     assert maxdiff(d1, orc.dcnv2(x.cpu(), off.cpu(), msk.cpu(), w.cpu(), b.cpu(), 8)) < 5e-5
     w.zero_()
     assert maxdiff(ops.dcnv2(x, off, msk, w, b, 3, 1, 1, 8), b.cpu().view(1, 32, 1, 1).expand(1, 32, 20, 36)) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["cat_resid", "slice", "shuffle2", "shuffle4", "unshuffle4"])
+def test_conv3x3_ex_operator_vs_torch(case):
+    """crfp_conv3x3_ex_f32 (the conv operator with everything SURVEY 8b lists: two inputs = fused cat, residual, channel-slice store,
+    pixel_shuffle store, pixel_unshuffle load) against the ATen ops the reference composes (model/CRFP.py:28-50,184-193)."""
+    from crfp_amd import ops
+    g = torch.Generator().manual_seed(5)
+    d = dev()
+    R = lambda *s: (torch.rand(*s, generator=g) - 0.5)
+    n, h, w = 2, 19, 37
+    if case == "cat_resid":
+        x, x2 = R(n, 24, h, w), R(n, 10, h, w)
+        wt, b, res = R(20, 34, 3, 3) * 0.2, R(20), R(n, 20, h, w)
+        ref = F.leaky_relu(F.conv2d(torch.cat([x, x2], 1), wt, b, padding=1), 0.1) * 0.5 + res
+        got = ops.conv3x3_ex(x.to(d), wt.to(d), b.to(d), x2=x2.to(d), residual=res.to(d), act="lrelu", post_scale=0.5)
+    elif case == "slice":
+        x = R(n, 12, h, w)
+        wt, b = R(6, 12, 3, 3) * 0.2, R(6)
+        base = R(n, 16, h, w)
+        ref = base.clone(); ref[:, 5:11] = F.relu(F.conv2d(x, wt, b, padding=1))
+        got = ops.conv3x3_ex(x.to(d), wt.to(d), b.to(d), act="relu", out=base.to(d).clone(), out_c0=5)
+    elif case in ("shuffle2", "shuffle4"):
+        r = int(case[-1])
+        x = R(n, 16, h, w)
+        wt, b = R(3 * r * r, 16, 3, 3) * 0.2, R(3 * r * r)
+        ref = F.pixel_shuffle(F.conv2d(x, wt, b, padding=1), r)
+        got = ops.conv3x3_ex(x.to(d), wt.to(d), b.to(d), shuffle=r)
+    else:
+        x = R(n, 2, 4 * h, 4 * w)
+        wt, b = R(9, 32, 3, 3) * 0.2, R(9)
+        ref = F.conv2d(F.pixel_unshuffle(x, 4), wt, b, padding=1)
+        got = ops.conv3x3_ex(x.to(d), wt.to(d), b.to(d), unshuffle=4)
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert maxdiff(got, ref) < 3e-5
+
+
+def test_conv3x3_ex_rejects_unsupported_combinations():
+    from crfp_amd import ops
+    d = dev()
+    x = torch.zeros(1, 8, 8, 8, device=d)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_ex(x, torch.zeros(6, 8, 3, 3, device=d), shuffle=2)                 # cout not a multiple of r^2
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_ex(x, torch.zeros(8, 8, 3, 3, device=d), shuffle=2, act="tanh")    # transcendental activation with a shuffle store
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_ex(x, torch.zeros(8, 8, 3, 3, device=d), unshuffle=3)               # only r = 4

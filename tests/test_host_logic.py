@@ -44,7 +44,7 @@ def test_binding_table_covers_header():
 
 def test_version_and_param_table(lib):
     from crfp_amd import engine
-    assert lib.crfp_version() == 200
+    assert lib.crfp_version() == 201
     names = engine.param_names()
     assert names == synth.state_dict_keys()
     sd = synth.make_state_dict(1)
