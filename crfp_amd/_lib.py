@@ -29,6 +29,8 @@ SIGNATURES = {
     "crfp_flow_warp_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_dcnv2_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "crfp_dcnv2_forward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 9 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_dcnv2_shared_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "crfp_dcnv2_shared_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_conv3x3_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "crfp_conv3x3_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_conv3x3_ex_workspace_bytes": (C.c_size_t, [C.c_int] * 9),

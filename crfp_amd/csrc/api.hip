@@ -11,6 +11,14 @@ static size_t p4_bytes(int n, int c, int h, int w) {
     return p4_guard(w) + align_up((size_t)n * ((c + 3) / 4) * (h + 1) * (w + 1) * 16, 256);
 }
 
+// offset [n,2,h,w] + mask [n,1,h,w] -> the compact quad (dy, dx, mask, 0) dcn3_kernel reads
+__global__ void offmask3_pack_kernel(const float* __restrict__ offset, const float* __restrict__ mask, float* __restrict__ out, long long hw, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long n = i / hw, p = i - n * hw;
+    reinterpret_cast<float4*>(out)[i] = make_float4(offset[(2 * n) * hw + p], offset[(2 * n + 1) * hw + p], mask[n * hw + p], 0.0f);
+}
+
 extern "C" {
 
 size_t crfp_flow_warp_workspace_bytes(int n, int c, int h, int w) { return 2 * q4_bytes(n, c, h, w); }
@@ -60,6 +68,36 @@ int crfp_dcnv2_forward_f32(const float* x, const float* offset, const float* mas
         return rc;
     }
     return launch_dcn_generic(x, offset, mask, weight, bias, out, n, cin, cout, h, w, dg, s);
+}
+
+// ---- DCNv2 4 -> 4, one deformable group, ONE (dy, dx) and ONE mask per pixel shared by the 9 taps (the
+// `offset_mask_shared_across_taps` form).  The reference builds this by tiling the 2 + 1 channels 9x before the DCNv2 call
+// (model/CRFP.py:341-347); here they stay compact: offset [n,2,h,w], mask [n,1,h,w].
+size_t crfp_dcnv2_shared_workspace_bytes(int n, int c, int h, int w) {
+    if (n < 1 || c != 4 || h < 1 || w < 1) return 0;
+    return p4_bytes(n, 4, h, w) + 2 * q4_bytes(n, 4, h, w);
+}
+
+int crfp_dcnv2_shared_f32(const float* x, const float* offset, const float* mask, const float* weight, const float* bias, float* out,
+                          int n, int cin, int cout, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !offset || !mask || !weight || !bias || !out || n < 1 || h < 1 || w < 1) { set_error("dcnv2_shared: bad argument"); return CRFP_E_BADARG; }
+    if (cin != 4 || cout != 4) { set_error("dcnv2_shared: the shared-offset form is built for 4 -> 4 channels (got %d -> %d)", cin, cout); return CRFP_E_UNSUPPORTED; }
+    if (!workspace || workspace_bytes < crfp_dcnv2_shared_workspace_bytes(n, 4, h, w)) { set_error("dcnv2_shared: workspace too small"); return CRFP_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    float* xq = (float*)(p + p4_guard(w)); p += p4_bytes(n, 4, h, w);   // P4: padded plane, guard + pads zero
+    float* om = (float*)p; p += q4_bytes(n, 4, h, w);
+    float* oq = (float*)p;
+    if (hipMemsetAsync((char*)xq - p4_guard(w), 0, p4_bytes(n, 4, h, w), s) != hipSuccess) { set_error("dcnv2_shared: memset failed"); return 1; }
+    int rc = launch_nchw_to_q4(x, xq, n, 4, h, w, 1, s);
+    if (!rc) {   // quad = (dy, dx, mask, 0)
+        const long long hw = (long long)h * w, total = hw * n;
+        offmask3_pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(offset, mask, om, hw, total);
+        if (hipGetLastError() != hipSuccess) { set_error("dcnv2_shared: pack launch failed"); rc = 1; }
+    }
+    if (!rc) rc = launch_dcn3(xq, (long long)(h + 1) * (w + 1) * 4, om, (long long)h * w * 4, weight, bias, oq, (long long)h * w * 4, n, h, w, s);
+    if (!rc) rc = launch_q4_to_nchw(oq, out, n, 4, h, w, 0, s);
+    return rc;
 }
 
 // (cin = cout = 32, dg = 8) with the weights packed once: crfp_dcnv2_g8_pack_f32 -> crfp_dcnv2_g8_packed_f32

@@ -115,6 +115,23 @@ def dcnv2(x, offset, mask, weight, bias, kernel_size=3, padding=1, dilation=1, d
     return out
 
 
+def dcnv2_shared(x, offset, mask, weight, bias):
+    """DCNv2 (4 -> 4 channels, one group) with one (dy, dx) [n,2,h,w] and one mask [n,1,h,w] per pixel shared by the 9 taps: equal to
+    ``dcnv2(x, offset.repeat(1, 9, 1, 1), mask.repeat(1, 9, 1, 1), ...)`` (reference model/CRFP.py:341-350) without the tiled tensors."""
+    x, offset, mask, weight, bias = _dev(x, "input"), _dev(offset, "offset"), _dev(mask, "mask"), _dev(weight, "weight"), _dev(bias, "bias")
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    assert tuple(offset.shape) == (n, 2, h, w) and tuple(mask.shape) == (n, 1, h, w), "dcnv2_shared: offset [n,2,h,w], mask [n,1,h,w]"
+    L = _lib.lib()
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    with _on(x, offset, mask, weight, bias):
+        nb = L.crfp_dcnv2_shared_workspace_bytes(n, cin, h, w)
+        ws = _ws(max(nb, 256), x.device)
+        _lib.check(L.crfp_dcnv2_shared_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                           n, cin, cout, h, w, ws.data_ptr(), ws.numel(), _stream()), "crfp_dcnv2_shared_f32")
+    return out
+
+
 def conv3x3(x, weight, bias=None, act="none", post_scale=1.0):
     """3x3 stride-1 pad-1 convolution + bias + activation on the fp32 MFMA path."""
     x, weight = _dev(x, "x"), _dev(weight, "weight")

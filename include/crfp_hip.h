@@ -82,6 +82,13 @@ int crfp_dcnv2_forward_f32(const float* x, const float* offset, const float* mas
                            const float* bias, float* out, int n, int cin, int cout, int h, int w, int k,
                            int pad, int dil, int dg, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- DCNv2 with ONE (dy, dx) and ONE mask per pixel shared by the 9 taps (cin = cout = 4, deformable_groups = 1): what
+ * DCN_module(repeat=True) computes after tiling its 2 + 1 channels 9x (model/CRFP.py:341-347,350); the tiled tensors never exist.
+ * offset [n,2,h,w] = (dy, dx), mask [n,1,h,w]. */
+size_t crfp_dcnv2_shared_workspace_bytes(int n, int c, int h, int w);
+int crfp_dcnv2_shared_f32(const float* x, const float* offset, const float* mask, const float* weight, const float* bias, float* out,
+                          int n, int cin, int cout, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- 3x3 stride-1 pad-1 convolution, NCHW f32, fused bias + activation (fp32 MFMA). */
 size_t crfp_conv3x3_workspace_bytes(int n, int cin, int cout, int h, int w);
 int crfp_conv3x3_f32(const float* x, const float* weight, const float* bias, float* out, int n, int cin,

@@ -372,3 +372,25 @@ def test_conv3x3_ex_rejects_unsupported_combinations():
         ops.conv3x3_ex(x, torch.zeros(8, 8, 3, 3, device=d), shuffle=2, act="tanh")    # transcendental activation with a shuffle store
     with pytest.raises(RuntimeError):
         ops.conv3x3_ex(x, torch.zeros(8, 8, 3, 3, device=d), unshuffle=3)               # only r = 4
+
+
+def test_dcnv2_shared_offsets_operator(orc):
+    """crfp_dcnv2_shared_f32 (one (dy, dx) and mask per pixel for all 9 taps, SURVEY 8b's offset_mask_shared_across_taps) equals the
+    general DCNv2 on the 9x-tiled tensors the reference builds (model/CRFP.py:341-350): against the oracle and against our own
+    general operator."""
+    from crfp_amd import ops
+    g = torch.Generator().manual_seed(9)
+    n, h, w = 2, 21, 45
+    x = torch.rand(n, 4, h, w, generator=g) - 0.5
+    off = (torch.rand(n, 2, h, w, generator=g) - 0.5) * 9.0
+    mk = torch.rand(n, 1, h, w, generator=g)
+    wt = (torch.rand(4, 4, 3, 3, generator=g) - 0.5) * 0.5
+    b = torch.rand(4, generator=g) - 0.5
+    ref = orc.dcnv2(x, off.repeat(1, 9, 1, 1), mk.repeat(1, 9, 1, 1), wt, b, 1)
+    d = dev()
+    got = ops.dcnv2_shared(x.to(d), off.to(d), mk.to(d), wt.to(d), b.to(d))
+    gen = ops.dcnv2(x.to(d), off.repeat(1, 9, 1, 1).to(d), mk.repeat(1, 9, 1, 1).to(d), wt.to(d), b.to(d), deformable_groups=1)
+    assert maxdiff(got, ref) < 3e-5 and maxdiff(gen, ref) < 3e-5
+    with pytest.raises(RuntimeError):
+        ops.dcnv2_shared(torch.zeros(1, 8, 8, 8, device=d), torch.zeros(1, 2, 8, 8, device=d), torch.zeros(1, 1, 8, 8, device=d),
+                         torch.zeros(8, 8, 3, 3, device=d), torch.zeros(8, device=d))
