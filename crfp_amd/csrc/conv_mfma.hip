@@ -1160,6 +1160,136 @@ __global__ __launch_bounds__(256, RPW == 1 ? 4 : 3) void conv3x3_bf16_kernel(con
     const EpiCtx ec = epi_ctx(a, n);
     conv_epilogue<CT, PT, RPW, 2>(ec, acc, T0, tx0, ty0, wave, j, h);
 }
+
+// ---------------------------------------------------------------- bf16 storage, 8 waves, two chunks per stage
+// The 32-cout layers (one cout tile): workgroup = 8 rows x 64 pixels (wave = one row, two 32-pixel tiles), 450 workgroups for a
+// 360 x 640 map = one round at two per CU, and 32 input channels (two 16-channel chunks: tile 42 KB + weights 18 KB) per barrier
+// pair -- a 32 -> 32 conv has ONE staging phase instead of two, a 64 -> 32 conv two instead of four.  Same K order, same
+// accumulate order per accumulator (chunk-major, taps inside) and the same epilogue as conv3x3_bf16_kernel: identical values.
+constexpr int B8_NT = 512, B8_TH = 8, B8_LH = B8_TH + 2, B8_NEL = B8_LH * LW, B8_NIN = (B8_NEL + B8_NT - 1) / B8_NT;
+constexpr int B8_WPC = 9 * 64, B8_NWS = (2 * B8_WPC + B8_NT - 1) / B8_NT;
+
+__global__ __launch_bounds__(B8_NT, 2) void conv3x3_bf16x8_kernel(const ConvArgs a) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ u32x4_t tile[2][2][B8_NEL];       // [chunk of the stage][quad pair][halo pixel]: 8 bf16 = 16 B      42.2 KB
+    __shared__ bf16x8 wlds[2 * B8_WPC];          // [chunk][tap][lane]                                             18.4 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int btile = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * B8_TH;
+    const int T0 = 0;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+
+    int cgy[B8_NIN], cgx[B8_NIN];
+    bool sval[B8_NIN];
+#pragma unroll
+    for (int t = 0; t < B8_NIN; ++t) {
+        const int idx = min(tid + B8_NT * t, B8_NEL - 1);
+        const int r = idx / LW, c = idx - r * LW;
+        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+        sval[t] = tid + B8_NT * t < B8_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        cgy[t] = min(max(gy, 0), H - 1);
+        cgx[t] = min(max(gx, 0), W - 1);
+    }
+
+    f32x16 acc[1][2];
+    {   // accumulators start at the bias
+        const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bq = bp[T0 * 8 + 2 * g + h];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                acc[0][pt][4 * g + 0] = bq.x; acc[0][pt][4 * g + 1] = bq.y;
+                acc[0][pt][4 * g + 2] = bq.z; acc[0][pt][4 * g + 3] = bq.w;
+            }
+        }
+    }
+
+    const int nchunks = a.kq >> 2, nstages = (nchunks + 1) >> 1;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit16);
+    cu32x2 rq[2][4][B8_NIN];   // [chunk of the stage][quad][halo slot]
+    int qm[2][4];
+    bf16x8 rws[B8_NWS];
+    // loads of stage ST: its one or two chunks' quads (per-quad descriptors) and weight fragments (consecutive in the packed image)
+#define CRFP_B8_ISSUE(ST)                                                                                 \
+    {                                                                                                     \
+        _Pragma("unroll") for (int c2 = 0; c2 < 2; ++c2) {                                                \
+            const int ch_ = min(2 * (ST) + c2, nchunks - 1);                                              \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
+                const QuadDesc d_ = a.qd[4 * ch_ + q];                                                    \
+                const float* qb_ = d_.base + (long long)n * d_.bstride;                                   \
+                qm[c2][q] = d_.mask;                                                                      \
+                _Pragma("unroll") for (int t = 0; t < B8_NIN; ++t)                                        \
+                    rq[c2][q][t] = *reinterpret_cast<const cu32x2*>(qb_ + cgy[t] * d_.rs + cgx[t] * d_.cs); \
+            }                                                                                             \
+        }                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < B8_NWS; ++k) {                                              \
+            const int idx = min(tid + B8_NT * k, 2 * B8_WPC - 1);                                         \
+            const int ch_ = min(2 * (ST) + idx / B8_WPC, nchunks - 1);                                    \
+            rws[k] = wp[((long long)T0 * nchunks + ch_) * B8_WPC + (idx % B8_WPC)];                       \
+        }                                                                                                 \
+    }
+
+    CRFP_B8_ISSUE(0)
+    for (int st = 0; st < nstages; ++st) {
+        const bool two = 2 * st + 1 < nchunks;   // the last stage of an odd chunk count holds one chunk
+        __syncthreads();
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int m0 = qm[c2][0], m1 = qm[c2][1], m2 = qm[c2][2], m3 = qm[c2][3];
+            if ((m0 & m1 & m2 & m3) == 15 && !((m0 | m1 | m2 | m3) & 32)) {
+#pragma unroll
+                for (int t = 0; t < B8_NIN; ++t) {
+                    const int idx = tid + B8_NT * t;
+                    if (idx < B8_NEL) {
+                        const unsigned km = sval[t] ? 0xffffffffu : 0u;
+                        tile[c2][0][idx] = u32x4_t{rq[c2][0][t].x & km, rq[c2][0][t].y & km, rq[c2][1][t].x & km, rq[c2][1][t].y & km};
+                        tile[c2][1][idx] = u32x4_t{rq[c2][2][t].x & km, rq[c2][2][t].y & km, rq[c2][3][t].x & km, rq[c2][3][t].y & km};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < B8_NIN; ++t) {
+                    const int idx = tid + B8_NT * t;
+                    if (idx < B8_NEL) {
+                        const cu32x2 w0 = quad_words(rq[c2][0][t], m0, sval[t]), w1 = quad_words(rq[c2][1][t], m1, sval[t]);
+                        const cu32x2 w2 = quad_words(rq[c2][2][t], m2, sval[t]), w3 = quad_words(rq[c2][3][t], m3, sval[t]);
+                        tile[c2][0][idx] = u32x4_t{w0.x, w0.y, w1.x, w1.y};
+                        tile[c2][1][idx] = u32x4_t{w2.x, w2.y, w3.x, w3.y};
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < B8_NWS; ++k) {
+            const int idx = tid + B8_NT * k;
+            if (idx < 2 * B8_WPC) wlds[idx] = rws[k];
+        }
+        __syncthreads();
+        if (st + 1 < nstages) CRFP_B8_ISSUE(st + 1)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            if (c2 == 1 && !two) break;   // workgroup-uniform
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const bf16x8 wa = wlds[c2 * B8_WPC + tap * 64 + lane];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int pix = (wave + ky) * LW + pt * 32 + j + kx;
+                    const bf16x8 bq = __builtin_bit_cast(bf16x8, tile[c2][h][pix]);
+                    acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bq, acc[0][pt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef CRFP_B8_ISSUE
+    const EpiCtx ec = epi_ctx(a, n);
+    conv_epilogue<1, 2, 1, 2>(ec, acc, T0, tx0, ty0, wave, j, h);
+}
 #endif  // CRFP_ACT_BF16
 
 #ifdef CRFP_LAB   // experiments that lose to conv3x3_split_kernel<1,1,2>: built only into the lab library (make lab)
@@ -2032,7 +2162,14 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // (8-row tiles, conv3x3_bf16_kernel<2>: 1.25 instead of 1.5 ds_read_b128 per MFMA and half the weight staging, but 450
         // workgroups on 256 CUs -- measured neutral to -8 % per conv, so 4-row tiles stay.  A register prefetch two chunks deep
         // (126 VGPRs, still 4 workgroups per CU) was also slower: 32->32 conv 15.2 -> 16.3 us, offset / mask head 70.8 -> 74.0.)
-        conv3x3_bf16_kernel<1><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
+        // 8-wave kernel, two chunks per staging phase, for the 32-cout layers with an even chunk count: same-box 32 -> 32 convs 16.0 ->
+        // 15.1 us, conv2(+x) 17.7 -> 17.0, conv_fuse 22.2 -> 21.6, identical values; block0 (5 chunks: a half-empty last stage) 25.4 -> 26.0,
+        // so odd chunk counts keep the 4-wave kernel
+        if (a.ctiles == 1 && ((a.kq >> 2) & 1) == 0) {
+            const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH);
+            conv3x3_bf16x8_kernel<<<dim3(tiles8, 1, a.N), B8_NT, 0, s>>>(am);
+        } else
+            conv3x3_bf16_kernel<1><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
 #else
         // 8-wave single-accumulator kernel for the convs with one cout tile (the 32-cout layers: one round of 450 workgroups
         // instead of 1.17 rounds of 900; same-box: conv1 26.4 -> 24.6 us, conv2 28.7 -> 26.1, block0 46.0 -> 43.2, main0 40.0 ->
