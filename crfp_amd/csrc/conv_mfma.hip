@@ -1176,9 +1176,11 @@ __global__ __launch_bounds__(B8_NT, 2) void conv3x3_bf16x8_kernel(const ConvArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
-    const int btile = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int ngrp = a.ctiles;
+    const int bwork = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int btile = bwork / ngrp;
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * B8_TH;
-    const int T0 = 0;
+    const int T0 = bwork - btile * ngrp;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
 
@@ -2165,9 +2167,10 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // 8-wave kernel, two chunks per staging phase, for the 32-cout layers with an even chunk count: same-box 32 -> 32 convs 16.0 ->
         // 15.1 us, conv2(+x) 17.7 -> 17.0, conv_fuse 22.2 -> 21.6, identical values; block0 (5 chunks: a half-empty last stage) 25.4 -> 26.0,
         // so odd chunk counts keep the 4-wave kernel
+        // (for layers with several cout tiles it loses: FNet dec2a 36 -> 43 us, enc3b 22 -> 26, the pixel-shuffle heads +0..1 us)
         if (a.ctiles == 1 && ((a.kq >> 2) & 1) == 0) {
             const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH);
-            conv3x3_bf16x8_kernel<<<dim3(tiles8, 1, a.N), B8_NT, 0, s>>>(am);
+            conv3x3_bf16x8_kernel<<<dim3(tiles8 * a.ctiles, 1, a.N), B8_NT, 0, s>>>(am);
         } else
             conv3x3_bf16_kernel<1><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
 #else
