@@ -72,7 +72,7 @@ def kernel_family(name: str) -> str:
 # hipEvent launch-site family -> rocprofv3 kernel names (for the PMC traffic lookup)
 ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_mfma_kernel", "conv3x3_bf16_kernel"),
                  "conv3x3_narrow": ("conv3x3_narrow_kernel",),
-                 "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel",),
+                 "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel<false>", "dcn3_kernel"), "dcnv2_shared_c4_fused": ("dcn3_kernel<true>",),
                  "flow_warp_q4_c4": ("flow_warp_p4_kernel",), "flow_warp_q4_c32": ("flow_warp_p4_kernel",),
                  "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "flow_warp_q4_c32+c24": ("flow_warp_p4_dual_kernel",),
                  "hr_prep_up8_blend": ("hr_prep_kernel",), "offset_mask_conv+dcnv2_g8_fused": ("dcn_fused_kernel",)}
@@ -308,7 +308,7 @@ def main():
             gb = sum(f["bytes"] for f in gat.values()); gs = sum(f["ms"] for f in gat.values()) * 1e-3
             # dcn_3 through the API moves 18 offset + 9 mask channels (the reference tiles 2+1 channels 9x); the kernel
             # reads the compact 2+1: SURVEY 8(d) asks for both figures
-            d3 = fam.get("dcnv2_shared_c4")
+            d3 = fam.get("dcnv2_shared_c4") or fam.get("dcnv2_shared_c4_fused")
             gb_api = gb + (d3["launches"] * (8 * h) * (8 * w) * 24 * 4.0 if d3 else 0.0)
             result["warp_dcn"] = {"bound": "hbm", "achieved": gb / gs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": gb / gs / 1e9 / HBM_PEAK_GBS, "frac_of_copy_ceiling": gb / gs / 1e9 / HBM_COPY_CEILING_GBS,

@@ -349,6 +349,8 @@ bool dcn_fused_enabled();   // default on; CRFP_DCN_FUSED=0 keeps the two-kernel
 int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s);
 int launch_dcn3(const float* x, long long xb, const float* offmask3, long long omb, const float* w_oihw,
                 const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
+int launch_dcn3_fused(const float* x, long long xb, const float* g2, long long gb, const float* flow, const float* wom, const float* bom,
+                      const float* w_oihw, const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
 int launch_dcn_generic(const float* x, const float* offset, const float* mask, const float* w, const float* b,
                        float* out, int N, int cin, int cout, int H, int W, int dg, hipStream_t s);
 // resample.hip

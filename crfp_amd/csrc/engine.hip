@@ -660,12 +660,19 @@ struct Runner {
             }
             if (pair_mask() & 2)
                 narrow_pair(IT_D3FUSE, IT_D3OM, "conv_narrow_pair:dcn3.fuse_offmask", H8, W8, {F(L.g1), F(L.poff)}, F(L.om3), nullptr, flow8);
-            else {
+            else
                 narrow(IT_D3FUSE, H8, W8, {F(L.g1), F(L.poff)}, F(L.g2));
-                narrow(IT_D3OM, H8, W8, {F(L.g2)}, F(L.om3), nullptr, flow8);
-            }
             const Item& d3 = M.items[IT_D3W];
-            RUN(launch_dcn3(F(L.state_hr), 0, F(L.om3), 0, packed + d3.off_w, packed + d3.off_b, F(L.al3), 0, 1, H8, W8, s));
+            // dcn_3 with its offset / mask conv inside (gather.hip dcn3_kernel<true>): fp32 build 94.0 vs 73.7 + 37.3 us same-box, bit-identical;
+            // the bf16 build keeps two kernels (its stand-alone conv runs on the bf16 MFMA: 84.8 vs 59.8 + 28.4 us, not worth the changed bits)
+            if (!kActBf16 && !(pair_mask() & 2) && dcn_fused_enabled()) {
+                const Item& om = M.items[IT_D3OM];
+                RUN(launch_dcn3_fused(F(L.state_hr), 0, F(L.g2), 0, flow8, packed + om.off_w, packed + om.off_b, packed + d3.off_w, packed + d3.off_b,
+                                      F(L.al3), 0, 1, H8, W8, s));
+            } else {
+                if (!(pair_mask() & 2)) narrow(IT_D3OM, H8, W8, {F(L.g2)}, F(L.om3), nullptr, flow8);
+                RUN(launch_dcn3(F(L.state_hr), 0, F(L.om3), 0, packed + d3.off_w, packed + d3.off_b, F(L.al3), 0, 1, H8, W8, s));
+            }
             if (fg) {           // model/CRFP_test.py:2389
                 RUN(launch_scale_q4(F(L.up), 0, F(L.sc_up), 1, H8, W8, nullptr, fg, s));
                 RUN(launch_scale_q4(F(L.al3), 0, F(L.sc_al3), 1, H8, W8, nullptr, fg, s));

@@ -1193,10 +1193,17 @@ __device__ __forceinline__ winel_t win_load(__amdgpu_buffer_rsrc_t r, int voff) 
 #endif
 constexpr int DCN3_WIN = 40960 / (int)sizeof(winel_t);   // 40 KB window: 2560 fp32 / 5120 bf16 elements
 
+// FUSE: the 4 -> 3 offset / mask conv of dcn_3 (model/CRFP.py:337-347, NE_OFFMASK3 of conv_narrow.hip) runs inside this kernel: `offmask3`
+// is then the conv's INPUT (the dcn_3 offset feature g2, one Q4 quad), staged as a (4+2) x (64+2) fp32 halo tile in LDS; every thread
+// computes its own pixel's (dy, dx, mask) with the narrow kernel's 4x4x1-MFMA form in the same order (fp32 build: bit-identical to the
+// two-kernel path) and samples at once -- the 59 MB offset / mask tensor and one launch per frame disappear.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, long long xb,
                                                    const float* __restrict__ offmask3, long long omb,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                   float* __restrict__ out, long long ob, int H, int W, int lds_max) {
+                                                   float* __restrict__ out, long long ob, int H, int W, int lds_max,
+                                                   const float* __restrict__ flow, const float* __restrict__ wom,
+                                                   const float* __restrict__ bom) {
     extern __shared__ __attribute__((aligned(16))) char dcn3_dyn_lds[];   // the window: allocated at launch only when lds_max > 0
     winel_t* const win = reinterpret_cast<winel_t*>(dcn3_dyn_lds);
     __shared__ int bnd[4];   // ymin, ymax, xmin, xmax of the tile's corner rows / columns
@@ -1206,7 +1213,48 @@ __global__ __launch_bounds__(256) void dcn3_kernel(const float* __restrict__ x, 
     const bool live = px < W && py < H;
     const int cpx = min(px, W - 1), cpy = min(py, H - 1);
     const long long pix = (long long)cpy * W + cpx;
-    const f32x4 om = ldg4(offmask3 + (long long)n * omb + pix * 4);   // read once: non-temporal
+    f32x4 om;
+    if constexpr (FUSE) {
+        __shared__ f32x4 gt[6][66];
+        __shared__ f32x4 wlo[36];   // [tap][cout] -> float4 over the 4 input channels
+        const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+        if (tid < 36) {
+            const float4 wv = reinterpret_cast<const float4*>(wom)[tid];   // packed (tap, comp) -> 4 couts (narrow_pack_kernel, kq = 1)
+            float* wf = reinterpret_cast<float*>(wlo) + (tid >> 2) * 16 + (tid & 3);
+            wf[0] = wv.x; wf[4] = wv.y; wf[8] = wv.z; wf[12] = wv.w;
+        }
+        const act_t* g2 = as_act(offmask3) + (long long)n * omb;
+        const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int idx = tid + 256 * t;
+            if (idx < 6 * 66) {
+                const int r = idx / 66, c = idx - r * 66;
+                const int gy = by0 + r - 1, gx = bx0 + c - 1;
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const cf32x4 v = ldq(g2 + ((long long)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 4);
+                (&gt[0][0])[idx] = ok ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+        const float2 fl = ldnt2(flow + pix * 2);
+        __syncthreads();
+        const float4 b4 = *reinterpret_cast<const float4*>(bom);
+        f32x4 a4 = f32x4{b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 wv = wlo[(ky * 3 + kx) * 4 + (tx & 3)];
+                const f32x4 u = gt[ty + ky][tx + kx];
+                a4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, u.x, a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, u.y, a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, u.z, a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, u.w, a4, 0, 0, 0);
+            }
+        om = f32x4{tanh10_plus(a4.x, 10.0f + fl.y), tanh10_plus(a4.y, 10.0f + fl.x), fast_sigmoid(a4.z), 0.0f};
+    } else {
+        om = ldg4(offmask3 + (long long)n * omb + pix * 4);   // read once: non-temporal
+    }
     const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
     const int guard = pitch + QB;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -1366,7 +1414,18 @@ int launch_dcn3(const float* x, long long xb, const float* offmask3, long long o
     static const int lds_env = getenv("CRFP_DCN3_LDS") ? atoi(getenv("CRFP_DCN3_LDS")) : 0;
     lds_max = lds_env;
 #endif
-    dcn3_kernel<<<grid, 256, lds_max > 0 ? DCN3_WIN * sizeof(winel_t) : 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W, lds_max);
+    dcn3_kernel<false><<<grid, 256, lds_max > 0 ? DCN3_WIN * sizeof(winel_t) : 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W, lds_max,
+                                                                                        nullptr, nullptr, nullptr);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// dcn_3 with its offset / mask conv inside: g2 = the conv's input (one Q4 quad), wom / bom = its narrow-packed weights and bias
+int launch_dcn3_fused(const float* x, long long xb, const float* g2, long long gb, const float* flow, const float* wom, const float* bom,
+                      const float* w, const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s) {
+    const double px = (double)N * H * W;
+    ProfScope prof("dcnv2_shared_c4_fused", s, px * ((4 + 4 + 4) * sizeof(act_t) + 2 * 4.0), px * (2.0 * 4 * 4 * 9 + 36 * 7 + 2.0 * 4 * 3 * 9));
+    dcn3_kernel<true><<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, 0, flow, wom, bom);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
