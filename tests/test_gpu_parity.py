@@ -316,6 +316,27 @@ def test_odd_geometries_vs_oracle(orc, h, w, t, fv):
     assert maxdiff(out, ref) < 1e-4
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_small_offset_regime_vs_oracle(orc, storage):
+    """SURVEY 8(d)'s offset / mask head scale (offset_std = 0.02: DCN residuals of a fraction of a pixel around the flow, as after
+    training) instead of the stress weights every other test uses: the regular 4x4-neighbourhood path of dcn_3 and near-identity
+    sampling in the fused DCN kernel, fp32 against the oracle and bf16 storage against its twin."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7, offset_std=0.02)
+    P = orc.load_numpy_state(sd)
+    lrs, fvs, mks = synth.make_clip(77, 1, 3, 24, 40, fv_size=64, sigma_t=10.0)
+    m = _model(sd)
+    m.storage = storage
+    d = dev()
+    out = m(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    ref = orc.crfp_dsv_forward(P, T(lrs), T(fvs), T(mks))
+    if storage == "f32":
+        assert maxdiff(out, ref) < 1e-4
+    else:   # the yardstick of tests/test_gpu_bf16.py: the twin (bf16 weights, rounds where the engine stores) and its distance to fp32
+        from test_gpu_bf16 import _check_frame_stats, _twin
+        _check_frame_stats(out, _twin(orc, sd, lrs, fvs, mks), ref, "small offsets 3x24x40")
+
+
 def test_batch_of_two_clips(orc):
     """n = 2 (the reference's forward takes a batch; here the clips of a batch go through the C-ABI one by one)."""
     from crfp_amd import synth
