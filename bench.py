@@ -28,6 +28,11 @@ Extra objects on that line:
   cpu_baseline  the oracle (CPU port of the reference path; its bf16 twin for the bf16 configs) timed on this host:
                 1 warm-up + 1 timed pass over the config-2 clip (or a bounded sample of the bigger configs).
   parity        max|HIP - oracle| (bf16 configs: statistics against the twin) and PSNR-Y delta on that sample.
+  other_configs (default run only) BASELINE configs[2..4] -- `--config 3|4|5` -- each as a short leg (3 steps) in a child process
+                after the headline's timed region: frames/s, ms per step, parity against the bf16 twin on 3 frames, conv roofline.
+  warp_dcn_8d   SURVEY 8(d)'s figure un-re-scoped: API-tensor bytes of flow_warp x3 + DCNv2 x4 per steady-state frame divided by
+                the time of ALL warp / DCN kernels of such a frame, the fused offset-head + DCN kernel included.
+  collectives   which backend ran the barrier / MAX / SUM reductions (CRFP_FORCE_DIST=1 initialises RCCL even with one rank).
 """
 import argparse
 import json
@@ -70,8 +75,9 @@ def kernel_family(name: str) -> str:
 
 
 # hipEvent launch-site family -> rocprofv3 kernel names (for the PMC traffic lookup)
-ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_mfma_kernel", "conv3x3_bf16_kernel"),
-                 "conv3x3_narrow": ("conv3x3_narrow_kernel",),
+ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_split8_kernel", "conv3x3_pair_kernel", "conv3x3_mfma_kernel",
+                                  "conv3x3_bf16_kernel", "conv3x3_bf16x8_kernel", "conv3x3_q16_kernel"),
+                 "conv3x3_narrow": ("conv3x3_narrow_kernel", "conv3x3_narrow_pair_kernel"),
                  "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel<false>", "dcn3_kernel"), "dcnv2_shared_c4_fused": ("dcn3_kernel<true>",),
                  "flow_warp_q4_c4": ("flow_warp_p4_kernel",), "flow_warp_q4_c32": ("flow_warp_p4_kernel",),
                  "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "flow_warp_q4_c32+c24": ("flow_warp_p4_dual_kernel",),
@@ -124,7 +130,8 @@ def main():
                     "default 1, config 4: 2 -- independent clips fill each other's kernel tails, bit-identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip strict_f32 / multi-stream / per-op legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip strict_f32 / multi-stream / per-op / other-config legs")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short legs of BASELINE configs 3 / 4 / 5")
     ap.add_argument("--cpu-sample-frames", type=int, default=None)
     ap.add_argument("--cpu-timeout", type=float, default=420.0)
     args = ap.parse_args()
@@ -140,13 +147,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")   # RCCL over xGMI
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    dist = None
+    # CRFP_FORCE_DIST=1: initialise the RCCL group even with ONE rank, so that the barrier and the two all-reduces of this file
+    # run on RCCL on a 1-GPU box exactly as they do with N ranks (tests/test_gpu_round3.py starts it under torch.distributed.run)
+    if world > 1 or os.environ.get("CRFP_FORCE_DIST") == "1":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        dist.init_process_group("nccl")   # RCCL over xGMI
 
     from crfp_amd import _lib, benchutil, ops, synth
     from crfp_amd.engine import DSVEngine
@@ -208,7 +220,7 @@ def main():
         elapsed = time.perf_counter() - t0
     elapsed = benchutil.reduce_elapsed(elapsed, dist, dev)
     frames_per_step = t * clips
-    assert not eng.overflowed(stream=(mode == "stream")), "numerics guard fired on the benchmark clip"
+    assert not any(e.overflowed(stream=(mode == "stream")) for e in engs), "numerics guard fired on the benchmark clip"
 
     # PSNR reduction (the only collective of the path): raw squared-error sums of the last SR frame(s) against the synthetic
     # HR scene inside the fovea window (not a quality figure without trained weights: it exercises the reduction)
@@ -232,6 +244,9 @@ def main():
                    "storage": storage, "parallelism": f"clip-sharded x{world}"},
         "per_gpu_frames_per_sec": agg["per_gpu_frames_per_sec"],
         "frames_per_step_per_gpu": frames_per_step,
+        "collectives": {"backend": dist.get_backend() if dist is not None else None, "initialised": dist is not None,
+                        "world_size": dist.get_world_size() if dist is not None else 1,
+                        "ops": ["barrier", "all_reduce(MAX) of the step time", "all_reduce(SUM) of the PSNR sums"]},
     }
 
     if rank == 0 and not args.no_kernel_profile:
@@ -301,8 +316,8 @@ def main():
                                    "hbm_bytes_not_moved_per_launch": 2.0 * px2 * 216 * 4,
                                    "note": "offset / mask head + dcn_g8 in one launch, bit-identical to the two-kernel path "
                                            "(CRFP_DCN_FUSED=0 restores it: conv_mfma:dcn.offset_mask + dcnv2_g8_c32); flops = conv + DCN GEMM + "
-                                           "bilinear; this kernel is bound by MFMA + VALU issue, which overlap only ~27 % on MI355X "
-                                           "(profiles/r02_mfma_valu_overlap_microtest.txt)"}
+                                           "bilinear; MFMA and sampling VALU share each SIMD's issue port (an MFMA gap hides up to ~24 issue "
+                                           "cycles of VALU, MI355X_MICROARCH.md; re-measured in profiles/r03_mfma_valu_overlap_microtest.txt)"}
         gat = {n: f for n, f in fam.items() if n.startswith("flow_warp") or n.startswith("dcnv2")}
         if gat:
             gb = sum(f["bytes"] for f in gat.values()); gs = sum(f["ms"] for f in gat.values()) * 1e-3
@@ -322,7 +337,45 @@ def main():
                                           + ("; dcn_g8 (dcn_0/1/2) runs inside the fused kernel reported under dcn_fused and is not "
                                              "part of this figure" if fz else "")}
 
+        if gat:
+            # SURVEY 8(d) as written, NOT re-scoped: API-tensor bytes of the three flow_warps and the four DCNv2 calls of a
+            # steady-state frame (fp32 @A: 254.4 + 1290.4 = 1544.7 MB) over the time of ALL kernels that do that work in such a
+            # frame -- including the fused offset-head + dcn_g8 kernel (whose time also contains the 32 -> 216 head conv) and the
+            # dcn_3 kernel with its offset conv inside.  Comparable across rounds whatever gets fused.
+            sb = 4 if storage == "f32" else 2
+            px2, px8 = (2 * h) * (2 * w), (8 * h) * (8 * w)
+            api_bytes = ((66 + 50) * px2 + 10 * px8) * sb + (3 * (280 * px2 + 32 * 32 * 9) + 35 * px8) * sb
+            names8d = [n for n in fam if n.startswith("flow_warp") or n.startswith("dcnv2") or n == "offset_mask_conv+dcnv2_g8_fused"]
+            steady = max(1, (t - 1) * clips * psteps) if mode == "clip" else max(1, (t - 1) * psteps)
+            t8d = sum(fam[n]["ms"] for n in names8d) * 1e-3 / steady
+            result["warp_dcn_8d"] = {"bound": "hbm", "api_tensor_bytes_per_steady_frame": api_bytes, "kernel_us_per_steady_frame": 1e6 * t8d,
+                                     "achieved": api_bytes / t8d / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": api_bytes / t8d / 1e9 / HBM_PEAK_GBS, "kernels": sorted(names8d),
+                                     "note": "SURVEY 8(d): (2C+2)HWs per flow_warp, (Cin + 2 dg K + dg K + Cout)HWs + weights per DCNv2 with the "
+                                             "offset / mask tensors as the reference's API passes them (144 + 72 channels, dcn_3: 18 + 9), divided "
+                                             "by the time of every warp / DCN kernel of a steady-state frame; the fused kernels' time includes "
+                                             "the offset / mask head convs they absorbed"}
+
     extras = rank == 0 and world == 1 and not args.no_extras
+    if extras and mode == "clip":
+        # what the two-stream schedule hides: the same steps with CRFP_DSV_SINGLE_STREAM (everything on the caller's stream)
+        eng.single_stream = True
+        with torch.no_grad():
+            eng.forward(*data[0])
+            torch.cuda.synchronize()
+            n_s = max(2, min(args.steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(n_s):
+                for d_ in data:
+                    eng.forward(*d_)
+            torch.cuda.synchronize()
+            single_ms = 1e3 * (time.perf_counter() - t0) / n_s
+        eng.single_stream = False
+        if n_flight == 1:
+            result["side_stream"] = {"single_stream_ms_per_step": single_ms, "two_stream_ms_per_step": agg["ms_per_step"],
+                                     "side_stream_hidden_ms": single_ms - agg["ms_per_step"],
+                                     "note": "FNet + fovea blend + encoder_hr + upsample conv + flow up-sampling run on the library's side "
+                                             "stream beside the recurrent chain; bit-identical results"}
     if extras and mode == "clip" and storage == "f32":
         # the same clip in strict fp32 (plain fp32 MFMA for every conv and the DCN GEMM): what the split-fp16 scheme buys
         model.precision = "f32"
@@ -381,6 +434,8 @@ def main():
         wd, bd = rn(32, 32, 3, 3) * 0.1, rn(32)
         wc, bc = rn(32, 64, 3, 3) * 0.05, rn(32)
         x64 = rn(1, 64, H2, W2)
+        spy = CRFP.SPyNet(pretrained=None, device=dev).to(dev).eval()
+        spy_a, spy_b = torch.rand(1, 3, 192, 320, generator=g).to(dev), torch.rand(1, 3, 192, 320, generator=g).to(dev)
         with torch.no_grad():
             result["per_op_us"] = {
                 "flow_warp_c32@2x": time_op(lambda: ops.flow_warp(x32, fl2)),
@@ -388,7 +443,34 @@ def main():
                 "dcnv2_c32_dg8@2x": time_op(lambda: ops.dcnv2(x32, off, msk, wd, bd, 3, 1, 1, 8)),
                 "conv3x3_64to32@2x": time_op(lambda: ops.conv3x3(x64, wc, bc, "lrelu")),
                 "upsample_bilinear_x8_c3": time_op(lambda: ops.upsample_bilinear(data[0][0][0, :1], scale_factor=8)),
+                "fnet_6pairs@lr": time_op(lambda: eng.compute_flow(data[0][0][0, 1:7], data[0][0][0, 0:6]), 10) if t >= 7 else None,
+                "spynet_1pair@192x320": time_op(lambda: spy(spy_a, spy_b), 5),
                 "note": "wall-clock per call incl. the NCHW <-> Q4 conversions the operator boundary needs (the engine pays none of them)"}
+
+    if extras and args.config == 2 and not custom and not args.no_other_configs:
+        # BASELINE configs[2..4] (the bf16 configurations) as short legs in child processes, outside the headline's timed region:
+        # frames/s, ms per step, parity against the bf16 twin on 3 frames, the conv family's roofline fraction
+        import subprocess
+        others = {}
+        for c in (3, 4, 5):
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(c), "--steps", "3", "--warmup", "1", "--no-extras",
+                   "--cpu-sample-frames", "3", "--cpu-timeout", "240"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CRFP_FORCE_DIST")}
+            try:
+                r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+                j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                others[str(c)] = {"workload": j["config"]["workload"], "frames_per_sec": j["value"], "ms_per_step": j["ms_per_step"],
+                                  "frames_per_step": j["frames_per_step_per_gpu"], "steps": j["steps"], "dtype": j["dtype"],
+                                  "clips_in_flight": j["config"]["clips_in_flight_per_gpu"], "parity_vs_twin": j.get("parity"),
+                                  "conv": {k: j["roofline"].get(k) for k in ("kernel", "frac", "achieved", "peak", "unit", "avg_launch_us")}
+                                  if "roofline" in j else None,
+                                  "dcn_fused_avg_us": j.get("dcn_fused", {}).get("avg_us"),
+                                  "warp_dcn_frac": j.get("warp_dcn", {}).get("frac"),
+                                  "warp_dcn_8d_frac": j.get("warp_dcn_8d", {}).get("frac"),
+                                  "cpu_baseline": j.get("cpu_baseline")}
+            except Exception as e:  # noqa: BLE001 -- a failed leg must not take the headline line down with it
+                others[str(c)] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        result["other_configs"] = others
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # The oracle (CPU port of the reference path; checker / baseline only, never on the product path) runs in a child

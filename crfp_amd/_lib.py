@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRFP_HIP_LIB") or os.path.join(_HERE, "libcrfp_hip.so")
 
 NUM_PARAMS = 118
-DSV_Y_ONLY, DSV_STRICT_F32 = 1, 2   # flags of crfp_dsv_forward_clip / crfp_dsv_stream_frame
+DSV_Y_ONLY, DSV_STRICT_F32, DSV_SINGLE_STREAM = 1, 2, 4   # flags of crfp_dsv_forward_clip / crfp_dsv_stream_frame
 
 c_float_p = C.POINTER(C.c_float)
 

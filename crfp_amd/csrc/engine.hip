@@ -812,7 +812,7 @@ int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* 
     const long long lr_f = 3LL * h * w, hr_px = 64LL * h * w;
     const int co = y_only ? 1 : 3;
     const long long xq = 8LL * h * w * 4, fq = 1LL * h * w * 4;
-    SideStream* ssp = side_stream_enabled() && !prof_enabled() ? side_stream() : nullptr;
+    SideStream* ssp = side_stream_enabled() && !prof_enabled() && !(flags & CRFP_DSV_SINGLE_STREAM) ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
     if (!ssp) {
         // single-stream schedule (also used while per-kernel timing is on: events bracket launches per stream)
@@ -839,9 +839,12 @@ int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* 
     auto fail = [&](const char* what) { join(); set_error("dsv_forward_clip: %s failed", what); return 1; };
     hipEvent_t ev_start = ss.event(0), ev_xlr = ss.event(1);
     if (!ss.ok) return fail("hipEventCreate");
+    // the status word and the recurrent state are cleared BEFORE the fork: the side stream's first kernel (frame 0's fovea
+    // blend) may raise the overflow bit, and a memset racing with it on the other stream could wipe that
+    R.reset_state();
+    if (R.rc) return R.rc;
     if (hipEventRecord(ev_start, main_s) != hipSuccess || hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
     forked = true;
-    R.reset_state();
     R.encode_lr(t, lrs, lr_f);
     if (hipEventRecord(ev_xlr, main_s) != hipSuccess) return fail("record");
     for (int i = 0; i < t && !R.rc; ++i) {
@@ -877,7 +880,7 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     if (!lr || !fv || !mk || !out || (!first && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
-    SideStream* ssp = (!first && side_stream_enabled() && !prof_enabled()) ? side_stream() : nullptr;
+    SideStream* ssp = (!first && side_stream_enabled() && !prof_enabled() && !(flags & CRFP_DSV_SINGLE_STREAM)) ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
     if (!ssp) {
         if (first) R.reset_state();

@@ -36,7 +36,9 @@ class DSVEngine:
         if self.device.type != "cuda":
             raise RuntimeError("crfp_amd.DSVEngine needs a CUDA/HIP device (no CPU path in the product)")
         self.y_only = int(bool(y_only))
+        self.single_stream = False   # True: CRFP_DSV_SINGLE_STREAM on every call (no fork onto the library's side stream)
         self._ws = {}
+        self._ovf = None             # int32[1] on the device: status words of the last forward()'s clips, OR-ed (no host sync)
         self._stream_ws = None
         self._stream_prev = None
         self._stream_prev_buf = None
@@ -61,6 +63,15 @@ class DSVEngine:
                 raise ValueError(f"parameter {k}: {t.numel()} elements, expected {want}")
             keep.append(t)
             ptrs[i] = t.data_ptr()
+        # range of the split-fp16 scheme (conv_mfma.hip, "f16x3s": the sum is kept scaled by 2^11, so 2^11 * w must stay an
+        # fp16 value): |w| < 32.  Checked HERE, where the offending tensor can be named; without it an out-of-range weight
+        # becomes an inf operand image and only shows up downstream as "an activation overflowed".
+        wmax = torch.stack([t.abs().max() for t, k in zip(keep, names) if k.endswith(".weight")]).cpu()
+        wnames = [k for k in names if k.endswith(".weight")]
+        self._wmax = float(wmax.max())
+        self._wmax_name = wnames[int(wmax.argmax())]
+        if not torch.isfinite(wmax).all():
+            raise ValueError(f"crfp_amd: parameter {wnames[int((~torch.isfinite(wmax)).nonzero()[0])]} holds inf / NaN")
         nbytes = self._fn("crfp_dsv_packed_weight_bytes")(self.y_only)
         self.packed = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
@@ -74,7 +85,10 @@ class DSVEngine:
             nb = self._fn("crfp_dsv_workspace_bytes")(t, h, w)
             if nb == 0:
                 raise ValueError(f"unsupported clip shape t={t} h={h} w={w}")
-            self._ws = {key: torch.empty(nb, dtype=torch.uint8, device=self.device)}  # keep one shape alive
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            off = self._fn("crfp_dsv_status_offset")(t, h, w)
+            ws[off:off + 256].zero_()   # a fresh workspace starts with a clear status word (crfp_fnet_forward never writes it)
+            self._ws = {key: ws}        # keep one shape alive
         return self._ws[key]
 
     @staticmethod
@@ -83,9 +97,17 @@ class DSVEngine:
             return mks.contiguous().view(torch.uint8)
         return (mks != 0).contiguous().view(torch.uint8)
 
+    WEIGHT_LIMIT_SPLIT = 32.0   # |w| < 32 for the default split-fp16 convolution scheme (fp32 storage)
+
     def _flags(self, strict=None):
         strict = (self.precision == "f32") if strict is None else strict
-        return self.y_only | (_lib.DSV_STRICT_F32 if strict else 0)
+        if not strict and self.storage == "f32" and self._wmax >= self.WEIGHT_LIMIT_SPLIT:
+            if self.on_overflow == "fallback":
+                return self.y_only | _lib.DSV_STRICT_F32 | (_lib.DSV_SINGLE_STREAM if self.single_stream else 0)
+            raise ValueError(f"crfp_amd: weight {self._wmax_name} has max |w| = {self._wmax:.4g} >= {self.WEIGHT_LIMIT_SPLIT:g}, outside "
+                             "the operand range of the split-fp16 convolution scheme; run this model with precision='f32' "
+                             "(CRFP_DSV_STRICT_F32)")
+        return self.y_only | (_lib.DSV_STRICT_F32 if strict else 0) | (_lib.DSV_SINGLE_STREAM if self.single_stream else 0)
 
     def _status(self, ws, t, h, w) -> int:
         off = self._fn("crfp_dsv_status_offset")(t, h, w)
@@ -96,7 +118,7 @@ class DSVEngine:
         streamed sequence).  Synchronises the device."""
         if stream:
             return self._stream_ws is not None and bool(self._status(self._stream_ws, 1, *self._stream_hw) & 1)
-        return any(self._status(ws, *key) & 1 for key, ws in self._ws.items())
+        return self._ovf is not None and bool(int(self._ovf.item()) & 1)   # OR over every clip of the last forward()
 
     def _after(self, ws, key, rerun):
         """on_overflow policy after a call that used workspace `ws`; `rerun(strict=True)` repeats it."""
@@ -126,10 +148,16 @@ class DSVEngine:
                                                fvs[b].data_ptr(), mk8[b].data_ptr(), out[b].data_ptr(), t, h, w,
                                                ws.data_ptr(), ws.numel(), _stream()), "crfp_dsv_forward_clip")
 
+        off = self._fn("crfp_dsv_status_offset")(t, h, w)
+        word = ws[off:off + 4].view(torch.int32)
         with torch.cuda.device(self.device):
+            if self._ovf is None:
+                self._ovf = torch.zeros(1, dtype=torch.int32, device=self.device)
             for b in range(n):
                 run(b)
                 self._after(ws, (t, h, w), lambda b=b: run(b, strict=True))
+                # every clip resets the workspace's status word: keep the OR over the batch (stream-ordered, no host sync)
+                self._ovf.copy_(word) if b == 0 else self._ovf.bitwise_or_(word)
         return out
 
     # ---- streaming: one frame per call, state lives in a dedicated workspace

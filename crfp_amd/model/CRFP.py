@@ -8,6 +8,8 @@ The modules only *hold parameters*; all arithmetic runs in the HIP library: ``CR
 one C-ABI call per clip (crfp_amd.engine.DSVEngine), the smaller modules call per-operator entry
 points.  Inference only (no autograd), CUDA/HIP tensors only.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -292,6 +294,7 @@ class CRFP_DSV(nn.Module):
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
         self._engine = None
         self._engine_sig = None
+        self._engine_sum = None
         # numerics policy of the HIP engine (crfp_amd.engine.DSVEngine): not part of the reference's interface
         self.precision = "split"      # "split": split-fp16 MFMA scheme (fp32-grade) | "f32": strict fp32 MFMA
         self.on_overflow = "poison"   # "poison" | "fallback" | "raise" when an activation leaves the fp16 operand range
@@ -299,15 +302,35 @@ class CRFP_DSV(nn.Module):
 
     # ---- engine management: repack whenever a parameter was modified or moved
     def _signature(self):
+        """(address, in-place version) of every parameter: changes under load_state_dict, optimizer steps, ``.to()`` and any
+        in-place op on the parameter itself.  It does NOT see writes through ``param.data`` (a ``.data`` alias has its own
+        version counter) -- after such writes call ``invalidate_packed()``.  ``CRFP_CHECK_PACKED=1`` in the environment makes
+        every ``engine()`` call verify an on-device checksum of the parameters against the one taken at pack time (one host
+        sync per call: a debugging aid) and raise if they differ."""
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _checksum(self):
+        ps = [p.detach().reshape(-1) for p in self.parameters()]
+        flat = torch.cat(ps).double()
+        return torch.stack([flat.sum(), flat.abs().sum(), (flat * torch.arange(1, flat.numel() + 1, device=flat.device, dtype=torch.float64)).sum()])
+
+    def invalidate_packed(self):
+        """Drop the packed-weight image: the next forward repacks from the current parameter values.  Needed only after
+        writing parameters through ``.data`` (see ``_signature``)."""
+        self._engine_sig = None
 
     def engine(self) -> DSVEngine:
         dev = next(self.parameters()).device
         sig = self._signature()
+        check = os.environ.get("CRFP_CHECK_PACKED") == "1"
         if (self._engine is None or self._engine_sig != sig or self._engine.device != dev
                 or self._engine.storage != self.storage):
             self._engine = DSVEngine(self.state_dict(), dev, self.y_only, storage=self.storage)
             self._engine_sig = sig
+            self._engine_sum = self._checksum() if check else None
+        elif check and self._engine_sum is not None and not torch.equal(self._engine_sum, self._checksum()):
+            raise RuntimeError("crfp_amd: parameters changed without their version counters moving (a write through `.data`?): "
+                               "the packed weights are stale -- call model.invalidate_packed() after such writes")
         self._engine.precision, self._engine.on_overflow = self.precision, self.on_overflow
         return self._engine
 

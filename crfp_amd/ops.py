@@ -37,32 +37,74 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-# Packed-weight cache of the per-operator entry points.  The packed buffer hangs on the weight tensor OBJECT (it dies with
-# it -- a cache keyed by data_ptr would hand a recycled address the previous owner's weights) and is valid while the
-# in-place version counters of the weight and of the companion tensors (bias) are unchanged: an optimizer step or the
-# reference's conv_identify (model/CRFP.py:359-370) repacks, an untouched module pays the repack once.
-import weakref
+# Weights of the per-operator entry points are repacked on EVERY call, on the caller's stream, right in front of the kernel that
+# reads them (one ~3 us pack launch).  Round 2 cached the packed image on the weight tensor keyed by ``Tensor._version``; writes
+# through ``.data`` (which the reference uses: ``m.weight.data *= scale``, conv_identify at model/CRFP.py:359-370) do not bump
+# that counter, so the cache could serve stale weights, and an image packed on one stream could be read half-written from
+# another.  Callers that own the immutability of their weights hoist the repack themselves: ``pack_conv3x3`` /
+# ``conv3x3_packed`` and ``pack_dcnv2_g8`` / ``dcnv2_g8_packed`` (the C-ABI's *_pack_f32 / *_packed_f32 forms); the engine
+# (crfp_amd/engine.py) packs once per ``DSVEngine`` and is rebuilt by ``CRFP_DSV.engine()`` / ``invalidate_packed()``.
 
 
-def _packed(kind, tensors, nbytes, pack_fn):
-    owner = tensors[0]
-    slot = getattr(owner, "_crfp_packed", None)
-    if slot is None:
-        slot = {}
-        try:
-            owner._crfp_packed = slot
-        except AttributeError:     # not attachable: pack every time
-            slot = None
-    ent = slot.get(kind) if slot is not None else None
-    if ent is not None:
-        refs, versions, buf = ent
-        if all(r() is t for r, t in zip(refs, tensors)) and versions == tuple(t._version for t in tensors) and buf.device == owner.device:
-            return buf
-    buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=owner.device)
-    pack_fn(buf)
-    if slot is not None:
-        slot[kind] = (tuple(weakref.ref(t) for t in tensors), tuple(t._version for t in tensors), buf)
-    return buf
+def _pack_buf(nbytes, device):
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("crfp_amd.ops: per-call weight repacking allocates; inside CUDA-graph capture use the *_packed forms "
+                           "with an image packed before the capture")
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def pack_conv3x3(weight, bias=None):
+    """Packed image of a [cout, cin, 3, 3] weight (+ bias) for ``conv3x3_packed``; valid until the caller changes the weights.
+    Produced on the current stream: use it on that stream, or order the consumer behind it."""
+    weight = _dev(weight, "weight")
+    cout, cin = weight.shape[:2]
+    assert tuple(weight.shape) == (cout, cin, 3, 3), "conv3x3: weight must be [cout, cin, 3, 3]"
+    bias = torch.zeros(cout, dtype=torch.float32, device=weight.device) if bias is None else _dev(bias, "bias")
+    L = _lib.lib()
+    with _on(weight, bias):
+        pk = _pack_buf(L.crfp_conv3x3_packed_bytes(cin, cout), weight.device)
+        _lib.check(L.crfp_conv3x3_pack_f32(weight.data_ptr(), bias.data_ptr(), cin, cout, pk.data_ptr(), pk.numel(), _stream()),
+                   "crfp_conv3x3_pack_f32")
+    pk._crfp_shape = (cin, cout)
+    return pk
+
+
+def conv3x3_packed(x, packed, act="none", post_scale=1.0):
+    """conv3x3 with an image from ``pack_conv3x3``."""
+    x = _dev(x, "x")
+    cin, cout = packed._crfp_shape
+    n, c, h, w = x.shape
+    assert c == cin, f"conv3x3_packed: input has {c} channels, the packed weight {cin}"
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    with _on(x, packed):
+        _lib.check(_lib.lib().crfp_conv3x3_packed_f32(x.data_ptr(), packed.data_ptr(), out.data_ptr(), n, cin, cout, h, w, ACT[act],
+                                                      float(post_scale), _stream()), "crfp_conv3x3_packed_f32")
+    return out
+
+
+def pack_dcnv2_g8(weight):
+    """Packed image of a DCNv2(32 -> 32, 3x3, 8 groups) weight for ``dcnv2_g8_packed``."""
+    weight = _dev(weight, "weight")
+    assert tuple(weight.shape) == (32, 32, 3, 3)
+    L = _lib.lib()
+    with _on(weight):
+        pk = _pack_buf(L.crfp_dcnv2_g8_packed_bytes(), weight.device)
+        _lib.check(L.crfp_dcnv2_g8_pack_f32(weight.data_ptr(), pk.data_ptr(), pk.numel(), _stream()), "crfp_dcnv2_g8_pack_f32")
+    return pk
+
+
+def dcnv2_g8_packed(x, offset, mask, packed, bias):
+    """DCNv2(32 -> 32, 3x3, pad 1, 8 groups) with an image from ``pack_dcnv2_g8``."""
+    x, offset, mask, bias = _dev(x, "input"), _dev(offset, "offset"), _dev(mask, "mask"), _dev(bias, "bias")
+    n, cin, h, w = x.shape
+    assert cin == 32 and tuple(offset.shape) == (n, 144, h, w) and tuple(mask.shape) == (n, 72, h, w)
+    L = _lib.lib()
+    out = torch.empty((n, 32, h, w), dtype=torch.float32, device=x.device)
+    with _on(x, offset, mask, packed, bias):
+        ws = _ws(L.crfp_dcnv2_workspace_bytes(n, 32, 32, h, w, 3, 8), x.device)
+        _lib.check(L.crfp_dcnv2_g8_packed_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), packed.data_ptr(), bias.data_ptr(),
+                                              out.data_ptr(), n, h, w, ws.data_ptr(), ws.numel(), _stream()), "crfp_dcnv2_g8_packed_f32")
+    return out
 
 
 def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_corners=True):
@@ -100,13 +142,8 @@ def dcnv2(x, offset, mask, weight, bias, kernel_size=3, padding=1, dilation=1, d
     L = _lib.lib()
     out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
     ws = _ws(L.crfp_dcnv2_workspace_bytes(n, cin, cout, h, w, kernel_size, deformable_groups), x.device)
-    if (cin, cout, deformable_groups, kernel_size, padding, dilation) == (32, 32, 8, 3, 1, 1):   # MFMA fast path, weights packed once
-        with _on(x, offset, mask, weight, bias):
-            pk = _packed("dcn_g8", (weight,), L.crfp_dcnv2_g8_packed_bytes(), lambda b: _lib.check(
-                L.crfp_dcnv2_g8_pack_f32(weight.data_ptr(), b.data_ptr(), b.numel(), _stream()), "crfp_dcnv2_g8_pack_f32"))
-            _lib.check(L.crfp_dcnv2_g8_packed_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), pk.data_ptr(), bias.data_ptr(),
-                                                  out.data_ptr(), n, h, w, ws.data_ptr(), ws.numel(), _stream()), "crfp_dcnv2_g8_packed_f32")
-        return out
+    if (cin, cout, deformable_groups, kernel_size, padding, dilation) == (32, 32, 8, 3, 1, 1):   # MFMA fast path
+        return dcnv2_g8_packed(x, offset, mask, pack_dcnv2_g8(weight), bias)
     with _on(x, offset, mask, weight, bias):
         _lib.check(L.crfp_dcnv2_forward_f32(x.data_ptr(), offset.data_ptr(), mask.data_ptr(), weight.data_ptr(),
                                             bias.data_ptr(), out.data_ptr(), n, cin, cout, h, w, kernel_size, padding,
@@ -133,22 +170,11 @@ def dcnv2_shared(x, offset, mask, weight, bias):
 
 
 def conv3x3(x, weight, bias=None, act="none", post_scale=1.0):
-    """3x3 stride-1 pad-1 convolution + bias + activation on the fp32 MFMA path."""
+    """3x3 stride-1 pad-1 convolution + bias + activation on the fp32 MFMA path (weights repacked by this call)."""
     x, weight = _dev(x, "x"), _dev(weight, "weight")
-    n, cin, h, w = x.shape
-    cout = weight.shape[0]
-    assert tuple(weight.shape) == (cout, cin, 3, 3), "conv3x3: weight must be [cout, cin, 3, 3]"
-    if bias is None:
-        bias = torch.zeros(cout, dtype=torch.float32, device=x.device)
-    bias = _dev(bias, "bias")
-    L = _lib.lib()
-    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
-    with _on(x, weight, bias):
-        pk = _packed("conv3x3", (weight, bias), L.crfp_conv3x3_packed_bytes(cin, cout), lambda b: _lib.check(
-            L.crfp_conv3x3_pack_f32(weight.data_ptr(), bias.data_ptr(), cin, cout, b.data_ptr(), b.numel(), _stream()), "crfp_conv3x3_pack_f32"))
-        _lib.check(L.crfp_conv3x3_packed_f32(x.data_ptr(), pk.data_ptr(), out.data_ptr(), n, cin, cout, h, w, ACT[act], float(post_scale),
-                                             _stream()), "crfp_conv3x3_packed_f32")
-    return out
+    assert tuple(weight.shape) == (weight.shape[0], x.shape[1], 3, 3), "conv3x3: weight must be [cout, cin, 3, 3]"
+    with _on(x, weight):
+        return conv3x3_packed(x, pack_conv3x3(weight, bias), act, post_scale)
 
 
 def conv3x3_ex(x, weight, bias=None, x2=None, residual=None, act="none", post_scale=1.0, unshuffle=0, shuffle=0, out=None, out_c0=0):
@@ -182,11 +208,13 @@ def conv3x3_ex(x, weight, bias=None, x2=None, residual=None, act="none", post_sc
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
         ctot = cout
     else:
-        out = _dev(out, "out")
+        # written in place: a copy made here would never reach the caller's tensor
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()):
+            raise ValueError("conv3x3_ex: `out` must be a contiguous float32 CUDA/HIP tensor (it is written in place)")
         assert out.shape[0] == n and tuple(out.shape[2:]) == (h, w), "conv3x3_ex: out must be [n, C, h, w]"
         ctot = out.shape[1]
     L = _lib.lib()
-    with _on(x, weight, bias):
+    with _on(x, weight, bias, x2, residual, out):
         nb = L.crfp_conv3x3_ex_workspace_bytes(n, cin, cin2, cout, h, w, int(unshuffle), r, int(residual is not None))
         if nb == 0:
             _lib.check(-3, "crfp_conv3x3_ex_workspace_bytes")

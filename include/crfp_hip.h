@@ -180,6 +180,8 @@ size_t crfp_dsv_workspace_bytes(int t, int h, int w);
 #define CRFP_DSV_Y_ONLY 1     /* the model was built with y_only=True: one output channel */
 #define CRFP_DSV_STRICT_F32 2 /* plain fp32 MFMA for every convolution and the DCN GEMM instead of the default split-fp16
                                * scheme (fp32-grade, 3 fp16 MFMAs per product, needs |activation|, |weight| < 65504) */
+#define CRFP_DSV_SINGLE_STREAM 4 /* this call enqueues everything on `stream` itself (no fork onto the library's side stream);
+                               * same bits, used to measure what the two-stream schedule hides */
 
 /* Numerics status: a 32-bit word inside the workspace at this byte offset.  Bit 0 is raised (sticky until the next clip
  * / the next `first` streamed frame) when a kernel of the split-fp16 scheme stores a value an fp16 operand cannot hold

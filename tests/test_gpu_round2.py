@@ -305,26 +305,67 @@ def test_runtime_variant_vs_reference_golden(orc, capsys):
 
 
 # ------------------------------------------------------------------------------------------------ pre-packed operator variants
-def test_packed_operator_variants_and_cache_invalidation(orc):
-    """crfp_conv3x3_packed_f32 / crfp_dcnv2_g8_packed_f32 (weights packed once) equal the one-call forms, and the Python-side
-    cache repacks when a weight is mutated IN PLACE (the reference does that: conv_identify, model/CRFP.py:359-370)."""
+def test_packed_operator_variants_and_weight_updates(orc):
+    """crfp_conv3x3_packed_f32 / crfp_dcnv2_g8_packed_f32 (weights packed by the caller) equal the one-call forms, and the
+    per-operator wrappers see EVERY kind of weight update -- in place, and through ``.data`` the way the reference writes
+    weights (``m.weight.data *= scale``, conv_identify, model/CRFP.py:359-370), which moves no version counter."""
     from crfp_amd import ops
     rs = np.random.RandomState(2)
     x = T(rs.standard_normal((1, 32, 20, 36)).astype(np.float32)).to(dev())
     w = T((rs.standard_normal((32, 32, 3, 3)) * 0.1).astype(np.float32)).to(dev())
     b = T(rs.standard_normal(32).astype(np.float32)).to(dev())
+    ref = lambda: F.leaky_relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1), 0.1)   # noqa: E731
     a1 = ops.conv3x3(x, w, b, "lrelu")
     assert maxdiff(a1, ops.conv3x3_unpacked(x, w, b, "lrelu")) == 0.0
-    assert maxdiff(ops.conv3x3(x, w, b, "lrelu"), a1) == 0.0                       # second call: cache hit
-    w.mul_(2.0)                                                                    # in-place update -> new version -> repack
+    pk = ops.pack_conv3x3(w, b)
+    assert maxdiff(ops.conv3x3_packed(x, pk, "lrelu"), a1) == 0.0                  # caller-hoisted pack == per-call pack
+    w.mul_(2.0)                                                                    # in-place update
     a2 = ops.conv3x3(x, w, b, "lrelu")
-    assert maxdiff(a2, F.leaky_relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1), 0.1)) < 3e-5 and maxdiff(a2, a1) > 1e-3
+    assert maxdiff(a2, ref()) < 3e-5 and maxdiff(a2, a1) > 1e-3
+    v = w._version
+    w.data *= 0.25                                                                 # .data update: the version counter stays
+    w.data[3] = 1.0
+    assert w._version == v
+    a3 = ops.conv3x3(x, w, b, "lrelu")
+    assert maxdiff(a3, ref()) < 3e-5 and maxdiff(a3, a2) > 1e-3
+    assert maxdiff(ops.conv3x3(x, w, None, "none"), F.conv2d(x.cpu(), w.cpu(), None, padding=1)) < 3e-5   # bias=None
     off = T(rs.uniform(-4, 4, (1, 144, 20, 36)).astype(np.float32)).to(dev())
     msk = T(rs.uniform(0, 1, (1, 72, 20, 36)).astype(np.float32)).to(dev())
     d1 = ops.dcnv2(x, off, msk, w, b, 3, 1, 1, 8)
     assert maxdiff(d1, orc.dcnv2(x.cpu(), off.cpu(), msk.cpu(), w.cpu(), b.cpu(), 8)) < 5e-5
-    w.zero_()
+    assert maxdiff(ops.dcnv2_g8_packed(x, off, msk, ops.pack_dcnv2_g8(w), b), d1) == 0.0
+    w.data.zero_()
     assert maxdiff(ops.dcnv2(x, off, msk, w, b, 3, 1, 1, 8), b.cpu().view(1, 32, 1, 1).expand(1, 32, 20, 36)) < 1e-6
+
+
+def test_module_sees_data_writes_after_invalidate_and_checked_mode_catches_stale_weights():
+    """CRFP_DSV keeps one packed-weight image per engine, keyed by (address, version) of every parameter.  A write through
+    ``.data`` moves neither: ``invalidate_packed()`` is the documented way to publish it, and CRFP_CHECK_PACKED=1 turns a
+    forgotten one into an error instead of a silently stale result."""
+    from crfp_amd import synth
+    sd = synth.make_state_dict(7)
+    m = _model(sd)
+    lrs, fvs, mks = synth.make_clip(5, 1, 2, 16, 24, fv_size=48)
+    d = dev()
+    a = dict(lrs=T(lrs).to(d), fvs=T(fvs).to(d), mks=T(mks).to(d))
+    ref = m(**a).clone()
+    m.conv_last.weight.data *= 0.5
+    m.invalidate_packed()
+    out = m(**a).clone()
+    assert maxdiff(out, ref) > 1e-4
+    m.conv_last.weight.mul_(2.0)                      # in place on the parameter: picked up by itself
+    assert maxdiff(m(**a), ref) < 1e-6
+    os.environ["CRFP_CHECK_PACKED"] = "1"
+    try:
+        m.invalidate_packed()
+        m(**a)                                        # packs and records the checksum
+        m.conv_last.bias.data += 1.0
+        with pytest.raises(RuntimeError, match="invalidate_packed"):
+            m(**a)
+        m.invalidate_packed()
+        assert maxdiff(m(**a), ref) > 0.5
+    finally:
+        os.environ.pop("CRFP_CHECK_PACKED")
 
 
 @pytest.mark.parametrize("case", ["cat_resid", "slice", "shuffle2", "shuffle4", "unshuffle4"])
