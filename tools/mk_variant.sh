@@ -1,0 +1,22 @@
+#!/bin/bash
+# A/B builds of the lab library: recompile ONE source with extra flags and link it with the other lab objects.
+#   tools/mk_variant.sh <name> <file.hip> "<extra flags>"   ->  _ab/libcrfp_<name>.so   (use: CRFP_HIP_LIB=_ab/libcrfp_<name>.so)
+set -e
+name=$1; src=$2; extra=$3
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+C=$ROOT/crfp_amd/csrc
+mkdir -p $ROOT/_ab/obj
+base=$(basename $src .hip)
+SCHED="-mllvm -amdgpu-sched-strategy=max-memory-clause"
+[ "$base" = conv_mfma ] && SCHED="-mllvm -amdgpu-sched-strategy=max-ilp"
+[ "$base" = gather ] && SCHED=""
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops"
+/opt/rocm/bin/hipcc $FLAGS -DCRFP_LAB $SCHED $extra -c $C/$base.hip -o $ROOT/_ab/obj/$base.$name.o 2>&1 | grep -v "not a recognized feature" | grep -E "error|warning: fail" || true
+objs=""
+for f in runtime conv_mfma conv_narrow gather resample metrics engine api spynet; do
+  if [ $f = $base ]; then objs="$objs $ROOT/_ab/obj/$base.$name.o"; else objs="$objs $C/build_lab/$f.o"; fi
+done
+if [[ "$extra" == *CRFP_ACT_BF16_VARIANT* ]]; then echo "bf16 variants: build by hand"; fi
+for f in conv_mfma conv_narrow gather resample engine; do objs="$objs $C/build/$f.bf16.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/_ab/libcrfp_$name.so $objs
+echo built _ab/libcrfp_$name.so
