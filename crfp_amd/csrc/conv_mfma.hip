@@ -870,6 +870,9 @@ __global__ __launch_bounds__(S8_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     __shared__ bf16x8 tile[2][2][S8_NEL];        // [split part][quad pair][halo pixel]   42.2 KB
     __shared__ bf16x8 wlds[S8_WPC];              // [(tap, image A/B/C)][lane]            27.6 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CRFP_PRIO47   // A/B builds: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(CRFP_PRIO47);
+#endif
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW;
     const int ngrp = a.ctiles;

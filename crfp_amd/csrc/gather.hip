@@ -190,8 +190,8 @@ __device__ __forceinline__ void warp_quads(__amdgpu_buffer_rsrc_t r, int voff, i
 }
 
 // NW waves = NW rows x 64 pixels per workgroup: with 4-row tiles the source window of a tile (rows + shift + 1 bilinear row) is
-// 1.27x the tile and neighbouring tiles sit on different XCDs (no shared L2): PMC 127.6 MB for 106.9 MB algorithmic (round 2);
-// 8-row tiles bring the window to 1.14x.
+// 1.27x the tile and neighbouring tiles sit on different XCDs (no shared L2): PMC 127.6 MB for 106.9 MB algorithmic (round 2).
+// 8-row tiles (window 1.14x) were measured in round 3 and are no faster (lab: CRFP_WARP_NW=8): the kernel is latency-, not byte-bound.
 template <int NQA, int NQB, int NW>
 __global__ __launch_bounds__(64 * NW) void flow_warp_p4_dual_kernel(const float* __restrict__ xa, const float* __restrict__ xb_,
                                                                     const float* __restrict__ flow, float* __restrict__ outa,
@@ -231,14 +231,14 @@ int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* 
     const double px = (double)H * W;
     ProfScope prof("flow_warp_q4_c32+c24", s, px * (2.0 * 14 * 4 * sizeof(act_t) + 8), px * 14 * 4 * 7.0);
 #ifdef CRFP_LAB
-    static const int nw4 = getenv("CRFP_WARP_NW") && atoi(getenv("CRFP_WARP_NW")) == 4;
-    if (nw4) {
-        flow_warp_p4_dual_kernel<8, 6, 4><<<dim3((W + 63) / 64, (H + 3) / 4, 1), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W);
+    static const int nw8 = getenv("CRFP_WARP_NW") && atoi(getenv("CRFP_WARP_NW")) == 8;
+    if (nw8) {   // 8-row tiles (window 1.14x instead of 1.27x the tile): 26.5 vs 26.0-26.4 us same box @A -- not the traffic
+        flow_warp_p4_dual_kernel<8, 6, 8><<<dim3((W + 63) / 64, (H + 7) / 8, 1), 512, 0, s>>>(xa, xb, flow, outa, outb, H, W);
         CRFP_CHECK_LAUNCH();
         return 0;
     }
 #endif
-    flow_warp_p4_dual_kernel<8, 6, 8><<<dim3((W + 63) / 64, (H + 7) / 8, 1), 512, 0, s>>>(xa, xb, flow, outa, outb, H, W);
+    flow_warp_p4_dual_kernel<8, 6, 4><<<dim3((W + 63) / 64, (H + 3) / 4, 1), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -497,16 +497,17 @@ __device__ __forceinline__ void dcn_issue_pair(DcnPair& P, __amdgpu_buffer_rsrc_
         dcn_issue_one(P, pi, rx, dyv[hb + pi], dxv[hb + pi], mmv[hb + pi], 4 * v + hb + pi, fy0, fx0, fH, fW, PW, pitch, plane_b, hbase);
 }
 
-__device__ __forceinline__ void dcn_consume_pair(const DcnPair& P, f32x16& acc, f32x16& acl, const f32x4* wl, int u, int lane) {
-    float xs[8];
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-        f32x4 val = pair_lo(P.tp[pi]) * P.w[pi][0];
-        val = __builtin_elementwise_fma(pair_hi(P.tp[pi]), f32x4{P.w[pi][1], P.w[pi][1], P.w[pi][1], P.w[pi][1]}, val);
-        val = __builtin_elementwise_fma(pair_lo(P.bt[pi]), f32x4{P.w[pi][2], P.w[pi][2], P.w[pi][2], P.w[pi][2]}, val);
-        val = __builtin_elementwise_fma(pair_hi(P.bt[pi]), f32x4{P.w[pi][3], P.w[pi][3], P.w[pi][3], P.w[pi][3]}, val);
-        xs[4 * pi + 0] = val.x; xs[4 * pi + 1] = val.y; xs[4 * pi + 2] = val.z; xs[4 * pi + 3] = val.w;
-    }
+// bilinear blend of position pi of a pair into xs[4 pi .. 4 pi + 3] (one multiply + three FMAs per channel)
+__device__ __forceinline__ void dcn_lerp_one(const DcnPair& P, int pi, float (&xs)[8]) {
+    f32x4 val = pair_lo(P.tp[pi]) * P.w[pi][0];
+    val = __builtin_elementwise_fma(pair_hi(P.tp[pi]), f32x4{P.w[pi][1], P.w[pi][1], P.w[pi][1], P.w[pi][1]}, val);
+    val = __builtin_elementwise_fma(pair_lo(P.bt[pi]), f32x4{P.w[pi][2], P.w[pi][2], P.w[pi][2], P.w[pi][2]}, val);
+    val = __builtin_elementwise_fma(pair_hi(P.bt[pi]), f32x4{P.w[pi][3], P.w[pi][3], P.w[pi][3], P.w[pi][3]}, val);
+    xs[4 * pi + 0] = val.x; xs[4 * pi + 1] = val.y; xs[4 * pi + 2] = val.z; xs[4 * pi + 3] = val.w;
+}
+
+// the sampled pair (8 values = one K = 16 step of the lane) split exactly into two fp16 terms and multiplied into the DCN sums
+__device__ __forceinline__ void dcn_split_mfma(const float (&xs)[8], f32x16& acc, f32x16& acl, const f32x4* wl, int u, int lane) {
     // the exact two-term split in its 3-op-per-value form (conv_mfma.hip split_f16x8_fast): one v_cvt_pk_f16_f32 per pair of
     // values, x - x0 as one v_fma_mix_f32, the scaled residuals through a second pack -- the same values as the scalar form
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -530,6 +531,13 @@ __device__ __forceinline__ void dcn_consume_pair(const DcnPair& P, f32x16& acc, 
     acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, acl, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, acc, 0, 0, 0);
     acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, acl, 0, 0, 0);
+}
+
+__device__ __forceinline__ void dcn_consume_pair(const DcnPair& P, f32x16& acc, f32x16& acl, const f32x4* wl, int u, int lane) {
+    float xs[8];
+    dcn_lerp_one(P, 0, xs);
+    dcn_lerp_one(P, 1, xs);
+    dcn_split_mfma(xs, acc, acl, wl, u, lane);
 }
 
 __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __restrict__ x, long long xb,
@@ -645,6 +653,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     __shared__ f32x4 wl[36 * 64];
     __shared__ f32x4 bl[DB ? 56 : 1];   // the head's 224 packed biases (NW = 8: LDS has room; NW = 4 keeps them in 4 VGPRs)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CRFP_PRIO47   // A/B builds: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(CRFP_PRIO47);
+#endif
     const int j = lane & 31, h = lane >> 5;
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * NW, n = blockIdx.z;
     const int H = a.H, W = a.W;
@@ -796,6 +807,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     }
 #define DF_C(U, P)                                                                                        \
     if (!(DF_PROBE & 1)) { dcn_consume_pair(P, acc, acl, wl, U, lane); }
+    // micro-items of the round-3 schedule (dcn_fused_schedule.inc): a quarter of a tile's activations, one position's coordinates +
+    // gathers, one position's blend, one pair's split + DCN MFMAs
+#define DF_TR(T, Q)                                                                                       \
+    {                                                                                                     \
+        _Pragma("unroll") for (int e = 4 * (Q); e < 4 * (Q) + 4; ++e) {                                   \
+            const int sl = 16 * (T) + e;                                                                  \
+            if (sl < 108)                                                                                 \
+                ov[sl] = sl % 3 == 0 ? tanh10_plus(ov[sl], cfy) : (sl % 3 == 1 ? tanh10_plus(ov[sl], cfx) : fast_sigmoid(ov[sl])); \
+        }                                                                                                 \
+    }
+#define DF_I1(U, PI, P)                                                                                   \
+    if (!(DF_PROBE & 1)) {                                                                                \
+        dcn_issue_one(P, PI, rx, ov[6 * (U) + 3 * (PI)] * pz, ov[6 * (U) + 3 * (PI) + 1] * pz, ov[6 * (U) + 3 * (PI) + 2], 2 * (U) + (PI), \
+                      fy0, fx0, fH, fW, PW, pitch, plane_b, hbase);                                       \
+    }
+#define DF_L(U, PI, P) if (!(DF_PROBE & 1)) { dcn_lerp_one(P, PI, xs); }
+#define DF_S(U) if (!(DF_PROBE & 1)) { dcn_split_mfma(xs, acc, acl, wl, U, lane); }
+    float xs[8];
+#ifdef CRFP_DF_SCHED_R2
     // Cout tile T completes the sampling pairs up to (16 T + 10) / 6: 1, 4, 7, 9, 12, 15, 17.  The pairs of tile T are sampled
     // INSIDE the two stages of tile T + 1, between its taps: the MFMA runs 32 clocks in its own pipe while the wave issues the
     // sampler's VALU work (coordinates, weights, bilinear FMAs, fp16 split: as many issue clocks per pixel as the MFMAs take),
@@ -821,8 +851,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     DF_BEGIN(6, 0) DF_TAPS(0, 0, 2) DF_TRANS(5) DF_SB DF_TAPS(0, 2, 4) DF_I(13, Q1) DF_SB DF_TAPS(0, 4, 7) DF_SB DF_C(12, Q0) DF_SB DF_TAPS(0, 7, 9) DF_I(14, Q0) DF_SB
     DF_BEGIN(6, 1) DF_TAPS(1, 0, 3) DF_SB DF_C(13, Q1) DF_SB DF_TAPS(1, 3, 6) DF_SB DF_C(14, Q0) DF_SB DF_TAPS(1, 6, 9) DF_I(15, Q1) DF_SB DF_RAW(6)
     DF_TRANS(6) DF_I(16, Q0) DF_SB DF_C(15, Q1) DF_SB DF_I(17, Q1) DF_SB DF_C(16, Q0) DF_SB DF_C(17, Q1)
+#else
+    // Round 3: ONE micro-item in front of EVERY tap instead of whole pairs between groups of 2-4 taps (tools/gen/dcn_fused_schedule.py
+    // holds the dependency rules and writes the table): <= ~30 vector instructions per 3 MFMAs, the regime in which
+    // tools/micro/mfma_valu_overlap2 shows the vector work disappearing in the MFMA gaps.  Same operations on the same values in
+    // the same per-accumulator order: bit-identical to the round-2 table (-DCRFP_DF_SCHED_R2) and to the two-kernel path.
+#ifdef CRFP_DF_SCHED_INC   // A/B builds: another run of the generator
+#include CRFP_DF_SCHED_INC
+#else
+#include "dcn_fused_schedule.inc"
+#endif
+#endif
 #undef DF_C
 #undef DF_I
+#undef DF_TR
+#undef DF_I1
+#undef DF_L
+#undef DF_S
 #undef DF_TAPS
 #undef DF_BEGIN
 #undef DF_WRITE

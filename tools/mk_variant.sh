@@ -11,10 +11,12 @@ SCHED="-mllvm -amdgpu-sched-strategy=max-memory-clause"
 [ "$base" = conv_mfma ] && SCHED="-mllvm -amdgpu-sched-strategy=max-ilp"
 [ "$base" = gather ] && SCHED=""
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops"
-/opt/rocm/bin/hipcc $FLAGS -DCRFP_LAB $SCHED $extra -c $C/$base.hip -o $ROOT/_ab/obj/$base.$name.o 2>&1 | grep -v "not a recognized feature" | grep -E "error|warning: fail" || true
+LABDEF="-DCRFP_LAB"; OBJDIR=build_lab
+if [ "${LAB:-1}" = 0 ]; then LABDEF=""; OBJDIR=build; fi   # LAB=0: a variant of the PRODUCT build (no lab switches compiled in)
+/opt/rocm/bin/hipcc $FLAGS $LABDEF $SCHED $extra -c $C/$base.hip -o $ROOT/_ab/obj/$base.$name.o 2>&1 | grep -v "not a recognized feature" | grep -E "error|warning: fail" || true
 objs=""
 for f in runtime conv_mfma conv_narrow gather resample metrics engine api spynet; do
-  if [ $f = $base ]; then objs="$objs $ROOT/_ab/obj/$base.$name.o"; else objs="$objs $C/build_lab/$f.o"; fi
+  if [ $f = $base ]; then objs="$objs $ROOT/_ab/obj/$base.$name.o"; else objs="$objs $C/$OBJDIR/$f.o"; fi
 done
 if [[ "$extra" == *CRFP_ACT_BF16_VARIANT* ]]; then echo "bf16 variants: build by hand"; fi
 for f in conv_mfma conv_narrow gather resample engine; do objs="$objs $C/build/$f.bf16.o"; done
