@@ -143,6 +143,7 @@ __device__ __forceinline__ void split_f16x4(const float (&x)[4], unsigned (&hi)[
 // selected per lane half) and preload the flow vectors of the lane's PT pixels (flpre, ST_OFFMASK).
 struct EpiCtx {
     int H, W, cout, ncq, act, store, n_off_quads, dstH, dstW, lr;
+    int xend;       // columns >= xend are not stored (W; the fused pair kernel's 62-column tiles end before their 64 computed columns)
     bool single;    // exactly one destination, starting at quad 0 and taking all of them
     long long* dbg; // diagnostic stamps (null in production)
     float slope, post;
@@ -161,6 +162,7 @@ struct EpiCtx {
 __device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
     EpiCtx e;
     e.H = a.H; e.W = a.W; e.cout = a.cout; e.act = a.act; e.store = a.store;
+    e.xend = a.W;
     e.ncq = (conv_packed_rows(a.cout, a.store, a.ps_r) + 3) >> 2;
     e.n_off_quads = a.n_off_quads; e.dstH = a.dstH; e.dstW = a.dstW;
     e.lr = a.ps_r == 4 ? 2 : 1;                           // ST_PS: r in {2, 4} (checked by the launcher)
@@ -221,7 +223,7 @@ __device__ __forceinline__ void conv_epilogue_t(const EpiCtx& e, f32x16 (&acc)[C
         if (pt == 1) d1 = __builtin_amdgcn_s_memtime();
 #endif
         const int y = ty0 + wave * RPW + (pt >> 1), x = tx0 + (pt & 1) * 32 + j;
-        if (y >= H || x >= W) continue;
+        if (y >= H || x >= e.xend) continue;
         float2 fl = make_float2(0.0f, 0.0f);
         if (STORE == ST_OFFMASK) fl = flpre ? flpre[pt] : *reinterpret_cast<const float2*>(e.flp + ((long long)y * W + x) * 2);
         float4 rr[CT][4];
@@ -1295,6 +1297,227 @@ __global__ __launch_bounds__(B8_NT, 2) void conv3x3_bf16x8_kernel(const ConvArgs
     const EpiCtx ec = epi_ctx(a, n);
     conv_epilogue<1, 2, 1, 2>(ec, acc, T0, tx0, ty0, wave, j, h);
 }
+
+// ---------------------------------------------------------------- bf16 storage: TWO 3x3 convs in one launch, the tensor between them in LDS
+// conv A (any sources, K in 16-channel chunks, 32 couts, bias + none / relu / lrelu) feeds conv B (32 -> 32) and has no other
+// reader: dcn_block.0 -> .2 and res conv1 -> conv2(+x) of every level (model/CRFP.py:331-333, 449-481).  Run separately each
+// of them is one round of 450 workgroups whose load / MFMA / store phases add up and the 14.7 MB tensor
+// between them is written and read back; here conv A is evaluated on the (8 + 2) x 64 region conv B's 8 x 62 output tile needs
+// (halo recompute: 20 pixel tiles of 32 per workgroup instead of 16, 3 + 2 per SIMD), rounded to bf16 exactly where the
+// two-kernel path stores it, zeroed outside the image (conv B's zero padding) and kept in LDS as conv B's B-operand image.
+// Same K order and per-accumulator accumulation order as conv3x3_bf16_kernel / conv3x3_bf16x8_kernel: identical values.
+// LDS 76.7 KB (two workgroups per CU): input chunk tile 25.3 KB (later conv B's 18.4 KB of weights), intermediate 42.2 KB,
+// conv A weight stage 9.2 KB.  45 x 11 = 495 workgroups for a 360 x 640 map = one round of the 512 slots.
+// (The fp32 build has no such kernel: its intermediate is two fp16 images = 84 KB, with the staging tile and the 27.6 KB
+// three-image weight stage 160 KB -- one 8-wave workgroup per CU and 1.9 rounds)
+constexpr int P2_NT = 512, P2_OW = 62, P2_IH = 10, P2_IW = 64, P2_LH = 12, P2_LW = 66;
+constexpr int P2_NEL = P2_LH * P2_LW, P2_NIN = (P2_NEL + P2_NT - 1) / P2_NT;   // 792 input halo pixels, 2 per thread
+constexpr int P2_MP = P2_IW + 2, P2_MEL = P2_IH * P2_MP;                       // intermediate rows of 64 + 2 zero columns
+constexpr int P2_WPC = 9 * 64, P2_NWS = (P2_WPC + P2_NT - 1) / P2_NT, P2_NWB = (2 * P2_WPC + P2_NT - 1) / P2_NT;
+
+struct PairB {          // what conv B adds to conv A's plan: its weights, bias, activation, destinations, residual
+    const void* wsplit16;
+    const float* bpk;
+    const float* resid;
+    long long resid_bstride;
+    ConvDst dst[CRFP_MAX_DST];
+    int ndst, cout, act;
+    float post_scale;
+};
+
+__global__ __launch_bounds__(P2_NT, 2) void conv3x3_bf16_pair_kernel(const ConvArgs a, const PairB b) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ u32x4_t tileA[2][P2_NEL];         // conv A: [quad pair][input halo pixel] of the current chunk; then conv B's weights
+    __shared__ u32x4_t mid[2][2][P2_MEL];        // conv A's output = conv B's input: [chunk][quad pair][pixel], 8 bf16 each
+    __shared__ bf16x8 wlds[P2_WPC];              // conv A: [tap][lane] of the current chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int tiles_x = (a.W + P2_OW - 1) / P2_OW;
+    const int btile = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int tx0 = (btile % tiles_x) * P2_OW, ty0 = (btile / tiles_x) * 8;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+
+    int cgy[P2_NIN], cgx[P2_NIN];
+    bool sval[P2_NIN];
+#pragma unroll
+    for (int t = 0; t < P2_NIN; ++t) {
+        const int idx = min(tid + P2_NT * t, P2_NEL - 1);
+        const int r = idx / P2_LW, c = idx - r * P2_LW;
+        const int gy = ty0 + r - 2, gx = tx0 + c - 2;
+        sval[t] = tid + P2_NT * t < P2_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        cgy[t] = min(max(gy, 0), H - 1);
+        cgx[t] = min(max(gx, 0), W - 1);
+    }
+    // the two zero columns behind each intermediate row (read by conv B's taps of the two discarded output columns)
+    if (tid < 4 * P2_IH * 2) {
+        const int pl = tid / (P2_IH * 2), rc = tid - pl * (P2_IH * 2);
+        (&mid[0][0][0])[pl * P2_MEL + (rc >> 1) * P2_MP + P2_IW + (rc & 1)] = u32x4_t{0u, 0u, 0u, 0u};
+    }
+
+    // conv A: wave w owns the 32-pixel tiles w, w + 8 (and w + 16 for w < 4) of the 10 x 64 region; tile t = row t >> 1, half t & 1
+    const int ntA = wave < 4 ? 3 : 2;
+    f32x16 accA[3];
+    {
+        const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bq = bp[2 * g + h];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                accA[k][4 * g + 0] = bq.x; accA[k][4 * g + 1] = bq.y; accA[k][4 * g + 2] = bq.z; accA[k][4 * g + 3] = bq.w;
+            }
+        }
+    }
+    const int nchunks = a.kq >> 2;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit16);
+    cu32x2 rq0[P2_NIN], rq1[P2_NIN], rq2[P2_NIN], rq3[P2_NIN];
+    bf16x8 rws[P2_NWS];
+    const float* qb0; const float* qb1; const float* qb2; const float* qb3;
+    int qrs0, qrs1, qrs2, qrs3, qcs0, qcs1, qcs2, qcs3, qm0 = 0, qm1 = 0, qm2 = 0, qm3 = 0;
+#define CRFP_QDESC(QB_, QRS, QCS, QM, QI, CH)                                                             \
+    {                                                                                                     \
+        const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
+        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+    }
+#define CRFP_P2_ISSUE(CH)                                                                                 \
+    {                                                                                                     \
+        CRFP_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) CRFP_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                   \
+        CRFP_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) CRFP_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                   \
+        _Pragma("unroll") for (int t = 0; t < P2_NIN; ++t) {                                              \
+            rq0[t] = *reinterpret_cast<const cu32x2*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);               \
+            rq1[t] = *reinterpret_cast<const cu32x2*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);               \
+            rq2[t] = *reinterpret_cast<const cu32x2*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);               \
+            rq3[t] = *reinterpret_cast<const cu32x2*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);               \
+        }                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < P2_NWS; ++k) {                                              \
+            const int idx = min(tid + P2_NT * k, P2_WPC - 1);                                             \
+            rws[k] = wp[(long long)(CH) * P2_WPC + idx];                                                  \
+        }                                                                                                 \
+    }
+    CRFP_P2_ISSUE(0)
+    bf16x8 rwb[P2_NWB];   // conv B's weights (both chunks), fetched under conv A's last chunk
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;
+        __syncthreads();  // every wave finished reading the previous chunk
+        if ((m0 & m1 & m2 & m3) == 15 && !((m0 | m1 | m2 | m3) & 32)) {   // wave-uniform: 16 real bf16 channels -> plain copy
+#pragma unroll
+            for (int t = 0; t < P2_NIN; ++t) {
+                const int idx = tid + P2_NT * t;
+                if (idx < P2_NEL) {
+                    const unsigned km = sval[t] ? 0xffffffffu : 0u;
+                    tileA[0][idx] = u32x4_t{rq0[t].x & km, rq0[t].y & km, rq1[t].x & km, rq1[t].y & km};
+                    tileA[1][idx] = u32x4_t{rq2[t].x & km, rq2[t].y & km, rq3[t].x & km, rq3[t].y & km};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < P2_NIN; ++t) {
+                const int idx = tid + P2_NT * t;
+                if (idx < P2_NEL) {
+                    const cu32x2 w0 = quad_words(rq0[t], m0, sval[t]), w1 = quad_words(rq1[t], m1, sval[t]);
+                    const cu32x2 w2 = quad_words(rq2[t], m2, sval[t]), w3 = quad_words(rq3[t], m3, sval[t]);
+                    tileA[0][idx] = u32x4_t{w0.x, w0.y, w1.x, w1.y};
+                    tileA[1][idx] = u32x4_t{w2.x, w2.y, w3.x, w3.y};
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < P2_NWS; ++k) {
+            const int idx = tid + P2_NT * k;
+            if (idx < P2_WPC) wlds[idx] = rws[k];
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) {
+            CRFP_P2_ISSUE(ch + 1)
+        } else {
+            const bf16x8* __restrict__ wb = reinterpret_cast<const bf16x8*>(b.wsplit16);
+#pragma unroll
+            for (int k = 0; k < P2_NWB; ++k) rwb[k] = wb[min(tid + P2_NT * k, 2 * P2_WPC - 1)];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const bf16x8 wa = wlds[tap * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k == 2 && ntA == 2) break;   // wave-uniform
+                const int t = wave + 8 * k;
+                const int pix = ((t >> 1) + ky) * P2_LW + (t & 1) * 32 + j + kx;
+                const bf16x8 bq = __builtin_bit_cast(bf16x8, tileA[h][pix]);
+                accA[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bq, accA[k], 0, 0, 0);
+            }
+        }
+    }
+#undef CRFP_P2_ISSUE
+#undef CRFP_QDESC
+    // conv A's epilogue into LDS: activation, zero outside the image, round to bf16 (what the two-kernel path stores), 8 bytes per
+    // (cout quad, pixel): channel 8 g + 4 h + r is position 4 h + r of the 8-channel element (chunk g >> 1, quad pair g & 1)
+    {
+        const float slope = a.act == CRFP_ACT_RELU ? 0.0f : (a.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+        const float post = a.post_scale;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k == 2 && ntA == 2) break;
+            const int t = wave + 8 * k, r = t >> 1, c = (t & 1) * 32 + j;
+            const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = accA[k][4 * g + e];
+                    v[e] = in ? fmaxf(x, slope * x) * post : 0.0f;
+                }
+                cu32x2* dst = reinterpret_cast<cu32x2*>(&mid[g >> 1][g & 1][r * P2_MP + c]) + h;
+                *dst = cu32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+    }
+    __syncthreads();   // conv A's last reads of tileA / wlds are done (and `mid` is on its way)
+    bf16x8* const wb_lds = reinterpret_cast<bf16x8*>(&tileA[0][0]);
+#pragma unroll
+    for (int k = 0; k < P2_NWB; ++k) {
+        const int idx = tid + P2_NT * k;
+        if (idx < 2 * P2_WPC) wb_lds[idx] = rwb[k];
+    }
+    f32x16 acc[1][2];
+    {
+        const float4* __restrict__ bp = reinterpret_cast<const float4*>(b.bpk);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bq = bp[2 * g + h];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                acc[0][pt][4 * g + 0] = bq.x; acc[0][pt][4 * g + 1] = bq.y; acc[0][pt][4 * g + 2] = bq.z; acc[0][pt][4 * g + 3] = bq.w;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const bf16x8 wa = wb_lds[c2 * P2_WPC + tap * 64 + lane];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int pix = (wave + ky) * P2_MP + pt * 32 + j + kx;
+                const bf16x8 bq = __builtin_bit_cast(bf16x8, mid[c2][h][pix]);
+                acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bq, acc[0][pt], 0, 0, 0);
+            }
+        }
+    // conv B's epilogue: the shared one, on conv B's destinations / residual / activation, 62 columns per tile
+    ConvArgs eb = a;
+    eb.cout = b.cout; eb.act = b.act; eb.post_scale = b.post_scale; eb.store = ST_Q4; eb.ps_r = 0;
+    eb.resid = b.resid; eb.resid_bstride = b.resid_bstride; eb.s3_dst = nullptr; eb.dst_f32 = 0; eb.ndst = b.ndst;
+#pragma unroll
+    for (int d = 0; d < CRFP_MAX_DST; ++d) eb.dst[d] = b.dst[d];
+    EpiCtx ec = epi_ctx(eb, n);
+    ec.xend = min(W, tx0 + P2_OW);
+    conv_epilogue<1, 2, 1, 2>(ec, acc, 0, tx0, ty0, wave, j, h);
+}
 #endif  // CRFP_ACT_BF16
 
 #ifdef CRFP_LAB   // experiments that lose to conv3x3_split_kernel<1,1,2>: built only into the lab library (make lab)
@@ -1983,6 +2206,7 @@ int launch_conv_pack(const ConvArgs& a, const float* w, const float* bias, const
 // call through ConvArgs::strict (CRFP_DSV_STRICT_F32 of the C-ABI) or for the whole process with CRFP_PRECISION=f32
 // (read once; CRFP_CONV_MODE=f32 / CRFP_DCN_MODE=f32 of round 1 still work).
 #ifndef CRFP_ACT_BF16
+
 }  // namespace CRFP_NS
 namespace crfp {
 bool precision_env_strict(const char* legacy_knob) {
@@ -2015,6 +2239,46 @@ bool conv_s3_supported() {
 }
 
 static bool uses_s3_dst_only_4wave(const ConvArgs&) { return false; }   // the shared epilogue writes S3 images from either kernel
+
+// per-quad load descriptors (wave-uniform in the kernels: one s_load per quad); filled into the caller's private plan copy
+static int build_quad_descs(ConvArgs& am, const char* name) {
+    const ConvArgs& a = am;
+    {
+        int q = 0;
+        for (int i = 0; i < a.nsrc; ++i)
+            for (int k = 0; k < a.src[i].nq; ++k, ++q) {
+                const ConvSrc& sr = a.src[i];
+                QuadDesc& d = am.qd[q];
+                d.bstride = sr.bstride; d.rsv = 0;
+                // strides and offsets are in FLOATS (4 bytes) for both builds: an activation quad spans kQuadBytes / 4 of them
+                constexpr int QF = kQuadBytes / 4;
+                if (sr.kind == SRC_Q4) {
+                    d.bstride = sr.bstride * (long long)sizeof(act_t) / 4;
+                    d.rs = (a.W + sr.pad) * QF; d.cs = QF; d.mask = 15;
+                    d.base = sr.p + (long long)k * (a.H + sr.pad) * d.rs;
+                } else if (sr.kind == SRC_UNSHUF4) {
+                    const int W4 = 4 * a.W + sr.pad, ij = k & 15;
+                    d.bstride = sr.bstride * (long long)sizeof(act_t) / 4;
+                    d.rs = 4 * W4 * QF; d.cs = 4 * QF; d.mask = 15;
+                    d.base = sr.p + ((long long)(k >> 4) * (4 * a.H + sr.pad) * W4 + (ij >> 2) * W4 + (ij & 3)) * QF;
+                } else if (sr.kind == SRC_FLOW2) {
+                    d.rs = 2 * a.W; d.cs = 2; d.mask = kActBf16 ? (32 | 3) : 3; d.base = sr.p;   // bit 5: fp32 (dx, dy) pair
+                } else if (sr.kind == SRC_S3) {
+                    // chunk-local quad qi -> 16-byte plane: qi 0/1 = x0 image, channels 0..7 / 8..15 of the chunk; qi 2/3 = x1s image
+                    if ((q & 3) != (k & 3) || (sr.nq & 3) || sr.pad) {
+                        set_error("conv_mfma %s: an SRC_S3 source must start on a 16-channel chunk, hold whole chunks and be unpadded", name);
+                        return CRFP_E_BADARG;
+                    }
+                    const int qi = k & 3, plane = (qi >> 1) * (sr.nq >> 1) + 2 * (k >> 2) + (qi & 1);
+                    d.rs = a.W * 4; d.cs = 4; d.mask = 16 | 15;
+                    d.base = sr.p + (long long)plane * a.H * d.rs;
+                } else {
+                    d.rs = 0; d.cs = 0; d.mask = 0; d.base = a.wpk; d.bstride = 0;
+                }
+            }
+    }
+    return 0;
+}
 
 int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     if (a.kq & 1 || a.kq < 2 || a.ctiles < 1 || a.nsrc < 1 || a.nsrc > CRFP_MAX_SRC) {
@@ -2065,39 +2329,9 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     am.wsplit_sa = a.wsplit ? (const char*)a.wsplit + conv_split_sa_offset_bytes(a) : nullptr;
 #endif
     if (env_strict || a.strict) am.ovf = nullptr;   // nothing downstream turns this output into an fp16 operand
-    if (a.kq <= CRFP_MAX_KQ) {  // per-quad load descriptors (wave-uniform in the kernel: one s_load per quad)
-        int q = 0;
-        for (int i = 0; i < a.nsrc; ++i)
-            for (int k = 0; k < a.src[i].nq; ++k, ++q) {
-                const ConvSrc& sr = a.src[i];
-                QuadDesc& d = am.qd[q];
-                d.bstride = sr.bstride; d.rsv = 0;
-                // strides and offsets are in FLOATS (4 bytes) for both builds: an activation quad spans kQuadBytes / 4 of them
-                constexpr int QF = kQuadBytes / 4;
-                if (sr.kind == SRC_Q4) {
-                    d.bstride = sr.bstride * (long long)sizeof(act_t) / 4;
-                    d.rs = (a.W + sr.pad) * QF; d.cs = QF; d.mask = 15;
-                    d.base = sr.p + (long long)k * (a.H + sr.pad) * d.rs;
-                } else if (sr.kind == SRC_UNSHUF4) {
-                    const int W4 = 4 * a.W + sr.pad, ij = k & 15;
-                    d.bstride = sr.bstride * (long long)sizeof(act_t) / 4;
-                    d.rs = 4 * W4 * QF; d.cs = 4 * QF; d.mask = 15;
-                    d.base = sr.p + ((long long)(k >> 4) * (4 * a.H + sr.pad) * W4 + (ij >> 2) * W4 + (ij & 3)) * QF;
-                } else if (sr.kind == SRC_FLOW2) {
-                    d.rs = 2 * a.W; d.cs = 2; d.mask = kActBf16 ? (32 | 3) : 3; d.base = sr.p;   // bit 5: fp32 (dx, dy) pair
-                } else if (sr.kind == SRC_S3) {
-                    // chunk-local quad qi -> 16-byte plane: qi 0/1 = x0 image, channels 0..7 / 8..15 of the chunk; qi 2/3 = x1s image
-                    if ((q & 3) != (k & 3) || (sr.nq & 3) || sr.pad) {
-                        set_error("conv_mfma %s: an SRC_S3 source must start on a 16-channel chunk, hold whole chunks and be unpadded", name);
-                        return CRFP_E_BADARG;
-                    }
-                    const int qi = k & 3, plane = (qi >> 1) * (sr.nq >> 1) + 2 * (k >> 2) + (qi & 1);
-                    d.rs = a.W * 4; d.cs = 4; d.mask = 16 | 15;
-                    d.base = sr.p + (long long)plane * a.H * d.rs;
-                } else {
-                    d.rs = 0; d.cs = 0; d.mask = 0; d.base = a.wpk; d.bstride = 0;
-                }
-            }
+    if (a.kq <= CRFP_MAX_KQ) {
+        const int rc = build_quad_descs(am, name);
+        if (rc) return rc;
     }
 #ifdef CRFP_LAB
     const bool use_f16 = strcmp(lab_conv_mode(), "bf16x6") != 0;
@@ -2199,5 +2433,44 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     CRFP_CHECK_LAUNCH();
     return 0;
 }
+
+
+#ifdef CRFP_ACT_BF16
+// conv A -> conv B in one launch (conv3x3_bf16_pair_kernel); both plans as launch_conv_mfma takes them.  Conv A's output tensor is
+// never written: it must have no other reader.
+int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, const char* name, hipStream_t s) {
+    if ((a.kq & 3) || a.kq > CRFP_MAX_KQ || a.ctiles != 1 || a.cout != 32 || a.store != ST_Q4 || !a.wsplit || a.act == CRFP_ACT_TANH ||
+        a.act == CRFP_ACT_SIGMOID || b.nsrc != 1 || b.src[0].kind != SRC_Q4 || b.kq != 8 || b.ctiles != 1 || b.cout != 32 || b.store != ST_Q4 ||
+        !b.wsplit || b.act == CRFP_ACT_TANH || b.act == CRFP_ACT_SIGMOID || b.s3_dst || b.dst_f32 || a.N != b.N || a.H != b.H || a.W != b.W) {
+        set_error("conv_pair %s: unsupported pair (A: kq=%d cout=%d store=%d; B: nsrc=%d kq=%d cout=%d store=%d)", name, a.kq, a.cout, a.store,
+                  b.nsrc, b.kq, b.cout, b.store);
+        return CRFP_E_UNSUPPORTED;
+    }
+    for (int i = 0; i < a.nsrc; ++i)
+        if (a.src[i].kind == SRC_NCHW || a.src[i].kind == SRC_S3) { set_error("conv_pair %s: NCHW / S3 sources are not supported", name); return CRFP_E_UNSUPPORTED; }
+    const double px = (double)a.N * a.H * a.W;
+    double in_ch = 0;
+    for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].kind == SRC_ZERO ? 0 : a.src[i].nch;
+    // algorithmic work of the PAIR: A's inputs + B's outputs (+ residual) cross HBM, the 32-channel tensor between them does not
+    ProfScope prof(name, s, px * (in_ch + 32 + (b.resid ? 32 : 0)) * (double)sizeof(act_t) + (32.0 * in_ch + 32.0 * 32.0) * 9 * 4.0,
+                   2.0 * px * 32 * (in_ch + 32) * 9.0);
+    ConvArgs am = a;
+    am.stamps = nullptr;
+    am.wsplit16 = (const char*)a.wsplit + conv_split16_offset_bytes(a);
+    const int rc = build_quad_descs(am, name);
+    if (rc) return rc;
+    PairB pb;
+    memset(&pb, 0, sizeof(pb));
+    pb.wsplit16 = (const char*)b.wsplit + conv_split16_offset_bytes(b);
+    pb.bpk = b.bpk; pb.resid = b.resid; pb.resid_bstride = b.resid_bstride;
+    for (int d = 0; d < CRFP_MAX_DST; ++d) pb.dst[d] = b.dst[d];
+    pb.ndst = b.ndst; pb.cout = b.cout; pb.act = b.act; pb.post_scale = b.post_scale;
+    am.ovf = b.ovf;
+    const int tiles = ((a.W + P2_OW - 1) / P2_OW) * ((a.H + 7) / 8);
+    conv3x3_bf16_pair_kernel<<<dim3(tiles, 1, a.N), P2_NT, 0, s>>>(am, pb);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+#endif
 
 }  // namespace CRFP_NS

@@ -305,6 +305,10 @@ size_t conv_packed_weight_floats(const ConvArgs& a);
 int launch_conv_pack(const ConvArgs& a, const float* w_oihw, const float* bias, const float* w2, const float* bias2,
                      int cout_split, float* wpk, float* bpk, hipStream_t s);
 int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s);
+#ifdef CRFP_ACT_BF16
+// bf16 build: conv a (32 couts, no other reader of its output) feeding conv b (32 -> 32) in ONE launch, the tensor between them in LDS
+int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, const char* name, hipStream_t s);
+#endif
 size_t conv_split_weight_bytes(const ConvArgs& a);
 size_t conv_split16_offset_bytes(const ConvArgs& a);   // offset of the fp16 pair (bf16 build: the bf16) image inside the split weight block
 int launch_conv_pack_split(const ConvArgs& a, const float* w_oihw, const float* w2, int cout_split, void* wsplit,

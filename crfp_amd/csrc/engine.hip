@@ -467,6 +467,38 @@ struct Runner {
         a.strict = strict;
         rc = launch_conv_mfma(a, it.name, s);
     }
+    // fills the per-launch fields of a packed MFMA item's plan (what mfma() passes to launch_conv_mfma)
+    ConvArgs bind(int id, int N, int H, int W, const std::vector<SrcBind>& srcs, const std::vector<DstBind>& dsts, const float* resid = nullptr,
+                  const float* flow = nullptr) const {
+        const Item& it = M.items[id];
+        ConvArgs a = it.c;
+        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i].p; a.src[i].bstride = srcs[i].bs; a.src[i].pad = srcs[i].pad; }
+        a.ndst = (int)dsts.size();
+        for (size_t i = 0; i < dsts.size(); ++i) {
+            a.dst[i].p = dsts[i].p; a.dst[i].bstride = dsts[i].bs; a.dst[i].q0 = dsts[i].q0; a.dst[i].q1 = dsts[i].q1;
+            a.dst[i].pad = dsts[i].pad;
+        }
+        a.N = N; a.H = H; a.W = W;
+        a.resid = resid; a.flow = flow;
+        a.wpk = packed + it.off_w; a.bpk = packed + it.off_b; a.wsplit = packed + it.off_s;
+        a.ovf = ovf();
+        a.strict = strict;
+        return a;
+    }
+#ifdef CRFP_ACT_BF16
+    // conv idA -> conv idB in one launch (conv3x3_bf16_pair_kernel): idA's output has no other reader and is never written
+    void mfma_pair(int idA, int idB, const char* name, int H, int W, std::vector<SrcBind> srcsA, std::vector<DstBind> dstsB,
+                   const float* residB = nullptr) {
+        if (rc) return;
+        const ConvArgs a = bind(idA, 1, H, W, srcsA, {}), b = bind(idB, 1, H, W, {{nullptr, 0}}, dstsB, residB);
+        rc = launch_conv_pair(a, b, name, s);
+    }
+#endif
+    // which 2x-resolution conv pairs run as one launch: bf16 storage only (the fp32 build's intermediate does not fit LDS, conv_mfma.hip)
+    static bool pair_convs() {
+        static const bool on = kActBf16 && !(getenv("CRFP_CONV_PAIR") && atoi(getenv("CRFP_CONV_PAIR")) == 0);   // read once
+        return on;
+    }
     // plain Q4 -> Q4 conv on whole tensors
     void mfma_q(int id, int N, const Q4& in, const Q4& out) {
         mfma(id, N, in.H, in.W, {{in.p, in.bs()}}, {{out.p, out.bs(), 0, out.nq}});
@@ -562,6 +594,20 @@ struct Runner {
         mfma_q(IT_ENC_LR1, n, e0, x);
     }
 
+    // ResidualBlockNoBN of level l (model/CRFP.py:449-481): y0 + conv2(relu(conv1(y0))), the 32 output channels going to the
+    // propagated features (24) and the carried ones (8).  bf16 build: one launch, conv1's output stays in LDS.
+    void res_block(int l, float* prop_next, float* carry_l, int H2, int W2) {
+#ifdef CRFP_ACT_BF16
+        if (pair_convs()) {
+            mfma_pair(it_lvl(l, L_RB1), it_lvl(l, L_RB2), "conv_mfma_pair:res.conv1_conv2_add", H2, W2, {{F(L.y0), 0}},
+                      {{prop_next, 0, 0, 6}, {carry_l, 0, 6, 8, 1}}, F(L.y0));
+            return;
+        }
+#endif
+        mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
+        mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry_l, 0, 6, 8, 1}}, 0, 0, F(L.y0), 0);
+    }
+
     // one iteration of the recurrent loop (reference model/CRFP.py:1555-1684)
     // state-independent part of a frame (reference model/CRFP.py:1538-1547,1560,1565-1566): buffer set `par`
     // before_ups: event this stream waits for right before the upsample conv, the only consumer of x_lr here (clip
@@ -607,15 +653,24 @@ struct Runner {
             if (fg) RUN(crfp::launch_fg_prep(fg, F(L.fg2), H8, W8, s));
             for (int l = 0; l < 3; ++l) {
                 const float* cw = adv(F(L.carryw), 2 * l * P2q);
-                mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
-                     {{F(L.fa), 0, 0, 8}});
                 float* f = F(L.offfeat[l]);
                 const bool s3 = M.use_s3;   // f holds the SRC_S3 image (same size) instead of fp32 Q4
+#ifdef CRFP_ACT_BF16
+                if (pair_convs())   // dcn_block.0 -> .2 in one launch, the 32-channel tensor between them stays in LDS
+                    mfma_pair(it_lvl(l, L_DB0), it_lvl(l, L_DB1), "conv_mfma_pair:dcn.block0_block2", H2, W2,
+                              {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}}, {{l == 0 ? f : F(L.fb), 0, 0, 8}});
+                else
+#endif
+                {
+                mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
+                     {{F(L.fa), 0, 0, 8}});
                 if (l == 0) {
                     if (s3) mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, 0);
                     else mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{f, 0, 0, 8}});
-                } else {
+                } else
                     mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{F(L.fb), 0, 0, 8}});
+                }
+                if (l > 0) {
                     if (s3) mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, 0);
                     else mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {{f, 0, 0, 8}});
                 }
@@ -643,9 +698,7 @@ struct Runner {
                     mfma(it_lvl(l, L_RB0), 1, H2, W2, {{F(L.sc_prop), 0}, {F(L.sc_cw), 0}, {F(L.sc_al), 0}}, {{F(L.y0), 0, 0, 8}});
                 } else
                     mfma(it_lvl(l, L_RB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.aligned), 0}}, {{F(L.y0), 0, 0, 8}});
-                mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
-                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {adv(carry, 2 * l * P2qp), 0, 6, 8, 1}}, 0, 0,
-                     F(L.y0), 0);
+                res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2);
                 prop = prop_next;
                 std::swap(prop_next, prop_other);
                 offprev = f;
@@ -682,9 +735,7 @@ struct Runner {
         } else {
             for (int l = 0; l < 3; ++l) {
                 mfma(it_lvl(l, L_RB0F), 1, H2, W2, {{prop, 0}, {nullptr, 0}}, {{F(L.y0), 0, 0, 8}});
-                mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
-                mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {adv(carry, 2 * l * P2qp), 0, 6, 8, 1}}, 0, 0,
-                     F(L.y0), 0);
+                res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2);
                 prop = prop_next;
                 std::swap(prop_next, prop_other);
             }

@@ -274,3 +274,23 @@ def test_overflow_flag_covers_every_clip_of_a_batch_and_fresh_workspaces():
     assert not m.engine().overflowed()
     m.compute_flow(torch.cat([lrs[1:], lrs[1:, :1]], 1))            # 3 frames: another workspace shape, freshly allocated
     assert not m.engine().overflowed()
+
+
+# ------------------------------------------------------------------------------------------------ round-3 kernels
+def test_bf16_fused_conv_pairs_are_bit_identical():
+    """bf16 build: dcn_block.0 -> .2 and res conv1 -> conv2(+x) of every level run as ONE launch each with the tensor between the
+    two convolutions kept in LDS (conv3x3_bf16_pair_kernel: 62-column tiles, halo recompute, bf16 rounding of the intermediate
+    exactly where the two-kernel path stores it).  Same arithmetic in the same order: the clip must not change by a bit --
+    on the golden clip (two 62-column tiles per row, ragged last one) and at the real 180 x 320 geometry."""
+    from test_gpu_parity import _golden_check
+    a = _golden_check({"CRFP_CHECK_STORAGE": "bf16"}, want="DIGEST")
+    b = _golden_check({"CRFP_CHECK_STORAGE": "bf16", "CRFP_CONV_PAIR": "0"}, want="DIGEST")
+    assert a == b
+    tool = os.path.join(ROOT, "tools", "ab_sites.py")
+    r = subprocess.run([sys.executable, tool, "--storage", "bf16", "--rounds", "1", "--steps", "1", "--t", "3", "--sites", "pair",
+                        "pair=", "single=CRFP_CONV_PAIR=0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = {ln.split()[0]: ln for ln in r.stdout.splitlines() if " digest " in ln}
+    assert set(lines) == {"pair", "single"}, r.stdout + r.stderr[-2000:]
+    dig = {k: v.split(" digest ")[1].split()[0] for k, v in lines.items()}
+    assert dig["pair"] == dig["single"], lines
+    assert "conv_mfma_pair" in lines["pair"] and "conv_mfma_pair" not in lines["single"]
