@@ -182,10 +182,14 @@ struct Model {
                                      "conv_mfma:fnet.dec1a", "conv_mfma:fnet.dec1b", "conv_mfma:fnet.dec2a",
                                      "conv_mfma:fnet.dec2b", "conv_mfma:fnet.dec3a", "conv_mfma:fnet.dec3b",
                                      "conv_mfma:fnet.flow0", "conv_mfma:fnet.flow2"};
-        add_mfma(IT_F0, fn[0], 0, -1, {{SRC_NCHW, 3}, {SRC_NCHW, 3}}, ST_Q4, 0, CRFP_ACT_RELU);
+        // The LR frames enter as Q4 quads of 3 channels (fp32 build: one tiny NCHW -> Q4 pass per call, Runner::lr_to_q4): a cin = 3 / 6
+        // NCHW source kept these two first layers on the fp32 MFMA (64 + 42 us per clip against ~20 + ~15 on the split-fp16 kernels).
+        // The bf16 build reads the fp32 NCHW frames directly: a Q4 copy there would be bf16, i.e. a rounded INPUT.
+        const int LRK = kActBf16 ? (int)SRC_NCHW : (int)Q;
+        add_mfma(IT_F0, fn[0], 0, -1, {{LRK, 3}, {LRK, 3}}, ST_Q4, 0, CRFP_ACT_RELU);
         for (int i = 1; i < 13; ++i) add_mfma(IT_F0 + i, fn[i], i, -1, {{Q, kConvs[i].cin}}, ST_Q4, 0, CRFP_ACT_RELU);
         add_mfma(IT_F0 + 13, fn[13], 13, -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_TANH, 256.0f);
-        add_mfma(IT_ENC_LR0, "conv_mfma:enc_lr0", CI_ENC_LR0, -1, {{SRC_NCHW, 3}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+        add_mfma(IT_ENC_LR0, "conv_mfma:enc_lr0", CI_ENC_LR0, -1, {{LRK, 3}}, ST_Q4, 0, CRFP_ACT_LRELU01);
         add_mfma(IT_ENC_LR1, "conv_mfma:enc_lr1", CI_ENC_LR1, -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_LRELU01);
         add_mfma(IT_UPS, "conv_mfma:upsample_ps2", CI_UPS, -1, {{Q, 32}}, ST_PS, 2, CRFP_ACT_NONE);
         add_mfma(IT_DOWN, "conv_mfma:downsample_unshuf4", CI_DOWN, -1, {{SRC_UNSHUF4, 64}}, ST_Q4, 0, CRFP_ACT_NONE);
@@ -299,7 +303,7 @@ struct Layout {
     // status word (fp16-operand overflow flag), then the persistent recurrent state (stable offsets for streaming)
     size_t status, state_hr, carry;
     // clip-level
-    size_t flow_lr, e_lr0, x_lr;
+    size_t flow_lr, e_lr0, x_lr, lr_q4;
     // FNet
     size_t fa0, fa1, fp1, fb0, fb1, fp2, fc0, fc1, fp3, fd0, fd1, fu1, fe0, fe1, fu2, ff0, ff1, fu3, fg0, fg1;
     // frame-level
@@ -315,6 +319,7 @@ struct Layout {
         state_hr = A.take("state_hr", 1, 1, H8, W8, 0, 1);
         carry = A.take("carry", 1, 6, H2, W2, 0, 1);
         flow_lr = A.take("flow_lr", nb, 1, h, w, 0, 0, true);
+        lr_q4 = A.take("lr_q4", 2 * t, 1, h, w);   // the LR frames as quads: [0, t) current frames, [t, 2t) previous frames when they are not the same tensor
         e_lr0 = A.take("enc_lr0", t, 8, h, w);
         x_lr = A.take("x_lr", t, 8, h, w);
         fa0 = A.take("fnet.a0", nb, 8, h, w);
@@ -541,9 +546,19 @@ struct Runner {
     static constexpr int pair_mask() { return kActBf16 ? 0 : 4; }
 #define RUN(expr) do { if (!rc) rc = (expr); } while (0)
 
-    // FNet over nb pairs (reference model/CRFP.py:797-814); cur/prev are NCHW 3-channel frames
+    // fp32 build: n NCHW LR frames -> Q4 quads in slot s0.. of lr_q4 (see the Model); the bf16 build reads the fp32 frames directly
+    const float* lr_to_q4(const float* lrs, int n, int s0) {
+        if (kActBf16) return lrs;
+        float* dst = adv(F(L.lr_q4), (long long)s0 * L.h * L.w * 4);
+        RUN(launch_nchw_to_q4(lrs, dst, n, 3, L.h, L.w, 0, s));
+        return dst;
+    }
+    long long lr_bs(long long nchw_bs) const { return kActBf16 ? nchw_bs : (nchw_bs ? (long long)L.h * L.w * 4 : 0); }
+
+    // FNet over nb pairs (reference model/CRFP.py:797-814); cur/prev: 3-channel frames as lr_to_q4 returns them (bs: NCHW batch stride)
     void fnet(int nb, const float* cur, long long cur_bs, const float* prev, long long prev_bs) {
         const int h = L.h, w = L.w;
+        cur_bs = lr_bs(cur_bs); prev_bs = lr_bs(prev_bs);
         Q4 a0 = q(L.fa0, 8, h, w), a1 = q(L.fa1, 8, h, w), p1 = q(L.fp1, 8, L.h1, L.w1);
         Q4 b0 = q(L.fb0, 16, L.h1, L.w1), b1 = q(L.fb1, 16, L.h1, L.w1), p2 = q(L.fp2, 16, L.h2, L.w2);
         Q4 c0 = q(L.fc0, 32, L.h2, L.w2), c1 = q(L.fc1, 32, L.h2, L.w2), p3 = q(L.fp3, 32, L.h3, L.w3);
@@ -588,9 +603,9 @@ struct Runner {
         }
     }
 
-    void encode_lr(int n, const float* lrs, long long bs) {
+    void encode_lr(int n, const float* lrs, long long bs) {   // lrs as lr_to_q4 returns them
         Q4 e0 = q(L.e_lr0, 8, L.h, L.w), x = q(L.x_lr, 8, L.h, L.w);
-        mfma(IT_ENC_LR0, n, L.h, L.w, {{lrs, bs}}, {{e0.p, e0.bs(), 0, 8}});
+        mfma(IT_ENC_LR0, n, L.h, L.w, {{lrs, lr_bs(bs)}}, {{e0.p, e0.bs(), 0, 8}});
         mfma_q(IT_ENC_LR1, n, e0, x);
     }
 
@@ -868,8 +883,10 @@ int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* 
     if (!ssp) {
         // single-stream schedule (also used while per-kernel timing is on: events bracket launches per stream)
         R.reset_state();
-        if (t > 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
-        R.encode_lr(t, lrs, lr_f);
+        const float* lq = R.lr_to_q4(lrs, t, 0);
+        const long long lq_f = kActBf16 ? lr_f : (long long)h * w * 4 * (long long)sizeof(act_t) / 4;   // floats between frames
+        if (t > 1) R.fnet(t - 1, lq + lq_f, lr_f, lq, lr_f);
+        R.encode_lr(t, lq, lr_f);
         for (int i = 0; i < t && !R.rc; ++i) {
             R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
                         i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.adv(R.F(L.x_lr), i * xq));
@@ -893,10 +910,12 @@ int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* 
     // the status word and the recurrent state are cleared BEFORE the fork: the side stream's first kernel (frame 0's fovea
     // blend) may raise the overflow bit, and a memset racing with it on the other stream could wipe that
     R.reset_state();
+    const float* lq = R.lr_to_q4(lrs, t, 0);   // before the fork: FNet on the side stream reads it as well
+    const long long lq_f = kActBf16 ? lr_f : (long long)h * w * 4 * (long long)sizeof(act_t) / 4;
     if (R.rc) return R.rc;
     if (hipEventRecord(ev_start, main_s) != hipSuccess || hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
     forked = true;
-    R.encode_lr(t, lrs, lr_f);
+    R.encode_lr(t, lq, lr_f);
     if (hipEventRecord(ev_xlr, main_s) != hipSuccess) return fail("record");
     for (int i = 0; i < t && !R.rc; ++i) {
         hipEvent_t pre_done = ss.event(2 + 2 * i), main_done = ss.event(3 + 2 * i);
@@ -905,7 +924,7 @@ int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* 
         R.s = ss.s;
         // FNet (all pairs, 0.7 ms) goes BEHIND frame 0's pre-work: frame 0 needs no flow, and with FNet first the caller's
         // stream sat idle for FNet + pre(0) at the start of every clip.  It now runs beside frame 0's recurrent part.
-        if (i == 1) R.fnet(t - 1, lrs + lr_f, lr_f, lrs, lr_f);
+        if (i == 1) R.fnet(t - 1, lq + lq_f, lr_f, lq, lr_f);
         if (i >= 2 && hipStreamWaitEvent(ss.s, ss.event(3 + 2 * (i - 2)), 0) != hipSuccess) return fail("wait");
         R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
                     i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.adv(R.F(L.x_lr), i * xq), i == 0 ? ev_xlr : nullptr);
@@ -935,8 +954,9 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     hipStream_t main_s = (hipStream_t)stream;
     if (!ssp) {
         if (first) R.reset_state();
-        if (!first) R.fnet(1, lr, 0, lr_prev, 0);
-        R.encode_lr(1, lr, 0);
+        const float* lq = R.lr_to_q4(lr, 1, 0);
+        if (!first) R.fnet(1, lq, 0, R.lr_to_q4(lr_prev, 1, 1), 0);
+        R.encode_lr(1, lq, 0);
         R.frame_pre(0, first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr));
         R.frame(0, first != 0, lr, mk, out, fg);
         return R.rc;
@@ -953,13 +973,15 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     auto fail = [&](const char* what) { join(); set_error("dsv_stream_frame: %s failed", what); return 1; };
     hipEvent_t ev_start = ss.event(0), ev_side = ss.event(1);
     if (!ss.ok) return fail("hipEventCreate");
+    const float* lq = R.lr_to_q4(lr, 1, 0);   // before the fork: read on both streams
+    const float* lqp = R.lr_to_q4(lr_prev, 1, 1);
     if (hipEventRecord(ev_start, main_s) != hipSuccess) return fail("record");
-    R.fnet(1, lr, 0, lr_prev, 0);
+    R.fnet(1, lq, 0, lqp, 0);
     R.frame_pre(0, false, lr, fv, mk, R.F(L.flow_lr), R.F(L.x_lr), nullptr, 2);
     R.s = ss.s;
     if (hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
     forked = true;
-    R.encode_lr(1, lr, 0);
+    R.encode_lr(1, lq, 0);
     R.frame_pre(0, false, lr, fv, mk, nullptr, R.F(L.x_lr), nullptr, 1);
     if (hipEventRecord(ev_side, ss.s) != hipSuccess) return fail("record");
     R.s = main_s;
@@ -983,7 +1005,7 @@ int CRFP_API(crfp_fnet_forward)(const void* packed, const float* cur, const floa
     if (rc) return rc;
     if (!cur || !prev || !flow) { set_error("fnet_forward: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(0), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
-    R.fnet(n, cur, 3LL * h * w, prev, 3LL * h * w);
+    R.fnet(n, R.lr_to_q4(cur, n, 0), 3LL * h * w, R.lr_to_q4(prev, n, n + 1), 3LL * h * w);
     if (!R.rc) R.rc = crfp::launch_q4_to_nchw(R.F(L.flow_lr), flow, n, 2, h, w, 0, (hipStream_t)stream);
     return R.rc;
 }

@@ -44,7 +44,10 @@ class PixelShufflePack(nn.Module):
         self.upsample_conv = nn.Conv2d(in_channels, out_channels * scale_factor * scale_factor, 3, padding=1)
 
     def forward(self, x):
-        return torch.nn.functional.pixel_shuffle(_run(self.upsample_conv, x), self.scale_factor)
+        c = self.upsample_conv
+        if self.scale_factor in (2, 4):   # F.pixel_shuffle (model/CRFP.py:192) fused into the conv's store
+            return ops.conv3x3_ex(x, c.weight, c.bias, shuffle=self.scale_factor)
+        return torch.nn.functional.pixel_shuffle(_run(c, x), self.scale_factor)
 
 
 class PixelUnShufflePack_v2(nn.Module):
@@ -56,7 +59,10 @@ class PixelUnShufflePack_v2(nn.Module):
         self.downsample_conv = nn.Conv2d(in_channels * scale_factor * scale_factor, out_channels, 3, padding=1)
 
     def forward(self, x):
-        return _run(self.downsample_conv, pixel_unshuffle(x, self.scale_factor))
+        c = self.downsample_conv
+        if self.scale_factor == 4 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0:   # pixel_unshuffle (:28-42) fused into the conv's load
+            return ops.conv3x3_ex(x, c.weight, c.bias, unshuffle=4)
+        return _run(c, pixel_unshuffle(x, self.scale_factor))
 
 
 class DCN_module(nn.Module):
@@ -104,17 +110,22 @@ class DCN_module(nn.Module):
             weight[d, d, kh // 2, kw // 2] = 1.0
 
     def forward(self, cur_x, pre_x, pre_x_aligned, flow, pre_offset=None):
-        f = torch.cat([cur_x, pre_x_aligned, flow], dim=1)
-        f = _run(self.dcn_block[2], _run(self.dcn_block[0], f, "lrelu"), "lrelu")
+        # torch.cat (model/CRFP.py:331,336) -> two-input convs (cur_x | [pre_x_aligned | flow]; f | pre_offset)
+        b0, b2 = self.dcn_block[0], self.dcn_block[2]
+        f = ops.conv3x3_ex(cur_x, b0.weight, b0.bias, x2=torch.cat([pre_x_aligned, flow], dim=1), act="lrelu")
+        f = _run(b2, f, "lrelu")
         if torch.is_tensor(pre_offset):
             if self.interpolate == 'pixelshuffle':
                 pre_offset = self.upsample(pre_offset) * 2.
             elif self.interpolate == 'bilinear':
                 pre_offset = ops.upsample_bilinear(pre_offset, scale_factor=4, mul=2.0)
-            f = _run(self.conv_fuse, torch.cat([f, pre_offset], dim=1), "lrelu")
+            f = ops.conv3x3_ex(f, self.conv_fuse.weight, self.conv_fuse.bias, x2=pre_offset, act="lrelu")
         offset = _run(self.dcn_offset, f, "tanh", float(self.max_residue_magnitude))
         mask = _run(self.dcn_mask, f, "sigmoid")
         flow_yx = flow.flip(1)
+        if self.repeat and self.dg_num == 1 and self.mid_channels == 4 and isinstance(self.dcn, DCNv2):
+            # one (dy, dx) and one mask per pixel for all 9 taps (:341-347): never tiled 9x (crfp_dcnv2_shared_f32)
+            return ops.dcnv2_shared(pre_x, offset + flow_yx, mask, self.dcn.weight, self.dcn.bias), f
         K = self.dk * self.dk
         if self.repeat:
             B, C2, H, W = offset.shape
@@ -134,7 +145,8 @@ class ResidualBlockNoBN(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return x + _run(self.conv2, _run(self.conv1, x, "relu")) * self.res_scale
+        # x + conv2(relu(conv1(x))) * res_scale: scale and residual ride in conv2's epilogue
+        return ops.conv3x3_ex(_run(self.conv1, x, "relu"), self.conv2.weight, self.conv2.bias, residual=x, post_scale=float(self.res_scale))
 
 
 class ResidualBlocksWithInputConv(nn.Module):
@@ -175,10 +187,11 @@ class FNet(nn.Module):
     def forward(self, x1, x2):
         """Flow from x1 to x2, [n,2,h,w]; convs and resizes on the HIP kernels."""
         _, _, h, w = x1.shape
-        o = torch.cat([x1, x2], dim=1)
+        o = None
         for blk in (self.encoder1, self.encoder2, self.encoder3):
-            o = _run(blk[2], _run(blk[0], o, "relu"), "relu")
-            o = torch.nn.functional.avg_pool2d(o, 2, 2)
+            # the first conv takes [x1 | x2] as two inputs (torch.cat of the reference, :801)
+            o = ops.conv3x3_ex(x1, blk[0].weight, blk[0].bias, x2=x2, act="relu") if o is None else _run(blk[0], o, "relu")
+            o = ops.avgpool2(_run(blk[2], o, "relu"))
         for blk in (self.decoder1, self.decoder2, self.decoder3):
             o = _run(blk[2], _run(blk[0], o, "relu"), "relu")
             o = ops.upsample_bilinear(o, scale_factor=2)

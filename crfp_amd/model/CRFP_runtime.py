@@ -35,7 +35,7 @@ class ResidualBlockNoBN(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return x + _run(self.conv2, _run(self.conv1, x, "relu")) * self.res_scale
+        return ops.conv3x3_ex(_run(self.conv1, x, "relu"), self.conv2.weight, self.conv2.bias, residual=x, post_scale=float(self.res_scale))
 
 
 class ResidualBlocksWithInputConv_v2(nn.Module):
@@ -104,6 +104,11 @@ class MRCF_simple_v18(nn.Module):
         self.print_timings = True        # the reference prints its stage means on every call (:8654-8662)
         self.last_timings = {}
 
+    def _upsample_post_lrelu(self, x):
+        """lrelu(pixel_shuffle(conv(x), 4)) (:8602, :8636): the activation is elementwise, so it and the shuffle ride in the conv's store"""
+        c = self.upsample_post.upsample_conv
+        return ops.conv3x3_ex(x, c.weight, c.bias, act="lrelu", shuffle=4)
+
     def compute_flow(self, lrs):
         n, t, c, h, w = lrs.shape
         lrs_1 = lrs[:, :-1].reshape(-1, c, h, w)
@@ -169,7 +174,7 @@ class MRCF_simple_v18(nn.Module):
                         offset = None
                     y = rb(torch.cat([feat_temp, aligned], dim=1), feat_temp)
                     feat_lv[k] = torch.cat(torch.chunk(y, 4, dim=1)[sr:4], dim=1)[:, :, :WP_h // 4, :WP_w // 4].contiguous()
-                feat_prop_lv0 = torch.nn.functional.leaky_relu(self.upsample_post(feat_prop_lv0), 0.1)
+                feat_prop_lv0 = self._upsample_post_lrelu(feat_prop_lv0)
                 win = feat_prop_lv0[:, :, :WP_h, :WP_w].contiguous()
                 aligned, _ = self.dcn_3(win, state, state_w, flow_lv0, offset)
                 feat_prop_lv3 = self.forward_resblocks_3(torch.cat([win, aligned], dim=1), feat_prop_lv0)
@@ -181,7 +186,7 @@ class MRCF_simple_v18(nn.Module):
                     ch = torch.chunk(rb(feat_prop_lv0), 4, dim=1)
                     feat_lv.append(torch.cat(ch[sr:4], dim=1)[:, :, :WP_h // 4, :WP_w // 4].contiguous())
                     feat_prop_lv0 = torch.cat(ch[:sr], dim=1).contiguous()
-                feat_prop_lv0 = torch.nn.functional.leaky_relu(self.upsample_post(feat_prop_lv0), 0.1)
+                feat_prop_lv0 = self._upsample_post_lrelu(feat_prop_lv0)
                 feat_prop_lv3 = self.forward_resblocks_3_(feat_prop_lv0)
                 toc("res")
             tic()
