@@ -394,6 +394,89 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
 #undef CRFP_NARROW_LOAD
 }
 
+#if !defined(CRFP_ACT_BF16) && defined(CRFP_LAB)
+// ---------------------------------------------------------------- round-3 experiment: the same stencil WITHOUT the LDS tile
+// The persistent LDS-tile kernel above spends 9.3 of the 26.6 us of a 4 -> 4 conv with loads, MFMAs and stores all removed
+// (per-tile index arithmetic, LDS staging, two barriers per tile, ramp).  Here a thread owns R vertically adjacent
+// pixels and reads their (R + 2) x 3 neighbourhood straight from global memory (each element is read by ~9 lanes: L1 / L2
+// hits; 4.5-6 x 16 B per pixel and input quad through the texture path = 7-9 us per quad at the L1 rate), zero padding through
+// the buffer range check (an invalid corner gets an out-of-range offset: one v_cndmask on the offset instead of four on the
+// data).  No barrier after the weight table, no persistence, 6 (R = 2) or 4 (R = 4) waves per SIMD.  Same MFMA chains in the
+// same order: bit-identical to conv3x3_narrow_kernel.  NE_PLAIN, Q4 sources only.  Lab: CRFP_NARROW_DIRECT=2|4.
+template <int KQ, int R>
+__global__ __launch_bounds__(256) void conv3x3_narrow_direct_kernel(const NarrowArgs a) {
+    __shared__ float4 wl[9 * KQ * 4];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    if (tid < 9 * KQ * 4) {
+        const float4 wv = reinterpret_cast<const float4*>(a.wpk)[tid];
+        float* wf = reinterpret_cast<float*>(wl) + (tid >> 2) * 16 + (tid & 3);
+        wf[0] = wv.x; wf[4] = wv.y; wf[8] = wv.z; wf[12] = wv.w;
+    }
+    const int n = blockIdx.z, H = a.H, W = a.W;
+    const int x = blockIdx.x * 64 + tx, y0 = (blockIdx.y * 4 + ty) * R;
+    const float4 bias = *reinterpret_cast<const float4*>(a.bpk);
+    f32x4 acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = f32x4{bias.x, bias.y, bias.z, bias.w};
+    bool rowok[R + 2], colok[3];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) rowok[r] = y0 + r - 1 >= 0 && y0 + r - 1 < H;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) colok[c] = x + c - 1 >= 0 && x + c - 1 < W;
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < KQ; ++k) {
+        int kql = k, sidx = 0;
+        while (sidx < a.nsrc - 1 && kql >= a.src[sidx].nq) { kql -= a.src[sidx].nq; ++sidx; }
+        const ConvSrc src = a.src[sidx];
+        const int pitch = (W + src.pad) * 16, plane = (H + src.pad) * pitch;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (char*)const_cast<float*>(src.p + (long long)n * src.bstride) + (long long)kql * plane, 0, plane, 0x00020000);
+        const int o00 = (y0 - 1) * pitch + (x - 1) * 16;
+        f32x4 nb[R + 2][3];
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int off = rowok[r] && colok[c] ? o00 + r * pitch + c * 16 : 0x7ffffff0;
+                nb[r][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 wv = wl[((ky * 3 + kx) * KQ + k) * 4 + (tx & 3)];
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, nb[ky + i][kx].x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, nb[ky + i][kx].y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, nb[ky + i][kx].z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < R; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, nb[ky + i][kx].w, acc[i], 0, 0, 0);
+            }
+    }
+    if (x >= W) return;
+    const float slope = a.act == CRFP_ACT_RELU ? 0.0f : (a.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const act_t* const resid = a.resid ? as_act(a.resid) + (long long)n * a.resid_bstride : nullptr;
+    act_t* const dsta = as_act(a.dst) + (long long)n * a.dst_bstride;
+    const int dpitch = W + a.dst_pad;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int y = y0 + i;
+        if (y >= H) break;
+        float v[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) v[o] = o < a.cout ? fmaxf(acc[i][o], slope * acc[i][o]) * a.post_scale : 0.0f;
+        if (resid) {
+            const cf32x4 rv = ldq(resid + ((long long)y * W + x) * 4);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+        stq(dsta + ((long long)y * dpitch + x) * 4, cf32x4{v[0], v[1], v[2], v[3]});
+    }
+}
+#endif
+
 // ---------------------------------------------------------------- two stencils in one pass (A -> B)
 // conv A (KQA input quads -> 4 channels, activation) feeding conv B (that quad -> 4 channels, NE_PLAIN with optional residual
 // or the dcn_3 offset/mask epilogue) without the round trip of A's output through HBM: at 8x resolution every tensor is
@@ -683,6 +766,24 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     if (a.resid) extra += 4;
     ProfScope prof(name, s, px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * (double)sizeof(act_t),
                    2.0 * px * in_ch * a.cout * 9.0);
+#if !defined(CRFP_ACT_BF16) && defined(CRFP_LAB)
+    static const int direct = getenv("CRFP_NARROW_DIRECT") ? atoi(getenv("CRFP_NARROW_DIRECT")) : 0;
+    bool q4only = true;
+    for (int i = 0; i < a.nsrc; ++i) q4only &= a.src[i].kind == SRC_Q4;
+    if (direct && a.epi == NE_PLAIN && q4only && a.act != CRFP_ACT_TANH && a.act != CRFP_ACT_SIGMOID) {
+        const int R = direct == 2 ? 2 : 4;
+        dim3 grid((a.W + 63) / 64, (a.H + 4 * R - 1) / (4 * R), a.N);
+#define CRFP_DIRECT_LAUNCH(KQ_) if (R == 2) conv3x3_narrow_direct_kernel<KQ_, 2><<<grid, 256, 0, s>>>(a); else conv3x3_narrow_direct_kernel<KQ_, 4><<<grid, 256, 0, s>>>(a);
+        switch (a.kq) {
+            case 1: CRFP_DIRECT_LAUNCH(1) break;
+            case 2: CRFP_DIRECT_LAUNCH(2) break;
+            default: CRFP_DIRECT_LAUNCH(3) break;
+        }
+#undef CRFP_DIRECT_LAUNCH
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
+#endif
     // persistent: a few workgroups per CU walk the tiles (ceil-balanced shares)
     const int ntl = ((a.W + NTW - 1) / NTW) * ((a.H + NTH - 1) / NTH);
 #ifdef CRFP_LAB

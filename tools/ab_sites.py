@@ -31,6 +31,16 @@ def child(a):
     eng = m.to(dev).eval().engine()
     lrs, fvs, mks = (torch.from_numpy(x).to(dev) for x in synth.make_clip(1234, 1, a.t, a.h, a.w, fv_size=a.fv, sigma_t=10.0))
     L = _lib.lib()
+    if a.mode == "stream":      # one frame per call (BASELINE config 3's call pattern), a.t calls per "step"
+        mk8 = mks.contiguous()
+
+        def run():
+            eng.clear_states()
+            o = None
+            for i in range(a.t):
+                o = eng.stream_frame(lrs[0, i], fvs[0, i], mk8[0, i])
+            return o
+        eng.forward = lambda *_: run()
     with torch.no_grad():
         for _ in range(3):
             out = eng.forward(lrs, fvs, mks)
@@ -47,7 +57,8 @@ def child(a):
         recs = _lib.prof_report(512)
         L.crfp_prof_enable(0)
     sites = {r["name"]: 1e3 * r["total_ms"] / r["launches"] for r in recs}
-    res = {"wall_ms": wall, "kernel_ms": sum(r["total_ms"] for r in recs) / a.steps, "sites": sites,
+    counts = {r["name"]: r["launches"] / a.steps for r in recs}
+    res = {"wall_ms": wall, "kernel_ms": sum(r["total_ms"] for r in recs) / a.steps, "sites": sites, "counts": counts,
            "digest": hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12], "finite": bool(torch.isfinite(out).all())}
     print("ABRESULT " + json.dumps(res))
 
@@ -61,6 +72,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--h", type=int, default=180); ap.add_argument("--w", type=int, default=320)
     ap.add_argument("--t", type=int, default=7); ap.add_argument("--fv", type=int, default=96)
+    ap.add_argument("--mode", default="clip", choices=("clip", "stream"))
+    ap.add_argument("--all-sites", action="store_true", help="print every launch site (sorted by time) for the first variant")
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
     if a.child:
@@ -83,7 +96,7 @@ def main():
     for r in range(a.rounds):
         for name, env in variants:
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--storage", a.storage, "--steps", str(a.steps), "--h", str(a.h),
-                   "--w", str(a.w), "--t", str(a.t), "--fv", str(a.fv)]
+                   "--w", str(a.w), "--t", str(a.t), "--fv", str(a.fv), "--mode", a.mode]
             p = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("ABRESULT ")]
             if not line:
@@ -100,6 +113,11 @@ def main():
         for s in rs[0]["sites"]:
             if any(w in s for w in want):
                 sel[s] = min(r["sites"][s] for r in rs)
+        if a.all_sites and name == variants[0][0]:
+            tot = sum(rs[0]["sites"][k] * rs[0]["counts"][k] for k in rs[0]["sites"])
+            for k in sorted(rs[0]["sites"], key=lambda k: -rs[0]["sites"][k] * rs[0]["counts"][k]):
+                us = min(r["sites"][k] for r in rs)
+                print(f"    {k:44s} {rs[0]['counts'][k]:6.1f} x {us:7.1f} us = {us * rs[0]['counts'][k] / 1e3:7.3f} ms  {100 * rs[0]['sites'][k] * rs[0]['counts'][k] / tot:5.1f} %")
         print(f"{name:22s} wall {wall:7.3f} ms  kernels {kern:7.3f} ms  digest {rs[0]['digest']} finite {rs[0]['finite']}  "
               + "  ".join(f"{k}={v:.1f}" for k, v in sorted(sel.items())), flush=True)
 
