@@ -892,6 +892,185 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     if (a.ovf && !(vmax < 65504.0f)) atomicOr(a.ovf, 1u);
 }
 
+// ---------------------------------------------------------------- round 3: the same fusion with ROLE-SPECIALISED waves
+// dcn_fused_kernel<8> runs conv taps and sampler items in ONE instruction stream per wave: 246 VGPRs = two waves per SIMD, and
+// whatever stalls the stream (an LDS operand read in front of an MFMA, a gather that has not landed, a barrier) stalls both roles'
+// work of that wave.  Per workgroup ~70 k cycles against 13.8 k of MFMA pipe time and 11 k of vector issue per wave; a finer
+// interleave and static wave priorities changed nothing (profiles/r03_mfma_valu_overlap_microtest.txt).
+// Here a workgroup is 16 waves on the same 8 x 32-pixel tile: waves 0-7 ("conv", row = wave) run ONLY the 32 -> 216 head -- the
+// MFMA stream, the weight stages (global -> registers -> LDS, double-buffered per 16-channel chunk) and the tanh / sigmoid of the
+// finished cout tile -- and hand the 16 activated (dy, dx, mask) values per lane of each tile to their partner wave 8 + row
+// ("sampler") through a 32 KB LDS block; waves 8-15 run ONLY coordinates, gathers, bilinear blends, fp16 split and the 54 DCN
+// MFMAs.  Each role fits 128 VGPRs, so four waves share a SIMD (two of each role) and a stalled sampler leaves the SIMD to the
+// MFMA stream and vice versa.  Hand-off: one workgroup barrier per chunk stage (15 in all); the values of tile T are written after
+// barrier 2T+1 and read after barrier 2T+2, those of tile T-1 are read (into registers) right after barrier 2T -- a full
+// barrier earlier -- so the block needs no second slot and no flags.  Same operations on the same values in the same per-accumulator
+// order as dcn_fused_kernel<8> and the two-kernel path: bit-identical results.
+// LDS: halo tile 43.5 KB + weight stages 2 x 18.4 KB + hand-off block 32 KB + DCN weight image 36 KB + biases 0.9 KB = 149 KB.
+constexpr int D2_NT = 1024, D2_NEL = 10 * DF_LW, D2_NIN = (8 * D2_NEL + D2_NT - 1) / D2_NT;
+constexpr int D2_NWS = (DF_WCH + 511) / 512;   // weight elements per conv-wave thread and chunk stage (512 conv threads)
+
+__global__ __launch_bounds__(D2_NT, 1) void dcn_fused2_kernel(const DcnFuseArgs a) {
+    __shared__ f32x4 tile[8][D2_NEL];          // [part * 4 + 8-channel group][halo pixel]
+    __shared__ f32x4 wst[2][DF_WCH];           // one (cout tile, chunk) stage per buffer
+    __shared__ float ovl[16][8][64];           // hand-off block: [slot of the tile][row][lane]
+    __shared__ f32x4 wl[36 * 64];              // DCN weight image (sampler)
+    __shared__ f32x4 bl[56];                   // the head's 224 packed biases
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool conv = wave < 8;
+    const int row = wave & 7, ctid = tid & 511;   // ctid: index among the 512 threads of this role
+    const int j = lane & 31, h = lane >> 5;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8, n = blockIdx.z;
+    const int H = a.H, W = a.W;
+#ifdef CRFP_LAB
+    const int D2_PROBE = a.probe;   // lab timing experiments (results wrong), bits: 1 = no sampling, 2 = no conv MFMAs, 4 = sampler waves at s_setprio 2, 8 = conv waves at s_setprio 2
+    if (D2_PROBE & 4) { if (!conv) __builtin_amdgcn_s_setprio(2); }
+    if (D2_PROBE & 8) { if (conv) __builtin_amdgcn_s_setprio(2); }
+#else
+    constexpr int D2_PROBE = 0;
+#endif
+
+    // ---- prologue, all 1024 threads: halo tile, DCN weights, biases
+    {
+        const f32x4* __restrict__ s3 = reinterpret_cast<const f32x4*>(a.feat + (long long)n * a.feat_b);
+        f32x4 rt[D2_NIN];
+        bool tv[D2_NIN];
+#pragma unroll
+        for (int t = 0; t < D2_NIN; ++t) {
+            const int idx = tid + D2_NT * t, idc = min(idx, 8 * D2_NEL - 1);
+            const int pl = idc / D2_NEL, pix = idc - pl * D2_NEL, r = pix / DF_LW, c = pix - r * DF_LW;
+            const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+            tv[t] = idx < 8 * D2_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            rt[t] = s3[((long long)pl * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1)];
+        }
+        for (int i = tid; i < 36 * 64; i += D2_NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
+        if (tid < 56) bl[tid] = reinterpret_cast<const f32x4*>(a.bconv)[tid];
+#pragma unroll
+        for (int t = 0; t < D2_NIN; ++t) {
+            const int idx = tid + D2_NT * t;
+            if (idx < 8 * D2_NEL) (&tile[0][0])[idx] = tv[t] ? rt[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+
+    if (conv) {
+        // ================================================================ conv waves
+        const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(a.wconv);
+        f32x4 rws[D2_NWS];
+#define D2_WLOAD(ST) _Pragma("unroll") for (int k = 0; k < D2_NWS; ++k) rws[k] = wc[(ST) * DF_WCH + min(ctid + 512 * k, DF_WCH - 1)];
+#define D2_WRITE(B)                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < D2_NWS; ++k) {                                                  \
+        const int idx = ctid + 512 * k;                                                                   \
+        if (idx < DF_WCH) wst[B][idx] = rws[k];                                                           \
+    }
+        D2_WLOAD(0)
+        D2_WRITE(0)
+        D2_WLOAD(1)
+        const int px = tx0 + j, py = ty0 + row;
+        const int cx = min(px, W - 1), cy = min(py, H - 1);
+        const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
+        const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
+        f32x16 ca, cl;
+#pragma unroll
+        for (int T = 0; T < 7; ++T) {
+#pragma unroll
+            for (int CH = 0; CH < 2; ++CH) {
+                const int st = 2 * T + CH;
+                __syncthreads();   // barrier `st`: stage st is in wst[st & 1], nobody reads wst[(st + 1) & 1] any more
+                if (CH == 0) {     // accumulators start at the bias (two-kernel path); the table is complete behind barrier 0
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 bq = bl[T * 8 + 2 * q + h];
+                        ca[4 * q] = bq.x; ca[4 * q + 1] = bq.y; ca[4 * q + 2] = bq.z; ca[4 * q + 3] = bq.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) cl[e] = 0.0f;
+                }
+                if (st + 1 < 14) { D2_WRITE((st + 1) & 1) }
+                if (st + 2 < 14) { D2_WLOAD(st + 2) }
+                __builtin_amdgcn_sched_barrier(0);   // the next stages' traffic leaves before this stage's MFMAs
+                const f32x4* wcur = &wst[st & 1][0];
+                if (!(D2_PROBE & 2))
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const dcn_f16x8 w0 = __builtin_bit_cast(dcn_f16x8, wcur[(tap * 2) * 64 + lane]);
+                    const dcn_f16x8 w1 = __builtin_bit_cast(dcn_f16x8, wcur[(tap * 2 + 1) * 64 + lane]);
+                    const int pix = (row + ky) * DF_LW + j + kx;
+                    const dcn_f16x8 b0 = __builtin_bit_cast(dcn_f16x8, tile[2 * CH + h][pix]);
+                    const dcn_f16x8 b1 = __builtin_bit_cast(dcn_f16x8, tile[4 + 2 * CH + h][pix]);
+                    cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, cl, 0, 0, 0);
+                    ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, ca, 0, 0, 0);
+                    cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, cl, 0, 0, 0);
+                }
+            }
+            // tile T done: raw sum = ca + cl * 2^-11 (one exact-product FMA), 10 tanh + flow / sigmoid, hand the 16 values over
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int sl = 16 * T + e, c3 = sl % 3;   // slot 3 p + c: component c of the half's position p (compile-time)
+                if (sl < 108) {
+                    const float raw = __builtin_fmaf(cl[e], 1.0f / 2048.0f, ca[e]);
+                    ovl[e][row][lane] = c3 == 0 ? tanh10_plus(raw, cfy) : (c3 == 1 ? tanh10_plus(raw, cfx) : fast_sigmoid(raw));
+                }
+            }
+        }
+        __syncthreads();   // barrier 14: tile 6's values are in the block
+#undef D2_WLOAD
+#undef D2_WRITE
+        return;
+    }
+
+    // ================================================================ sampler waves
+    const int px = tx0 + j, py = ty0 + row;
+    const bool valid = px < W && py < H;
+    const int cx = min(px, W - 1), cy = min(py, H - 1);
+    const long long plane = (long long)H * W * 4;
+    const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
+    const int guard = pitch + QB;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (char*)const_cast<act_t*>(as_act(a.x) + (long long)n * a.xb) - guard, 0, 8 * plane_b + guard, 0x00020000);
+    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
+    const int hbase = 4 * h * plane_b + guard;
+    f32x16 acc, acl;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acl[e] = 0.0f; }
+    float ov[112];   // activated (dy, dx, mask) of position p at 3 p + c; every index below is a compile-time constant
+    float xs[8];
+    DcnPair Q0;
+#define D2_BAR __syncthreads();
+#define D2_GET(S) ov[S] = ovl[(S) & 15][row][lane];
+#define D2_PAIR(U)                                                                                        \
+    if (!(D2_PROBE & 1)) {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);   /* the hand-off reads of later pairs stay behind this pair (registers) */ \
+        dcn_issue_one(Q0, 0, rx, ov[6 * (U)], ov[6 * (U) + 1], ov[6 * (U) + 2], 2 * (U), fy0, fx0, fH, fW, PW, pitch, plane_b, hbase); \
+        dcn_issue_one(Q0, 1, rx, ov[6 * (U) + 3], ov[6 * (U) + 4], ov[6 * (U) + 5], 2 * (U) + 1, fy0, fx0, fH, fW, PW, pitch, plane_b, hbase); \
+        dcn_lerp_one(Q0, 0, xs);                                                                          \
+        dcn_lerp_one(Q0, 1, xs);                                                                          \
+        dcn_split_mfma(xs, acc, acl, wl, U, lane);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+    // window T (T = 1..6) = chunk stages 2T, 2T + 1: the pairs tile T - 1 completed (up to (16 (T - 1) + 10) / 6: 1, 4, 7, 9, 12, 15),
+    // split over the two stages; after barrier 14 the last two.  Barriers 0 and 1 have no sampler work behind them.  The table
+    // (tools/gen/dcn_fused2_sampler.py) reads every hand-off value as late as it is still in LDS.
+#include "dcn_fused2_sampler.inc"
+#undef D2_PAIR
+#undef D2_GET
+#undef D2_BAR
+    if (!valid) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
+    act_t* o = as_act(a.out) + (long long)n * a.ob + ((long long)py * W + px) * 4;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cq = 2 * g + h;
+        const float4 bb = *reinterpret_cast<const float4*>(a.bdcn + 4 * cq);
+        const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
+    }
+    if (a.ovf && !(vmax < 65504.0f)) atomicOr(a.ovf, 1u);
+}
+
 bool dcn_fused_enabled() {
     static const bool on = !(getenv("CRFP_DCN_FUSED") && atoi(getenv("CRFP_DCN_FUSED")) == 0);
     return on;
@@ -914,13 +1093,20 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
         fprintf(stderr, "dcn_fused_kernel: %d workgroups per CU (hip error %d)\n", nb, (int)e);
     }
     static const int nw_lab = getenv("CRFP_DCN_FUSE_NW") ? atoi(getenv("CRFP_DCN_FUSE_NW")) : 8;
-    if (nw_lab == 8) dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(b);
+    static const int fuse_v_lab = getenv("CRFP_DCN_FUSE_V") ? atoi(getenv("CRFP_DCN_FUSE_V")) : 1;
+    if (nw_lab == 8 && fuse_v_lab == 2) dcn_fused2_kernel<<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), D2_NT, 0, s>>>(b);
+    else if (nw_lab == 8) dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(b);
     else dcn_fused_kernel<4><<<dim3((a.W + 31) / 32, (a.H + 3) / 4, a.N), 256, 0, s>>>(b);
     CRFP_CHECK_LAUNCH();
     return 0;
 #endif
     // 8-wave workgroups: 151.6 vs 165.3 us per launch same-box against <4> (lab library: CRFP_DCN_FUSE_NW=4)
-    dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
+    // CRFP_DCN_FUSE_V=2 (read once): the role-specialised 16-wave form above -- bit-identical, 141.2 vs 136.6 us per launch same-box @A:
+    // both forms pay the same ~53 us of per-workgroup fixed cost (116 KB of tile / weight prologue and 258 KB of streamed head
+    // weights per 256 pixels, 15 barriers), and the specialised one overlaps only 17 of the 49 us its sampler role adds
+    static const int fuse_v = getenv("CRFP_DCN_FUSE_V") ? atoi(getenv("CRFP_DCN_FUSE_V")) : 1;
+    if (fuse_v == 2) dcn_fused2_kernel<<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), D2_NT, 0, s>>>(a);
+    else dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
     CRFP_CHECK_LAUNCH();
     return 0;
 }

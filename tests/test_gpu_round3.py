@@ -294,3 +294,15 @@ def test_bf16_fused_conv_pairs_are_bit_identical():
     dig = {k: v.split(" digest ")[1].split()[0] for k, v in lines.items()}
     assert dig["pair"] == dig["single"], lines
     assert "conv_mfma_pair" in lines["pair"] and "conv_mfma_pair" not in lines["single"]
+
+
+def test_role_specialised_fused_dcn_kernel_is_bit_identical():
+    """dcn_fused2_kernel (CRFP_DCN_FUSE_V=2: 8 conv waves hand the activated offsets / masks of every cout tile to 8 sampler waves
+    through LDS, 16 waves per workgroup) against the shipped single-role kernel: same arithmetic, same order, same bits."""
+    from test_gpu_parity import _golden_check
+    assert _golden_check({}, want="DIGEST") == _golden_check({"CRFP_DCN_FUSE_V": "2"}, want="DIGEST")
+    tool = os.path.join(ROOT, "tools", "ab_sites.py")
+    r = subprocess.run([sys.executable, tool, "--rounds", "1", "--steps", "1", "--t", "3", "v1=", "v2=CRFP_DCN_FUSE_V=2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    dig = {ln.split()[0]: ln.split(" digest ")[1].split()[0] for ln in r.stdout.splitlines() if " digest " in ln}
+    assert set(dig) == {"v1", "v2"} and dig["v1"] == dig["v2"], r.stdout + r.stderr[-2000:]
