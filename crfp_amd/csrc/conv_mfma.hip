@@ -105,6 +105,24 @@ __device__ __forceinline__ void load_quad_batch(float4 (&r)[NIN], const ConvSrc&
                 }
             break;
         }
+        case SRC_NCHW_SHIFT: {   // the tensor shifted by (sy, sx): its own validity test (ok[] belongs to the unshifted tile)
+            const int sy = (s.rsv & 15) - 8, sx = ((s.rsv >> 4) & 15) - 8;
+            const float lo = (s.rsv & 256) ? 0.0f : -__builtin_inff();   // ReLU on the way in
+            const long long pl = (long long)H * W;
+            const int c0 = 4 * kql;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                const int y = gy[k] + sy, x = gx[k] + sx;
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    const long long o = (long long)y * W + x;
+                    r[k].x = c0 + 0 < s.nch ? fmaxf(base[(c0 + 0) * pl + o], lo) : 0.0f;
+                    r[k].y = c0 + 1 < s.nch ? fmaxf(base[(c0 + 1) * pl + o], lo) : 0.0f;
+                    r[k].z = c0 + 2 < s.nch ? fmaxf(base[(c0 + 2) * pl + o], lo) : 0.0f;
+                    r[k].w = c0 + 3 < s.nch ? fmaxf(base[(c0 + 3) * pl + o], lo) : 0.0f;
+                }
+            }
+            break;
+        }
         default: break;
     }
 }
@@ -361,15 +379,18 @@ __device__ __forceinline__ void load_weight_batch(f32x4 (&rw)[NW], const f32x4* 
 }
 
 // CT = cout tiles (of 32) per workgroup, RPW = output rows per wave (tile = 4*RPW rows x 64 px).
-template <int CT, int RPW>
+// KP = K-chunks (of 8 channels) per staging phase: 1 everywhere except the long-K convolutions of SPyNet (9 x cin virtual channels,
+// up to 72 chunks: on its coarse pyramid levels a conv is one or two workgroups walking that many barrier pairs, so two chunks per
+// phase halve the fixed part; same chunk order, same accumulation order, same values).
+template <int CT, int RPW, int KP = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) {
     constexpr int TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
     // One K-chunk (2 quads = 8 input channels) lives in LDS at a time: the halo tile of both quads
     // and the packed weights of the chunk for the CT cout tiles.  The NEXT chunk's global loads are
     // issued into registers before the MFMAs of the current chunk start, so HBM/L2 latency hides
     // behind 144*CT MFMAs per wave; LDS is rewritten between two barriers.
-    __shared__ float4 tile[2][LH][LW];
-    __shared__ float4 wlds[CT][9 * 64];
+    __shared__ float4 tile[2 * KP][LH][LW];
+    __shared__ float4 wlds[KP][CT][9 * 64];
     constexpr int NIN = (LH * LW + 255) / 256;       // 3 halo elements per thread per quad
     constexpr int NW = (CT * 9 * 64 + 255) / 256;    // 3 (CT=1) or 5 (CT=2) weight float4 per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -382,7 +403,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     const int btile = bwork / ngrp;
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = (bwork - btile * ngrp) * CT;
-    const int n = blockIdx.z;
+    const int n = blockIdx.z;                                         // destination "batch item" (ksplit: one per K slice)
+    const int n_src = a.ksplit > 0 ? n / a.ksplit : n;                // source batch item
     const int H = a.H, W = a.W;
 
     // per-thread staging coordinates (constant over the K loop)
@@ -406,61 +428,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             for (int e = 0; e < 16; ++e) acc[ct][pt][e] = 0.0f;
 
     const int npairs = a.kq >> 1;
+    const int npl = a.ksplit > 0 ? npairs / a.ksplit : npairs;        // K chunks this workgroup walks ...
+    const int pair0 = a.ksplit > 0 ? (n % a.ksplit) * npl : 0;        // ... starting here
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(a.wpk);
-    float4 rin0[NIN], rin1[NIN];
-    f32x4 rw[NW];
+    float4 rin0[KP][NIN], rin1[KP][NIN];
+    f32x4 rw[KP][NW];
 
-#define CRFP_ISSUE_LOADS(PAIR)                                                                          \
-    {                                                                                                   \
+    // loads of the KP chunks of staging phase ST (chunk index clamped past the end: an odd chunk count repeats the last one, unused)
+#define CRFP_ISSUE_LOADS(ST)                                                                            \
+    _Pragma("unroll") for (int kp = 0; kp < KP; ++kp) {                                                 \
+        const int pair_ = pair0 + min(KP * (ST) + kp, npl - 1);                                         \
         {                                                                                               \
-            int kql = 2 * (PAIR), s = 0;                                                                \
+            int kql = 2 * pair_, s = 0;                                                                 \
             while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }                  \
-            load_quad_batch<NIN>(rin0, a.src[s], n, kql, sgy, sgx, sval, H, W);                         \
+            load_quad_batch<NIN>(rin0[kp], a.src[s], n_src, kql, sgy, sgx, sval, H, W);                 \
         }                                                                                               \
         {                                                                                               \
-            int kql = 2 * (PAIR) + 1, s = 0;                                                            \
+            int kql = 2 * pair_ + 1, s = 0;                                                             \
             while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }                  \
-            load_quad_batch<NIN>(rin1, a.src[s], n, kql, sgy, sgx, sval, H, W);                         \
+            load_quad_batch<NIN>(rin1[kp], a.src[s], n_src, kql, sgy, sgx, sval, H, W);                 \
         }                                                                                               \
-        load_weight_batch<CT, NW>(rw, wp, T0, npairs, (PAIR), tid);                                     \
+        load_weight_batch<CT, NW>(rw[kp], wp, T0, npairs, pair_, tid);                                  \
     }
 
+    const int nstages = (npl + KP - 1) / KP;
     CRFP_ISSUE_LOADS(0)
-    for (int pair = 0; pair < npairs; ++pair) {
+    for (int st = 0; st < nstages; ++st) {
         __syncthreads();  // every wave finished reading the previous chunk
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) {
-            const int idx = tid + 256 * k;
-            if (idx < LH * LW) {
-                (&tile[0][0][0])[idx] = rin0[k];
-                (&tile[1][0][0])[idx] = rin1[k];
+        for (int kp = 0; kp < KP; ++kp) {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                const int idx = tid + 256 * k;
+                if (idx < LH * LW) {
+                    (&tile[2 * kp][0][0])[idx] = rin0[kp][k];
+                    (&tile[2 * kp + 1][0][0])[idx] = rin1[kp][k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const int idx = tid + 256 * k;
+                if (idx < CT * 576) reinterpret_cast<f32x4*>(&wlds[kp][0][0])[idx] = rw[kp][k];
             }
         }
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int idx = tid + 256 * k;
-            if (idx < CT * 576) reinterpret_cast<f32x4*>(&wlds[0][0])[idx] = rw[k];
-        }
         __syncthreads();
-        if (pair + 1 < npairs) CRFP_ISSUE_LOADS(pair + 1)
+        if (st + 1 < nstages) CRFP_ISSUE_LOADS(st + 1)
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+        if (KP * st + kp >= npl) break;   // workgroup-uniform
 #pragma unroll CRFP_TAP_UNROLL
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
             float4 wa[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wa[ct] = wlds[ct][tap * 64 + lane];
+            for (int ct = 0; ct < CT; ++ct) wa[ct] = wlds[kp][ct][tap * 64 + lane];
             float4 b[PT];
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) b[pt] = tile[h][wave * RPW + (pt >> 1) + ky][(pt & 1) * 32 + j + kx];
+            for (int pt = 0; pt < PT; ++pt) b[pt] = tile[2 * kp + h][wave * RPW + (pt >> 1) + ky][(pt & 1) * 32 + j + kx];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
+                    if ((pt & 1) && tx0 + 32 >= W) continue;   // workgroup-uniform: the tile's right half lies outside a narrow map
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct].x, b[pt].x, acc[ct][pt], 0, 0, 0);
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct].y, b[pt].y, acc[ct][pt], 0, 0, 0);
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct].z, b[pt].z, acc[ct][pt], 0, 0, 0);
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct].w, b[pt].w, acc[ct][pt], 0, 0, 0);
                 }
+        }
         }
     }
 #undef CRFP_ISSUE_LOADS
@@ -2293,7 +2328,7 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     const bool use_split = !(env_strict || a.strict);
     bool ct2 = a.ctiles % 2 == 0;
     bool nchw_src = false, s3_src = false;
-    for (int i = 0; i < a.nsrc; ++i) { nchw_src |= a.src[i].kind == SRC_NCHW; s3_src |= a.src[i].kind == SRC_S3; }
+    for (int i = 0; i < a.nsrc; ++i) { nchw_src |= a.src[i].kind == SRC_NCHW || a.src[i].kind == SRC_NCHW_SHIFT; s3_src |= a.src[i].kind == SRC_S3; }
     const bool split = a.wsplit && use_split && (a.kq & 3) == 0 && !nchw_src && a.kq <= CRFP_MAX_KQ;
     const bool uses_s3 = a.s3_dst != nullptr || s3_src;
     if (uses_s3 && (!split || !conv_s3_supported() || (a.s3_dst && (a.store != ST_Q4 || (a.cout & 7))))) {
@@ -2420,6 +2455,11 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         } else
             conv3x3_split_kernel<1, 1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
 #endif
+    } else if (a.src[0].kind == SRC_NCHW_SHIFT) {   // SPyNet's 7x7-as-3x3 convolutions: 18 ... 144 K-quads, two chunks per staging phase
+        const int tiles4 = ((a.W + TW - 1) / TW) * ((a.H + 3) / 4);
+        const int nz = a.N * (a.ksplit > 0 ? a.ksplit : 1);
+        if (ct2) conv3x3_mfma_kernel<2, 1, 2><<<dim3(tiles4 * (a.ctiles / 2), 1, nz), 256, 0, s>>>(a);
+        else conv3x3_mfma_kernel<1, 1, 2><<<dim3(tiles4 * a.ctiles, 1, nz), 256, 0, s>>>(a);
     } else if (ct2) {
         conv3x3_mfma_kernel<2, 1><<<dim3(tiles * (a.ctiles / 2), 1, a.N), 256, 0, s>>>(a);
     } else if ((long long)tiles * a.ctiles * a.N < 512) {

@@ -97,10 +97,13 @@ enum SrcKind : int {
     SRC_UNSHUF4 = 2, // Q4 tensor at 4x resolution read through pixel_unshuffle(4): nch = 16 * C_hi
     SRC_FLOW2 = 3,   // [H][W][2] (dx,dy) pairs -> quad (dx,dy,0,0)
     SRC_ZERO = 4,    // padding quad(s)
-    SRC_S3 = 5       // pre-split fp16 pair image written by a producing conv (ConvArgs::s3_dst): 2 x nch/8 planes of
+    SRC_S3 = 5,      // pre-split fp16 pair image written by a producing conv (ConvArgs::s3_dst): 2 x nch/8 planes of
                      // [H][W] 16-byte elements = 8 channels of fp16; planes [0, nch/8) hold x0 = fp16(x), planes
                      // [nch/8, nch/4) hold x1s = fp16((x - x0) * 2^11).  Same bytes per pixel as the fp32 Q4 tensor it
                      // replaces; the consuming conv copies it to LDS instead of converting (nch % 16 == 0, chunk aligned)
+    SRC_NCHW_SHIFT = 6 // NCHW planes read at (y + sy, x + sx), zero outside the image, optional ReLU on the way in; ConvSrc::rsv packs
+                     // (sy + 8) | (sx + 8) << 4 | relu << 8.  Nine of them over one tensor turn a 7x7 convolution into a 3x3 one
+                     // (spynet.hip); fp32-MFMA kernel only
 };
 
 enum StoreMode : int {
@@ -130,7 +133,7 @@ struct ConvDst {
     int pad, rsv;       // 1: destination planes are (H+1) x (W+1) (pad row/column never written)
 };
 
-#define CRFP_MAX_SRC 5
+#define CRFP_MAX_SRC 9
 #define CRFP_MAX_DST 3
 #define CRFP_MAX_KQ 80   // K-quads per conv the per-quad descriptor table can hold (Cin <= 320)
 
@@ -174,6 +177,9 @@ struct ConvArgs {
     unsigned* ovf;
     int strict;         // 1: plain fp32 MFMA for this launch (CRFP_DSV_STRICT_F32)
     int dst_f32;        // bf16 build, ST_Q4, one destination: store float quads (FNet's flow output stays fp32)
+    int ksplit;         // fp32-MFMA kernel only: > 0 = blockIdx.z enumerates (batch item, K slice): slice z % ksplit covers K-quads
+                        // [slice * kq / ksplit, ...), reads batch item z / ksplit and writes "batch item" z of the destination (partial sums,
+                        // added up by the caller).  SPyNet's coarse pyramid levels: one workgroup per shifted view instead of one for all nine
 };
 
 bool conv_s3_supported();   // the selected conv kernels consume SRC_S3 sources (default f16x3 path of the fp32 build only)
@@ -212,6 +218,7 @@ __host__ __device__ inline int conv_k_to_cin(int kind, int nch, int kql, int com
     switch (kind) {
         case SRC_Q4:
         case SRC_S3:
+        case SRC_NCHW_SHIFT:
         case SRC_NCHW: {
             const int c = 4 * kql + comp;
             return c < nch ? c : -1;
@@ -232,6 +239,7 @@ __host__ __device__ inline int src_quads(int kind, int nch) {
     switch (kind) {
         case SRC_Q4:
         case SRC_S3:
+        case SRC_NCHW_SHIFT:
         case SRC_NCHW: return (nch + 3) / 4;
         case SRC_UNSHUF4: return ((nch / 16 + 3) / 4) * 16;
         case SRC_FLOW2: return 1;

@@ -7,9 +7,10 @@
 //   flow_up, border) (:655-657); out = 5 x (ReLU -> conv7x7) on the virtual concat [ref | warped | flow_up] (:658-659,
 //   :693-734); flow = flow_up + out (:660)
 //   resize the flow back (align_corners=False) and rescale its components by w / w_up, h / h_up           (:728-739)
-// The 7x7 convolutions are direct fp32 convolutions: thread = one pixel x 16 output channels, 16 x 16 pixel tile, input
-// halo staged in LDS four channels at a time (ReLU applied on the way in), weights through the scalar cache (they are
-// uniform over the workgroup).  fp32 FMA throughout.
+// Round 3: the 30 7x7 convolutions of the pyramid run on the fp32 MFMA as 3x3 convolutions over nine shifted views of their input
+// (spy_conv7_mfma below): 28.6 -> ~5 ms per 192 x 320 pair.  The direct fp32 convolution (thread = one pixel x 16 output
+// channels, 16 x 16 pixel tile, input halo staged in LDS four channels at a time, weights through the scalar cache) stays
+// behind the stand-alone crfp_convkxk_f32 operator, which has no workspace to pack weights into.
 #include "crfp_common.h"
 
 #include <cstring>
@@ -91,6 +92,101 @@ static int launch_spy_conv(const SpyConvArgs& a, int K, hipStream_t s) {
         case 7: spy_conv_kernel<7><<<grid, 256, 0, s>>>(a); break;
         default: set_error("convkxk: kernel size %d unsupported (3, 5, 7)", K); return CRFP_E_UNSUPPORTED;
     }
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- 7x7 convolution on the MFMA (round 3).  A 7x7 kernel padded to 9x9 is a 3x3 grid of 3x3 blocks: with S_ij = the input
+// shifted by (3 i - 3, 3 j - 3) (zero outside the image),
+//     conv7(x)[y, x] = sum_{i, j} conv3(S_ij; W9_ij)[y, x],   W9_ij[ky][kx] = W7[3 i + ky - 1][3 j + kx - 1] (0 outside 0..6),
+// i.e. ONE 3x3 convolution over 9 cin "virtual" channels.  The nine shifted views are nine SRC_NCHW_SHIFT sources of the same
+// tensor (conv_mfma.hip: shifted read, own zero-padding test, ReLU on the way in), so the library's implicit-GEMM kernel
+// (v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, exact fp32 products) runs it unchanged; 81 / 49 of the taps are structural
+// zeros.  Weights are rearranged (spy_w9_kernel) and packed per call into the workspace.  Needs cin % 4 == 0.
+__global__ void spy_w9_kernel(const float* __restrict__ w7, float* __restrict__ w9, int cout, int cin) {
+    const int total = cout * 9 * cin * 9;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int tap = idx % 9, vc = (idx / 9) % (9 * cin), o = idx / (81 * cin);
+        const int sblk = vc / cin, c = vc - sblk * cin, i = sblk / 3, j = sblk - 3 * i;
+        const int u = 3 * i + tap / 3 - 1, v = 3 * j + tap % 3 - 1;
+        w9[idx] = (u >= 0 && u < 7 && v >= 0 && v < 7) ? w7[((long long)o * cin + c) * 49 + u * 7 + v] : 0.0f;
+    }
+}
+
+// [ref(3) | warped(3) | flow(2)] -> one 8-channel NCHW tensor (the first conv of a basic module reads one source nine times)
+__global__ void spy_cat8_kernel(const float* __restrict__ a3, const float* __restrict__ b3, const float* __restrict__ c2,
+                                float* __restrict__ out, long long HW) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (i >= HW) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[((long long)n * 8 + c) * HW + i] = a3[((long long)n * 3 + c) * HW + i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[((long long)n * 8 + 3 + c) * HW + i] = b3[((long long)n * 3 + c) * HW + i];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) out[((long long)n * 8 + 6 + c) * HW + i] = c2[((long long)n * 2 + c) * HW + i];
+}
+
+__global__ void spy_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = b[i] + a[i];   // flow_up + out, the operand order of the reference (:660)
+}
+
+// partial sums of the K-split form: 9 slices x up to 64 channels of a map of at most a quarter of the padded frame (px pixels)
+static size_t spy_partial_floats(int n, size_t px) { return (size_t)9 * 64 * (px / 4) * (size_t)(n > 0 ? n : 1); }
+static size_t spy_mfma_scratch_floats(int cin, int cout) {
+    const size_t ctiles = (cout + 31) / 32, kq = 9 * (size_t)cin / 4;
+    return align_up((size_t)cout * 81 * cin, 64) + align_up(ctiles * (kq / 2) * 9 * 64 * 4, 64) + align_up(ctiles * 32, 64);
+}
+
+// out[n][c][px] = bias[c] + sum over the 9 K slices, in slice order (deterministic)
+__global__ void spy_sum9_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out, long long per,
+                                long long HW, int cout, int n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * n) return;
+    const long long b = i / per, r = i - b * per;
+    float acc = bias[(int)(r / HW)];
+#pragma unroll
+    for (int sb = 0; sb < 9; ++sb) acc += part[(b * 9 + sb) * per + r];
+    out[i] = acc;
+}
+
+// out[n,cout,H,W] = conv7x7(relu?(x[n,cin,H,W])) + bias on the fp32 MFMA; scratch: spy_mfma_scratch_floats(cin, cout) floats
+static int spy_conv7_mfma(const float* x, int cin, const float* w7, const float* bias, float* out, int cout, int n, int H, int W,
+                          int pre_relu, float* scratch, size_t partial_floats, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = 9;
+    for (int sb = 0; sb < 9; ++sb) {
+        ConvSrc& d = a.src[sb];
+        d.p = x; d.bstride = (long long)cin * H * W; d.kind = SRC_NCHW_SHIFT; d.nch = cin; d.nq = cin / 4; d.cbase = sb * cin; d.pad = 0;
+        d.rsv = (3 * (sb / 3) - 3 + 8) | ((3 * (sb % 3) - 3 + 8) << 4) | (pre_relu ? 256 : 0);
+    }
+    a.kq = 9 * cin / 4; a.cin_total = 9 * cin; a.cout = cout; a.ctiles = (cout + 31) / 32;
+    a.N = n; a.H = H; a.W = W; a.act = CRFP_ACT_NONE; a.post_scale = 1.0f; a.store = ST_NCHW;
+    a.ndst = 1; a.dst[0].p = out; a.dst[0].bstride = (long long)cout * H * W; a.dst[0].q0 = 0; a.dst[0].q1 = (cout + 3) / 4;
+    float* w9 = scratch;
+    float* wpk = w9 + align_up((size_t)cout * 81 * cin, 64);
+    float* bpk = wpk + align_up(conv_packed_weight_floats(a), 64);
+    float* part = bpk + align_up((size_t)a.ctiles * 32, 64);
+    const int total = cout * 81 * cin;
+    spy_w9_kernel<<<(total + 255) / 256 < 512 ? (total + 255) / 256 : 512, 256, 0, s>>>(w7, w9, cout, cin);
+    CRFP_CHECK_LAUNCH();
+    // Coarse pyramid levels: the whole conv is a handful of workgroups, each walking all 9 cin / 8 K chunks on the (slow) fp32 MFMA --
+    // ~200 us whatever the map size.  There every shifted view gets its own workgroup (ConvArgs::ksplit = 9) that writes a partial sum,
+    // and a fixed-order pass adds bias + the nine partials: deterministic, 9x the parallelism.
+    const long long wgs = (long long)((W + 63) / 64) * ((H + 3) / 4) * a.ctiles * n;
+    const bool split = wgs * 9 <= 2048 && (size_t)9 * n * cout * H * W <= partial_floats;
+    int rc = launch_conv_pack(a, w9, split ? nullptr : bias, nullptr, nullptr, cout, wpk, bpk, s);
+    if (rc) return rc;
+    a.wpk = wpk; a.bpk = bpk;
+    if (!split) return launch_conv_mfma(a, "spynet_conv7_mfma", s);
+    a.ksplit = 9;
+    a.dst[0].p = part;
+    rc = launch_conv_mfma(a, "spynet_conv7_mfma_ksplit", s);
+    if (rc) return rc;
+    const long long per = (long long)cout * H * W;
+    spy_sum9_kernel<<<(unsigned)((per * n + 255) / 256), 256, 0, s>>>(part, bias, out, per, (long long)H * W, cout, n);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -200,8 +296,9 @@ int crfp_upsample_bilinear_ac_f32(const float* x, float* out, int n, int c, int 
 size_t crfp_spynet_workspace_bytes(int n, int h, int w) {
     if (n < 1 || h < 1 || w < 1) return 0;
     const size_t px = (size_t)up32(h) * up32(w);
-    // pyramids of both frames (3 ch, sum over levels < 4/3), warped (3), flow x2 (2 + 2), conv ping-pong (64 + 64)
-    return align_up((size_t)n * px * sizeof(float) * (2 * 4 + 3 + 4 + 128), 256) + 4096;
+    // pyramids of both frames (3 ch, sum over levels < 4/3), warped (3), flow x2 (2 + 2), conv ping-pong (64 + 64), the first conv's
+    // 8-channel input, and the rearranged + packed weights of one 7x7 conv at a time (largest: 32 -> 64)
+    return align_up((size_t)n * px * sizeof(float) * (2 * 4 + 3 + 4 + 128 + 8), 256) + align_up((spy_mfma_scratch_floats(32, 64) + spy_partial_floats(n, px)) * sizeof(float), 256) + 4096;
 }
 
 int crfp_spynet_forward(const float* const* params, const float* ref, const float* supp, float* flow, int n, int h, int w,
@@ -218,7 +315,9 @@ int crfp_spynet_forward(const float* const* params, const float* ref, const floa
         for (int l = 0; l < 6; ++l) { pyr[f][l] = p; p += (size_t)n * 3 * (hu >> l) * (wu >> l); }   // l = 0 finest
     float* warped = p; p += (size_t)n * 3 * hu * wu;
     float* fl[2] = {p, p + (size_t)n * 2 * hu * wu}; p += (size_t)n * 4 * hu * wu;
-    float* t0 = p; float* t1 = p + (size_t)n * 64 * hu * wu;
+    float* t0 = p; float* t1 = p + (size_t)n * 64 * hu * wu; p += (size_t)n * 128 * hu * wu;
+    float* x8 = p; p += (size_t)n * 8 * hu * wu;
+    float* wscratch = p;
     // torch computes in / out in float for size= resizes
     const float sh = (float)h / (float)hu, sw = (float)w / (float)wu;
     for (int f = 0; f < 2; ++f) {
@@ -246,19 +345,20 @@ int crfp_spynet_forward(const float* const* params, const float* ref, const floa
         spy_warp_border_kernel<<<px_grid(W, H, n), 256, 0, s>>>(pyr[1][l], flow_up, warped, 3, H, W);
         CRFP_CHECK_LAUNCH();
         const float* in = nullptr;
+        spy_cat8_kernel<<<dim3((unsigned)(((long long)H * W + 255) / 256), n), 256, 0, s>>>(pyr[0][l], warped, flow_up, x8, (long long)H * W);
+        CRFP_CHECK_LAUNCH();
         for (int j = 0; j < 5; ++j) {
-            SpyConvArgs a;
-            memset(&a, 0, sizeof(a));
-            if (j == 0) { a.src[0] = pyr[0][l]; a.nch[0] = 3; a.src[1] = warped; a.nch[1] = 3; a.src[2] = flow_up; a.nch[2] = 2; a.nsrc = 3; }
-            else { a.src[0] = in; a.nch[0] = chans[j]; a.nsrc = 1; }
-            a.w = params[(level * 5 + j) * 2]; a.b = params[(level * 5 + j) * 2 + 1];
-            a.N = n; a.cin = chans[j]; a.cout = chans[j + 1]; a.H = H; a.W = W; a.pre_relu = 1;
-            float* o = j == 4 ? fl[cur ^ 1] : ((j & 1) ? t1 : t0);
-            a.out = o;
-            a.resid = j == 4 ? flow_up : nullptr;   // flow = flow_up + out
-            int rc = launch_spy_conv(a, 7, s);
+            // 8 -> 32 -> 64 -> 32 -> 16 -> 2 on the MFMA; flow = flow_up + out of the last one (:660) in a tiny pass of its own
+            float* o = (j & 1) ? t1 : t0;
+            int rc = spy_conv7_mfma(j == 0 ? x8 : in, chans[j], params[(level * 5 + j) * 2], params[(level * 5 + j) * 2 + 1], o, chans[j + 1], n, H, W,
+                                    1, wscratch, spy_partial_floats(n, (size_t)hu * wu), s);
             if (rc) return rc;
             in = o;
+            if (j == 4) {
+                const long long tot = (long long)n * 2 * H * W;
+                spy_add_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(o, flow_up, fl[cur ^ 1], tot);
+                CRFP_CHECK_LAUNCH();
+            }
         }
         cur ^= 1;
     }
