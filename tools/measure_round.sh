@@ -5,7 +5,9 @@ TAG=${1:-r02_vX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 mkdir -p gpurun_out
-for c in 2 3 4 5; do python bench.py --config $c > gpurun_out/${TAG}_bench_c$c.json 2> gpurun_out/${TAG}_bench_c$c.err; done
+# the default run (what the driver runs: config 2 + short legs of configs 3 / 4 / 5), then the full lines of the bf16 configs
+python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_c2.json 2> gpurun_out/${TAG}_bench_c2.err
+for c in 3 4 5; do python bench.py --config $c > gpurun_out/${TAG}_bench_c$c.json 2> gpurun_out/${TAG}_bench_c$c.err; done
 python tools/site_table.py > gpurun_out/${TAG}_site_f32.txt 2>&1
 python tools/site_table.py --storage bf16 > gpurun_out/${TAG}_site_bf16.txt 2>&1
 bash tools/collect_profiles.sh ${TAG}_f32 > gpurun_out/${TAG}_collect_f32.log 2>&1

@@ -42,3 +42,16 @@ for k in mf:
     rows.append((g, k, calls[k], mfma, lds, bc))
 for g, k, c, mfma, lds, bc in sorted(rows, reverse=True)[:14]:
     print(f"{k[:44]:44s} {c:6d} {mfma:12.1f} {lds:11.1f} {bc:13.1f}")
+
+co, _ = load("coexec")
+if co:
+    print()
+    print(f"{'kernel':44s} {'COEXEC / MFMA-busy %':>20s} {'WAIT_ANY / WAVE_CYCLES %':>25s} {'VALU active / WAVE_CYCLES %':>28s}")
+    for g, k, c, mfma, lds, bc in sorted(rows, reverse=True)[:14]:
+        d = co.get(k)
+        if not d:
+            continue
+        busy = mf[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * co[k].get("_cycles", 1.0) / max(mf[k].get("_cycles", 1.0), 1.0)
+        wc = d.get("SQ_WAVE_CYCLES", 0.0)
+        print(f"{k[:44]:44s} {100.0 * d.get('SQ_VALU_MFMA_COEXEC_CYCLES', 0.0) / busy if busy else float('nan'):20.1f} "
+              f"{100.0 * d.get('SQ_WAIT_ANY', 0.0) / wc if wc else float('nan'):25.1f} {100.0 * d.get('SQ_ACTIVE_INST_VALU', 0.0) / wc if wc else float('nan'):28.1f}")
