@@ -919,6 +919,15 @@ __global__ __launch_bounds__(S8_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const int T0 = bwork - btile * ngrp;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
+#ifdef CRFP_LAB
+    // diagnostic timeline (CRFP_STAMP_PTR / CRFP_STAMP_NAME, tools/stamp_conv8.py): absolute s_memtime of wave 0 at kernel entry,
+    // first tile in LDS, end of chunk 0's MFMAs, end of the MFMA loop, epilogue stores issued, stores acknowledged
+    long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (a.stamps) ts[0] = __builtin_amdgcn_s_memtime();
+#define S8_STAMP(I) if (a.stamps) ts[I] = __builtin_amdgcn_s_memtime();
+#else
+#define S8_STAMP(I)
+#endif
 
     int cgy[S8_NIN], cgx[S8_NIN];
     bool sval[S8_NIN];
@@ -1022,6 +1031,7 @@ __global__ __launch_bounds__(S8_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             if (idx < S8_WPC) wlds[idx] = rws[k];
         }
         __syncthreads();
+        if (ch == 0) { S8_STAMP(1) }
         if (ch + 1 < nchunks) CRFP_S8_ISSUE(ch + 1)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -1039,7 +1049,13 @@ __global__ __launch_bounds__(S8_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wA, b0, acc[0][pt], 0, 0, 0);
             }
         }
+#ifdef CRFP_LAB
+        if (a.stamps && ch == 0) { asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[0][1][15])); ts[2] = __builtin_amdgcn_s_memtime(); }
+#endif
     }
+#ifdef CRFP_LAB
+    if (a.stamps) { asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[0][1][15])); ts[3] = __builtin_amdgcn_s_memtime(); }
+#endif
 #undef CRFP_S8_ISSUE
 #undef CRFP_QDESC
 #pragma unroll
@@ -1048,6 +1064,20 @@ __global__ __launch_bounds__(S8_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         for (int e = 0; e < 16; ++e) acc[0][pt][e] *= (1.0f / F16_RES_SCALE);
     const EpiCtx ec = epi_ctx(a, n);
     conv_epilogue<1, 2, 1, 2>(ec, acc, T0, tx0, ty0, wave, j, h);
+#ifdef CRFP_LAB
+    if (a.stamps) {
+        ts[4] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[5] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            long long* o = a.stamps + (long long)blockIdx.x * 8;
+            for (int q = 0; q < 6; ++q) o[q] = ts[q];
+            o[6] = __builtin_amdgcn_s_getreg(6 << 11 | 4 << 6 | 20);   // HW_REG_HW_ID (id 4), offset 0? -> unused placeholder
+            o[7] = 1;
+        }
+    }
+#endif
+#undef S8_STAMP
 }
 
 #endif  // !CRFP_ACT_BF16
