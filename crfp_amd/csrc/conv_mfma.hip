@@ -900,11 +900,17 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
 // the bias enters as 2^11 b and the result leaves through one multiply by 2^-11).  Three weight images instead of two,
 // 32 VGPRs less; with 8 waves per workgroup (8 rows x 64 pixels, one weight image per 8 rows instead of per 4) the kernel
 // fits 128 VGPRs: 2 workgroups = 16 waves per CU, 450 tiles on 512 slots -- one round.  Needs |w| < 32 (A must stay finite).
-constexpr int S8_NT = 512, S8_TH = 8, S8_LH = S8_TH + 2, S8_NEL = S8_LH * LW, S8_NIN = (S8_NEL + S8_NT - 1) / S8_NT;
-constexpr int S8_WPC = 9 * 3 * 64, S8_NWS = (S8_WPC + S8_NT - 1) / S8_NT;
+constexpr int S8_TH = 8;
+constexpr int S8_WPC = 9 * 3 * 64;
 
-__global__ __launch_bounds__(S8_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_split8_kernel(const ConvArgs a) {
-    __shared__ bf16x8 tile[2][2][S8_NEL];        // [split part][quad pair][halo pixel]   42.2 KB
+// NW = 8: two workgroups per CU (the shipped form).  NW = 16 (A/B builds, -DCRFP_S8_NW=16): ONE 16-row workgroup per CU -- the 27.6 KB
+// weight stage is loaded once per CU instead of twice and the halo is 18 / 16 instead of 10 / 8 rows: 104 instead of 139 KB of ingest
+// per CU and chunk (profiles/r03_conv_split8_timeline.txt: the prologue is ingest-bound).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_split8_kernel(const ConvArgs a) {
+    constexpr int S8_NT = 64 * NW, S8_LH = NW + 2, S8_NEL = S8_LH * LW, S8_NIN = (S8_NEL + S8_NT - 1) / S8_NT;
+    constexpr int S8_NWS = (S8_WPC + S8_NT - 1) / S8_NT;
+    __shared__ bf16x8 tile[2][2][S8_NEL];        // [split part][quad pair][halo pixel]   42.2 KB (NW = 8)
     __shared__ bf16x8 wlds[S8_WPC];              // [(tap, image A/B/C)][lane]            27.6 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CRFP_PRIO47   // A/B builds: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(S8_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const int ngrp = a.ctiles;
     const int bwork = xcd_band_tile(blockIdx.x, gridDim.x);
     const int btile = bwork / ngrp;
-    const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * S8_TH;
+    const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * NW;
     const int T0 = bwork - btile * ngrp;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
@@ -2480,8 +2486,13 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // instead of 1.17 rounds of 900; same-box: conv1 26.4 -> 24.6 us, conv2 28.7 -> 26.1, block0 46.0 -> 43.2, main0 40.0 ->
         // 38.0, clip -1.5 %); with several cout tiles the 4-wave kernel stays (offset/mask head 114.0 vs 117.7 us)
         if (a.ctiles == 1 && !uses_s3_dst_only_4wave(a)) {
-            const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + S8_TH - 1) / S8_TH);
-            conv3x3_split8_kernel<<<dim3(tiles8 * a.ctiles, 1, a.N), S8_NT, 0, s>>>(am);
+#ifdef CRFP_S8_NW
+            constexpr int s8nw = CRFP_S8_NW;
+#else
+            constexpr int s8nw = S8_TH;
+#endif
+            const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + s8nw - 1) / s8nw);
+            conv3x3_split8_kernel<s8nw><<<dim3(tiles8 * a.ctiles, 1, a.N), 64 * s8nw, 0, s>>>(am);
         } else
             conv3x3_split_kernel<1, 1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
 #endif
