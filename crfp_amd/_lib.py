@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRFP_HIP_LIB") or os.path.join(_HERE, "libcrfp_hip.so")
 
 NUM_PARAMS = 118
+RT_NUM_PARAMS = 158   # CRFP_RT_NUM_PARAMS
 DSV_Y_ONLY, DSV_STRICT_F32, DSV_SINGLE_STREAM = 1, 2, 4   # flags of crfp_dsv_forward_clip / crfp_dsv_stream_frame
 
 c_float_p = C.POINTER(C.c_float)
@@ -63,6 +64,12 @@ SIGNATURES = {
     "crfp_dsv_stream_frame": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 3 +
                               [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_fnet_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_rt_param_name": (C.c_char_p, [C.c_int]),
+    "crfp_rt_param_numel": (C.c_int, [C.c_int, C.c_int]),
+    "crfp_rt_packed_weight_bytes": (C.c_size_t, [C.c_int]),
+    "crfp_rt_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_rt_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
+    "crfp_rt_forward_clip": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_prof_enable": (C.c_int, [C.c_int]),
     "crfp_prof_reset": (C.c_int, []),
     "crfp_prof_report": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),

@@ -222,3 +222,89 @@ class DSVEngine:
         _lib.check(self._fn("crfp_dsv_debug_fetch")(name.encode(), t, h, w, ws.data_ptr(), out.data_ptr(), None, None, None,
                                           _stream()), "crfp_dsv_debug_fetch")
         return out
+
+
+class RuntimeEngine:
+    """Handle on the one-call schedule of the benchmark-only regional wiring (crfp_amd/csrc/engine_rt.hip; reference
+    model/CRFP_runtime.py::MRCF_simple_v18.forward, :8469-8664): packed weights + one workspace per geometry, one
+    ``crfp_rt_forward_clip`` per clip.  fp32 storage, default (split-fp16) precision; the range guard poisons the output
+    frames with NaN like DSVEngine's and ``overflowed()`` tells why."""
+
+    WEIGHT_LIMIT_SPLIT = DSVEngine.WEIGHT_LIMIT_SPLIT
+
+    def __init__(self, state_dict, device, y_only: bool = False):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("crfp_amd.RuntimeEngine needs a CUDA/HIP device (no CPU path in the product)")
+        self.y_only = int(bool(y_only))
+        self._ws = {}
+        self._last_ws = None
+        self.pack(state_dict)
+
+    @staticmethod
+    def param_names():
+        L = _lib.lib()
+        return [L.crfp_rt_param_name(i).decode() for i in range(_lib.RT_NUM_PARAMS)]
+
+    def pack(self, state_dict):
+        L = _lib.lib()
+        names = self.param_names()
+        missing = [k for k in names if k not in state_dict]
+        if missing:
+            raise KeyError(f"state_dict lacks MRCF_simple_v18 parameters: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        keep = []
+        ptrs = (C.c_void_p * _lib.RT_NUM_PARAMS)()
+        for i, k in enumerate(names):
+            t = state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            want = L.crfp_rt_param_numel(i, self.y_only)
+            if t.numel() != want:
+                raise ValueError(f"parameter {k}: {t.numel()} elements, expected {want}")
+            keep.append(t)
+            ptrs[i] = t.data_ptr()
+        wnames = [k for k in names if k.endswith(".weight")]
+        wmax = torch.stack([t.abs().max() for t, k in zip(keep, names) if k.endswith(".weight")]).cpu()
+        if not torch.isfinite(wmax).all():
+            raise ValueError(f"crfp_amd: parameter {wnames[int((~torch.isfinite(wmax)).nonzero()[0])]} holds inf / NaN")
+        if float(wmax.max()) >= self.WEIGHT_LIMIT_SPLIT:   # same operand range as DSVEngine's default precision; no strict mode here
+            raise ValueError(f"crfp_amd: weight {wnames[int(wmax.argmax())]} has max |w| = {float(wmax.max()):.4g} >= "
+                             f"{self.WEIGHT_LIMIT_SPLIT:g}, outside the operand range of the split-fp16 convolution scheme")
+        nbytes = L.crfp_rt_packed_weight_bytes(self.y_only)
+        self.packed = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.crfp_rt_pack_weights(ptrs, self.y_only, self.packed.data_ptr(), nbytes, _stream()), "crfp_rt_pack_weights")
+            torch.cuda.current_stream().synchronize()   # `keep` may be freed after this point
+
+    def _workspace(self, key):
+        if key not in self._ws:
+            nb = _lib.lib().crfp_rt_workspace_bytes(*key)
+            if nb == 0:
+                raise ValueError(f"unsupported geometry (t, h, w, fh, fw, wp_h, wp_w) = {key}: {_lib.lib().crfp_last_error_string().decode(errors='replace')}")
+            self._ws = {key: torch.empty(nb, dtype=torch.uint8, device=self.device)}   # keep one geometry alive
+        return self._ws[key]
+
+    def overflowed(self) -> bool:
+        """True when the range guard fired in the last forward (any clip of the batch).  Synchronises the device."""
+        return self._ovf is not None and bool(int(self._ovf.item()) & 1)
+
+    _ovf = None
+
+    def forward(self, lrs, fvs, warp_size):
+        """lrs[n,t,3,h,w], fvs[n,t,3,fh,fw] (the fovea crop) -> [n,t,3|1,8h,8w]"""
+        lrs, fvs = _dev(lrs, "lrs"), _dev(fvs, "fvs")
+        n, t, c, h, w = lrs.shape
+        fh, fw = fvs.shape[-2:]
+        if c != 3 or tuple(fvs.shape[:3]) != (n, t, 3):
+            raise ValueError(f"lrs {tuple(lrs.shape)} / fvs {tuple(fvs.shape)}: expected [n,t,3,h,w] and [n,t,3,fh,fw]")
+        key = (t, h, w, fh, fw, int(warp_size[0]), int(warp_size[1]))
+        ws = self._workspace(key)
+        out = torch.empty(n, t, 1 if self.y_only else 3, 8 * h, 8 * w, dtype=torch.float32, device=self.device)
+        L = _lib.lib()
+        ovf = torch.zeros(1, dtype=torch.int32, device=self.device) if n > 1 else None
+        with torch.cuda.device(self.device):
+            for b in range(n):
+                _lib.check(L.crfp_rt_forward_clip(self.packed.data_ptr(), self.y_only, lrs[b].data_ptr(), fvs[b].data_ptr(), out[b].data_ptr(),
+                                                  *key, ws.data_ptr(), ws.numel(), _stream()), "crfp_rt_forward_clip")
+                if ovf is not None:
+                    ovf |= ws[:4].view(torch.int32)
+        self._ovf = ovf if ovf is not None else ws[:4].view(torch.int32)
+        return out

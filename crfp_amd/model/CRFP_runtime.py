@@ -1,8 +1,12 @@
 """Host-side mirror of the reference's benchmark-only wiring ``model/CRFP_runtime.py::MRCF_simple_v18`` (:8364-8682), the
 model ``test_runtime.py`` builds through ``from model import MRCF_runtime`` (:1,41) and calls as
 ``model(lr, fv, warp_size=(WP_h, WP_w))`` (:142).  Same constructor, parameter names and call signature; every
-convolution, warp, DCN and resize runs in libcrfp_hip.so through the per-operator C-ABI (crfp_amd.ops), the remaining
-steps are views / crops / concatenations of device tensors.
+convolution, warp, DCN and resize runs in libcrfp_hip.so.  Two routes to the same arithmetic:
+  * ``forward`` with ``print_timings = False``: ONE C-ABI call per clip (``crfp_rt_forward_clip``, csrc/engine_rt.hip) -- the
+    whole wiring scheduled inside the library on its Q4 / P4 layouts; what ``crfp_amd.runtime_rig`` times;
+  * ``forward`` with ``print_timings = True`` (the constructor default, as the reference prints on every call): the wiring
+    composed of per-operator C-ABI calls (crfp_amd.ops) with the reference's five stage timers around them (a host
+    synchronisation per stage, like the reference's).
 
 How this wiring differs from CRFP_DSV (model/CRFP.py:1387-1706) -- restated from the cited lines:
   * flow (FNet), warps and all four DCNs only see the top-left ``warp_size`` window (:8487, :8533-8620); the 8x state that
@@ -103,6 +107,36 @@ class MRCF_simple_v18(nn.Module):
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
         self.print_timings = True        # the reference prints its stage means on every call (:8654-8662)
         self.last_timings = {}
+        self._engine = None
+        self._engine_sig = None
+        self._engine_sum = None
+
+    # ---- packed-weight management: same contract as CRFP_DSV's (model/CRFP.py of this package)
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _checksum(self):
+        flat = torch.cat([p.detach().reshape(-1) for p in self.parameters()]).double()
+        return torch.stack([flat.sum(), flat.abs().sum(), (flat * torch.arange(1, flat.numel() + 1, device=flat.device, dtype=torch.float64)).sum()])
+
+    def invalidate_packed(self):
+        """drop the packed weights; needed only after writes through ``.data`` (CRFP_CHECK_PACKED=1 detects a missed one)"""
+        self._engine_sig = None
+
+    def engine(self):
+        import os
+        from crfp_amd.engine import RuntimeEngine
+        dev = next(self.parameters()).device
+        sig = self._signature()
+        check = os.environ.get("CRFP_CHECK_PACKED") == "1"
+        if self._engine is None or self._engine_sig != sig or self._engine.device != dev:
+            self._engine = RuntimeEngine(self.state_dict(), dev, y_only=self.y_only)
+            self._engine_sig = sig
+            self._engine_sum = self._checksum() if check else None
+        elif check and self._engine_sum is not None and not torch.equal(self._engine_sum, self._checksum()):
+            raise RuntimeError("crfp_amd: parameters changed without their version counters moving (a write through `.data`?): "
+                               "the packed weights are stale -- call model.invalidate_packed() after such writes")
+        return self._engine
 
     def _upsample_post_lrelu(self, x):
         """lrelu(pixel_shuffle(conv(x), 4)) (:8602, :8636): the activation is elementwise, so it and the shuffle ride in the conv's store"""
@@ -117,6 +151,16 @@ class MRCF_simple_v18(nn.Module):
 
     @torch.no_grad()
     def forward(self, lrs, fvs, warp_size=(1080, 1920)):
+        if not self.print_timings:
+            if self.mid_channels != 32:
+                raise NotImplementedError("the one-call schedule is built for mid_channels = 32 (test_runtime.py:41); "
+                                          "print_timings = True runs the per-operator composition")
+            return self.engine().forward(lrs, fvs, warp_size)
+        return self.forward_staged(lrs, fvs, warp_size)
+
+    @torch.no_grad()
+    def forward_staged(self, lrs, fvs, warp_size=(1080, 1920)):
+        """the wiring as per-operator calls with the reference's stage timers (:8469-8664)"""
         WP_h, WP_w = warp_size
         n, t, c, h, w = lrs.shape
         lists = {k: [] for k in ("flow", "enc", "dcn", "res", "last")}

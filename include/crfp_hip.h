@@ -246,6 +246,23 @@ int crfp_prof_report(crfp_prof_record* out, int cap);
 int crfp_dsv_debug_fetch(const char* name, int t, int h, int w, const void* workspace, float* out_nchw,
                          int* c_out, int* h_out, int* w_out, void* stream);
 
+/* ---- The benchmark-only regional wiring, model/CRFP_runtime.py::MRCF_simple_v18.forward(lrs, fvs, warp_size) (:8469-8664;
+ * built and timed by the reference's test_runtime.py:41,142) as ONE call per clip.  mid_channels = 32, split_ratio = 3, offset_prop.
+ * Same conventions as the CRFP_DSV engine above: parameters as CRFP_RT_NUM_PARAMS device pointers in state_dict order
+ * (crfp_rt_param_name), packed once, one workspace, everything enqueued on `stream`.  FNet, the warps and the four DCNs only see the
+ * top-left (wp_h, wp_w) window of the 8x frame (multiples of 8, >= 64, inside the frame); fvs is the (fh, fw) fovea crop the
+ * reference feeds twice to encoder_hr (:8507) and fuses into the top-left (fh, fw) pixels (:8645-8648).
+ * lrs[t,3,h,w], fvs[t,3,fh,fw], out[t,3|1,8h,8w] fp32.  Default (split-fp16) precision only: CRFP_DSV_STRICT_F32 is refused;
+ * the overflow word sits at byte 0 of the workspace and poisons the output like the CRFP_DSV engine's. */
+#define CRFP_RT_NUM_PARAMS 158
+const char* crfp_rt_param_name(int index);
+int crfp_rt_param_numel(int index, int y_only);
+size_t crfp_rt_packed_weight_bytes(int y_only);
+int crfp_rt_pack_weights(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+size_t crfp_rt_workspace_bytes(int t, int h, int w, int fh, int fw, int wp_h, int wp_w);   /* 0: bad geometry (crfp_last_error) */
+int crfp_rt_forward_clip(const void* packed, int flags, const float* lrs, const float* fvs, float* out, int t, int h, int w,
+                         int fh, int fw, int wp_h, int wp_w, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

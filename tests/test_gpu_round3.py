@@ -306,3 +306,72 @@ def test_role_specialised_fused_dcn_kernel_is_bit_identical():
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     dig = {ln.split()[0]: ln.split(" digest ")[1].split()[0] for ln in r.stdout.splitlines() if " digest " in ln}
     assert set(dig) == {"v1", "v2"} and dig["v1"] == dig["v2"], r.stdout + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ regional wiring as one C-ABI call (f4)
+def _runtime_model(seed, y_only=False):
+    from crfp_amd import synth
+    from crfp_amd.model import MRCF_runtime
+    m = MRCF_runtime.MRCF_simple_v18(mid_channels=32, y_only=y_only, hr_dcn=True, offset_prop=True, split_ratio=3,
+                                     spynet_pretrained='pretrained_models/fnet.pth', device=dev())
+    sd = synth.make_state_dict_like({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
+    m.load_state_dict({k: T(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.to(dev()).eval()
+    m.print_timings = False       # -> crfp_rt_forward_clip (csrc/engine_rt.hip)
+    return m, sd
+
+
+def test_runtime_engine_one_call_vs_reference_golden_and_oracle(orc):
+    """``MRCF_runtime.MRCF_simple_v18(...)(lr, fv, warp_size=)`` through ``crfp_rt_forward_clip`` -- the whole wiring of
+    model/CRFP_runtime.py:8469-8664 scheduled inside the library -- against the output of the reference class itself
+    (tests/golden/runtime_small.npz), against the per-operator composition, and against the oracle at geometries the golden does
+    not cover: window = whole frame, a window that is not a multiple of 64, ragged frame sizes, t = 1, y_only."""
+    from oracle import runtime_oracle as ro
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "runtime_small.npz")))
+    m, sd = _runtime_model(int(g["weights_seed"]))
+    lrs, fvs, warp = T(g["lrs"]).to(dev()), T(g["fvs"]).to(dev()), tuple(int(v) for v in g["warp"])
+    out = m(lrs, fvs, warp_size=warp)
+    assert tuple(out.shape) == g["out"].shape and _stats(out, T(g["out"]))[0] < 2e-4
+    assert not m.engine().overflowed()
+    staged = m.forward_staged(lrs, fvs, warp)
+    assert _stats(out, staged.cpu())[0] < 2e-4
+    again = m(lrs, fvs, warp_size=warp)                     # same workspace, second clip: the recurrent state is reset per call
+    assert torch.equal(out, again)
+    P = orc.load_numpy_state(sd)
+    rs = np.random.RandomState(5)
+    for (t, h, w, fv, wp) in ((2, 16, 40, 48, (128, 192)),     # window = the whole frame in y
+                              (2, 17, 27, 40, (136, 216)),     # window = the whole (ragged) frame
+                              (3, 21, 30, 56, (72, 104)),      # window not a multiple of 64, FNet resize 8 x 8 -> 9 x 13
+                              (1, 12, 20, 96, (64, 64))):      # one frame: no flow, no DCN; fovea = the whole frame height
+        l = T(rs.rand(1, t, 3, h, w).astype(np.float32))
+        f = T(rs.rand(1, t, 3, fv, fv).astype(np.float32))
+        got = m(l.to(dev()), f.to(dev()), warp_size=wp)
+        ref = ro.runtime_forward(P, l, f, wp)
+        assert tuple(got.shape) == tuple(ref.shape) and _stats(got, ref)[0] < 2e-4, (t, h, w, fv, wp, _stats(got, ref))
+    my, sdy = _runtime_model(3, y_only=True)
+    l = T(rs.rand(2, 2, 3, 16, 24).astype(np.float32))
+    f = T(rs.rand(2, 2, 3, 32, 32).astype(np.float32))
+    got = my(l.to(dev()), f.to(dev()), warp_size=(96, 128))
+    ref = ro.runtime_forward(orc.load_numpy_state(sdy), l, f, (96, 128), y_only=True)
+    assert tuple(got.shape) == (2, 2, 1, 128, 192) and _stats(got, ref)[0] < 2e-4
+    # geometry the schedule cannot run is refused by name, nothing is computed
+    with pytest.raises(ValueError, match="warp_size"):
+        m(lrs, fvs, warp_size=(100, 192))
+    with pytest.raises(ValueError, match="warp_size"):
+        m(lrs, fvs, warp_size=(256, 192))                   # taller than the 192-row frame
+    # `.data` writes + invalidate_packed, like CRFP_DSV
+    m.conv_last.weight.data *= 0.5
+    m.invalidate_packed()
+    half = m(lrs, fvs, warp_size=warp)
+    assert _stats(half, out.cpu())[0] > 1e-3
+
+
+def test_runtime_engine_overflow_poisons_output():
+    """an activation beyond the fp16 operand range inside the regional schedule: the frames come back NaN and overflowed() says why"""
+    m, sd = _runtime_model(11)
+    m.encoder_lr.slice1[0].bias.data.fill_(7.0e4)
+    m.invalidate_packed()
+    l = torch.rand(1, 2, 3, 16, 24, device=dev())
+    f = torch.rand(1, 2, 3, 32, 32, device=dev())
+    out = m(l, f, warp_size=(64, 64))
+    assert m.engine().overflowed() and torch.isnan(out).all()

@@ -82,7 +82,9 @@ def test_packs_and_blocks(ops_golden, weights_np):
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_fnet(ops_golden, weights_np, tag):
     g, P = ops_golden, orc.load_numpy_state(weights_np)
-    close(orc.fnet(P, "spynet.", T(g[f"fnet_{tag}_x1"]), T(g[f"fnet_{tag}_x2"])), g[f"fnet_{tag}_y"], 2e-5)
+    # flows are 256 * tanh(.) pixels: one fp32 ulp at that magnitude is 3e-5, and torch's CPU convolutions change their summation
+    # order with the thread partition (seen once: 2e-5 exceeded on a loaded host)
+    close(orc.fnet(P, "spynet.", T(g[f"fnet_{tag}_x1"]), T(g[f"fnet_{tag}_x2"])), g[f"fnet_{tag}_y"], 1e-4)
 
 
 def test_dcn_module_wiring(ops_golden, weights_np):
