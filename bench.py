@@ -30,6 +30,8 @@ Extra objects on that line:
   parity        max|HIP - oracle| (bf16 configs: statistics against the twin) and PSNR-Y delta on that sample.
   other_configs (default run only) BASELINE configs[2..4] -- `--config 3|4|5` -- each as a short leg (3 steps) in a child process
                 after the headline's timed region: frames/s, ms per step, parity against the bf16 twin on 3 frames, conv roofline.
+  runtime_rig   (default run only) the reference's test_runtime.py measurement: ms per 1080p frame of the regional wiring (one C-ABI call
+                per 5-frame clip) and of the whole-frame CRFP_DSV engine on the same rig.
   warp_dcn_8d   SURVEY 8(d)'s figure un-re-scoped: API-tensor bytes of flow_warp x3 + DCNv2 x4 per steady-state frame divided by
                 the time of ALL warp / DCN kernels of such a frame, the fused offset-head + DCN kernel included.
   collectives   which backend ran the barrier / MAX / SUM reductions (CRFP_FORCE_DIST=1 initialises RCCL even with one rank).
@@ -446,6 +448,16 @@ def main():
                 "fnet_6pairs@lr": time_op(lambda: eng.compute_flow(data[0][0][0, 1:7], data[0][0][0, 0:6]), 10) if t >= 7 else None,
                 "spynet_1pair@192x320": time_op(lambda: spy(spy_a, spy_b), 5),
                 "note": "wall-clock per call incl. the NCHW <-> Q4 conversions the operator boundary needs (the engine pays none of them)"}
+
+    if extras and storage == "f32" and args.config == 2 and not custom:
+        # the reference's stand-alone speed test (test_runtime.py:81-99,142-186) on the regional wiring: 1 x 5 frames, 135 x 240 -> 1080p,
+        # 96 x 96 fovea crop, 720 x 720 warp window; one crfp_rt_forward_clip per clip (csrc/engine_rt.hip)
+        from crfp_amd import runtime_rig
+        _, spf = runtime_rig.run(repeat_time=30, warm_up=10)
+        _, spf_dsv = runtime_rig.run(repeat_time=12, warm_up=4, variant="dsv")
+        result["runtime_rig"] = {"regional_ms_per_1080p_frame": round(1e3 * spf, 4), "dsv_whole_frame_ms_per_1080p_frame": round(1e3 * spf_dsv, 4),
+                                 "note": "seconds / (repeat - warm_up + 1) / t as test_runtime.py:186 prints it; regional = MRCF_runtime.MRCF_simple_v18 "
+                                         "through crfp_rt_forward_clip (round 2: 3.0 ms composed of per-operator calls)"}
 
     if extras and args.config == 2 and not custom and not args.no_other_configs:
         # BASELINE configs[2..4] (the bf16 configurations) as short legs in child processes, outside the headline's timed region:

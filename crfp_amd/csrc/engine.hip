@@ -784,6 +784,7 @@ __global__ void round_bf16_copy_kernel(const float* __restrict__ src, float* __r
 namespace crfp_bf16 { void shutdown_side_streams() { for (int d = 0; d < kMaxDevices; ++d) g_side[d].destroy(); } }
 #else
 namespace crfp_bf16 { void shutdown_side_streams(); }
+namespace crfp { void rt_shutdown_streams(); }   // engine_rt.hip
 #endif
 
 extern "C" {
@@ -994,6 +995,7 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
 int crfp_shutdown(void) {
     for (int d = 0; d < kMaxDevices; ++d) g_side[d].destroy();
     crfp_bf16::shutdown_side_streams();
+    crfp::rt_shutdown_streams();
     return 0;
 }
 #endif

@@ -210,8 +210,10 @@ struct Layout {
     size_t status, state, carry, prev2;
     size_t lr_q4, lrw_q4, e_lr0, x_lr, fvq, eh0, x_hr, flow_lr;
     size_t fa0, fa1, fp1, fb0, fb1, fp2, fc0, fc1, fp3, fd0, fd1, fu1, fe0, fe1, fu2, ff0, ff1, fu3, fg0, fg1;
-    size_t prop0, prop_a, prop_b, y0f, y1f, tmp8f, flow2, flow8, state_w, prev2w, carryw, win, fa, fb, offfeat[3], aligned, y0, y1;
-    size_t up_full, upw, poff, g0, g1, g2, al3, tmpw, featf, z1, feat2, fcrop, tcrop;
+    // [2]: written by the state-independent pre-work of frame i into set i & 1 while frame i - 1 still reads the other set; [3]: one per
+    // level (the three levels of a frame run on three streams)
+    size_t prop0[2], prop_a, prop_b, y0f, y1f, tmp8f, flow2[2], flow8[2], state_w, prev2w, carryw, win[2], fa[3], fb[3], offfeat[3], aligned[3], y0[3], y1[3];
+    size_t up_full[2], upw[2], poff, g0, g1, g2, al3, tmpw, featf[2], z1, feat2, fcrop, tcrop;
 
     // Q4 tensor of nq quads (pad = 1: P4 planes with a zeroed guard in front, see engine.hip); kind 1 = [H][W][2] floats
     size_t take(int N, int nq, int H, int W, int kind = 0, int pad = 0) {
@@ -248,18 +250,23 @@ struct Layout {
         fe0 = take(nb, 32, 2 * h3, 2 * w3); fe1 = take(nb, 32, 2 * h3, 2 * w3); fu2 = take(nb, 32, 4 * h3, 4 * w3);
         ff0 = take(nb, 16, 4 * h3, 4 * w3); ff1 = take(nb, 16, 4 * h3, 4 * w3); fu3 = take(nb, 16, 8 * h3, 8 * w3);
         fg0 = take(nb, 8, 8 * h3, 8 * w3); fg1 = take(nb, 1, 8 * h3, 8 * w3);
-        prop0 = take(1, 6, H2, W2); prop_a = take(1, 6, H2, W2); prop_b = take(1, 6, H2, W2);
+        prop_a = take(1, 6, H2, W2); prop_b = take(1, 6, H2, W2);
         y0f = take(1, 8, H2, W2); y1f = take(1, 4, H2, W2); tmp8f = take(1, 2, H2, W2);
-        flow2 = take(1, 0, wh2, ww2, 1); flow8 = take(1, 0, wh8, ww8, 1);
+        for (int p = 0; p < 2; ++p) {
+            prop0[p] = take(1, 6, H2, W2); win[p] = take(1, 6, wh2, ww2);
+            flow2[p] = take(1, 0, wh2, ww2, 1); flow8[p] = take(1, 0, wh8, ww8, 1);
+            up_full[p] = take(1, 1, H8, W8); upw[p] = take(1, 1, wh8, ww8); featf[p] = take(1, 1, H8, W8);
+        }
         state_w = take(1, 1, wh8, ww8);
-        prev2w = take(1, 8, wh2, ww2); carryw = take(1, 6, wh2, ww2); win = take(1, 6, wh2, ww2);
-        fa = take(1, 8, wh2, ww2); fb = take(1, 8, wh2, ww2);
-        for (int l = 0; l < 3; ++l) offfeat[l] = take(1, 8, wh2, ww2);
-        aligned = take(1, 8, wh2, ww2); y0 = take(1, 8, wh2, ww2); y1 = take(1, 4, wh2, ww2);
-        up_full = take(1, 1, H8, W8); upw = take(1, 1, wh8, ww8); poff = take(1, 1, wh8, ww8);
+        prev2w = take(1, 8, wh2, ww2); carryw = take(1, 6, wh2, ww2);
+        for (int l = 0; l < 3; ++l) {
+            fa[l] = take(1, 8, wh2, ww2); fb[l] = take(1, 8, wh2, ww2); offfeat[l] = take(1, 8, wh2, ww2);
+            aligned[l] = take(1, 8, wh2, ww2); y0[l] = take(1, 8, wh2, ww2); y1[l] = take(1, 4, wh2, ww2);
+        }
+        poff = take(1, 1, wh8, ww8);
         g0 = take(1, 1, wh8, ww8); g1 = take(1, 1, wh8, ww8); g2 = take(1, 1, wh8, ww8); al3 = take(1, 1, wh8, ww8);
         tmpw = take(1, 1, wh8, ww8);
-        featf = take(1, 1, H8, W8); z1 = take(1, 1, H8, W8); feat2 = take(1, 1, H8, W8);
+        z1 = take(1, 1, H8, W8); feat2 = take(1, 1, H8, W8);
         fcrop = take(1, 1, fh, fw); tcrop = take(1, 1, fh, fw);
     }
     size_t bytes() const { return cur; }
@@ -302,6 +309,47 @@ __global__ void rt_lrelu_paste_kernel(float4* __restrict__ feat, int H, int W, c
     feat[(long long)y * W + x] = v;
     const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));   // the state feeds split-fp16 convs
     if (ovf && !(m < 65504.0f)) atomicOr(ovf, 1u);
+}
+
+// ------------------------------------------------------------------ side streams
+// Three non-blocking streams + an event pool per (host thread, device), created lazily by the first crfp_rt_forward_clip on that device
+// and destroyed by crfp_shutdown(): the same contract as the CRFP_DSV engine's side stream (crfp_hip.h).  Every call joins all of them
+// back into the caller's stream before it returns.
+struct Lanes {
+    hipStream_t s[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    bool ok = true;
+    hipEvent_t next_event() {
+        if (used == ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ok = false; return nullptr; }
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    bool create() {
+        for (int i = 0; i < 3 && ok; ++i)
+            if (!s[i] && hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) ok = false;
+        return ok;
+    }
+    void destroy() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear(); used = 0;
+        for (int i = 0; i < 3; ++i) { if (s[i]) (void)hipStreamDestroy(s[i]); s[i] = nullptr; }
+        ok = true;
+    }
+};
+constexpr int kRtMaxDevices = 64;
+static thread_local Lanes g_lanes[kRtMaxDevices];
+static Lanes* lanes_for_current_device() {
+    static const bool on = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);   // read once
+    int dev = 0;
+    if (!on || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kRtMaxDevices) return nullptr;
+    Lanes& l = g_lanes[dev];
+    if (!l.create()) return nullptr;
+    l.used = 0;
+    return &l;
 }
 
 // ------------------------------------------------------------------ the schedule
@@ -384,65 +432,139 @@ struct Runner {
         if (!rc && hipMemsetAsync(ws + off - guard, 0, bytes + guard, s) != hipSuccess) { set_error("rt: hipMemsetAsync failed"); rc = 1; }
     }
 
-    void frame(int i, const float* lr_nchw, float* out) {
-        const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
-        const int wh2 = L.wh2, ww2 = L.ww2, wh8 = L.wh8, ww8 = L.ww8;
-        const long long P2w = (long long)wh2 * ww2 * 4, P2wp = (long long)(wh2 + 1) * (ww2 + 1) * 4, P2f = (long long)H2 * W2 * 4;
+    // ---- streams.  Lane 0 is the caller's stream; lanes 1..3 are the library's side streams (null pool: every lane is the caller's
+    // stream and rec() / wait() do nothing -- the enqueue order below is a valid single-stream order as it stands)
+    Lanes* lanes = nullptr;
+    hipStream_t main_s = nullptr;
+    void on(int lane) { s = (lanes && lane) ? lanes->s[lane - 1] : main_s; }
+    hipEvent_t rec() {
+        if (!lanes || rc) return nullptr;
+        hipEvent_t e = lanes->next_event();
+        if (!e || hipEventRecord(e, s) != hipSuccess) { set_error("rt: hipEventRecord failed"); rc = 1; return nullptr; }
+        return e;
+    }
+    void wait(hipEvent_t e) {
+        if (!lanes || rc || !e) return;
+        if (hipStreamWaitEvent(s, e, 0) != hipSuccess) { set_error("rt: hipStreamWaitEvent failed"); rc = 1; }
+    }
+    // every lane drains into the caller's stream (also after an error: the caller may reuse its buffers once `stream` has drained)
+    void join_all() {
+        if (!lanes) return;
+        for (int l = 0; l < 3; ++l) {
+            hipEvent_t e = lanes->next_event();
+            if (e && hipEventRecord(e, lanes->s[l]) == hipSuccess) (void)hipStreamWaitEvent(main_s, e, 0);
+        }
+        s = main_s;
+    }
+
+    // state-independent work of frame i >= 1 into parity set i & 1 (current stream): the flow fields at 2x / 8x, upsample(x_lr) and its
+    // window (:8524, :8548), lrelu(upsample_post(.)) and its window (:8602), forward_resblocks_3.conv2 on the full frame (:8607-8609)
+    void frame_pre(int i) {
+        const int par = i & 1, h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         const float* x_lr_i = F(L.x_lr) + (long long)i * 8 * h * w * 4;
-        mfma(RI_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0), 0, 0, 6}}, H2, W2);                      // feat_prop_lv0 = upsample(x_lr) (:8524)
+        const float* flow = F(L.flow_lr) + (long long)(i - 1) * L.whl * L.wwl * 4;
+        RUN(launch_upflow(flow, 0, F(L.flow2[par]), 0, 1, L.whl, L.wwl, 2, s));                       // :8531-8532
+        RUN(launch_upflow(flow, 0, F(L.flow8[par]), 0, 1, L.whl, L.wwl, 8, s));
+        mfma(RI_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0[par]), 0, 0, 6}}, H2, W2);
+        RUN(rt_copy_q4(F(L.prop0[par]), H2, W2, 0, F(L.win[par]), L.wh2, L.ww2, 0, 6, L.wh2, L.ww2, s));
+        mfma(RI_UPP, 1, H2, W2, {{F(L.prop0[par]), 0}}, {{F(L.up_full[par]), 0, 0, 1}}, H8, W8);
+        RUN(rt_copy_q4(F(L.up_full[par]), H8, W8, 0, F(L.upw[par]), L.wh8, L.ww8, 0, 1, L.wh8, L.ww8, s));
+        narrow(RI_R3_C2, H8, W8, {F(L.up_full[par])}, F(L.featf[par]));
+    }
+
+    // level l of frame i >= 1 up to its offset feature (current stream): dcn_block.0 -> .2 (-> conv_fuse with the previous level's feature)
+    void level_head(int l, int par, const float* offprev) {
+        const int wh2 = L.wh2, ww2 = L.ww2;
+        const float* cw = F(L.carryw) + 2 * l * (long long)wh2 * ww2 * 4;
+        mfma(it_lvl(l, L_DB0), 1, wh2, ww2, {{F(L.win[par]), 0}, {cw, 0}, {F(L.prev2w), 0}, {F(L.flow2[par]), 0}, {nullptr, 0}}, {{F(L.fa[l]), 0, 0, 8}});
+        if (l == 0) mfma(it_lvl(l, L_DB1), 1, wh2, ww2, {{F(L.fa[l]), 0}}, {}, 0, 0, nullptr, nullptr, F(L.offfeat[l]));
+        else mfma(it_lvl(l, L_DB1), 1, wh2, ww2, {{F(L.fa[l]), 0}}, {{F(L.fb[l]), 0, 0, 8}});
+        (void)offprev;
+    }
+    void level_fuse(int l, const float* offprev) {
+        mfma(it_lvl(l, L_FUSE), 1, L.wh2, L.ww2, {{F(L.fb[l]), 0}, {offprev, 0}}, {}, 0, 0, nullptr, nullptr, F(L.offfeat[l]));
+    }
+    // ... and from the offset feature to the carried 8 channels: fused offset head + DCN, forward_resblocks_l([cur | carry | aligned], .) of
+    // which only channels 24..31 leave the level (:8571-8599)
+    void level_tail(int l, int par) {
+        const int wh2 = L.wh2, ww2 = L.ww2;
+        const long long P2w = (long long)wh2 * ww2 * 4, P2wp = (long long)(wh2 + 1) * (ww2 + 1) * 4;
+        const float* cw = F(L.carryw) + 2 * l * P2w;
+        const Item& om = M.items[it_lvl(l, L_OMF)];
+        const Item& dw = M.items[it_lvl(l, L_DCNW)];
+        DcnFuseArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.feat = F(L.offfeat[l]); fa.flow = F(L.flow2[par]);
+        fa.wconv = (const char*)(packed + om.off_s) + conv_split16_offset_bytes(om.c); fa.bconv = packed + om.off_b;
+        fa.x = F(L.prev2); fa.wdcn = packed + dw.off_w + 36 * 2 * 32 * 4; fa.bdcn = packed + dw.off_b;
+        fa.out = F(L.aligned[l]); fa.N = 1; fa.H = wh2; fa.W = ww2; fa.ovf = ovf();
+        RUN(launch_dcn_fused(fa, s));
+        mfma(it_lvl(l, L_C1), 1, wh2, ww2, {{F(L.win[par]), 0}, {cw, 0}, {F(L.aligned[l]), 0}}, {{F(L.y0[l]), 0, 0, 8}});
+        mfma(it_lvl(l, L_B1), 1, wh2, ww2, {{F(L.y0[l]), 0}}, {{F(L.y1[l]), 0, 0, 4}});
+        mfma(it_lvl(l, L_B2), 1, wh2, ww2, {{F(L.y1[l]), 0}}, {{F(L.carry) + 2 * l * P2wp, 0, 6, 8, 1}}, 0, 0, F(L.y0[l]));
+    }
+
+    hipEvent_t pre_done[2] = {nullptr, nullptr}, frame_done[2] = {nullptr, nullptr};
+
+    void frame(int i, int t, const float* lr_nchw, float* out) {
+        const int par = i & 1, h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
+        const int wh2 = L.wh2, ww2 = L.ww2, wh8 = L.wh8, ww8 = L.ww8;
+        const long long P2wp = (long long)(wh2 + 1) * (ww2 + 1) * 4;
         float* feat = F(L.feat2);
+        hipEvent_t e_l[3] = {nullptr, nullptr, nullptr};
+        on(0);
         if (i > 0) {
-            const float* flow = F(L.flow_lr) + (long long)(i - 1) * L.whl * L.wwl * 4;
-            RUN(launch_upflow(flow, 0, F(L.flow2), 0, 1, L.whl, L.wwl, 2, s));                       // :8531-8532
-            RUN(launch_upflow(flow, 0, F(L.flow8), 0, 1, L.whl, L.wwl, 8, s));
-            RUN(launch_flow_warp_q4(F(L.state), 0, F(L.flow8), 0, F(L.state_w), 0, 1, 1, wh8, ww8, 0, 1, s));   // :8534-8535
+            wait(pre_done[par]);
+            RUN(launch_flow_warp_q4(F(L.state), 0, F(L.flow8[par]), 0, F(L.state_w), 0, 1, 1, wh8, ww8, 0, 1, s));   // :8534-8535
             mfma(RI_DOWN, 1, wh2, ww2, {{F(L.state_w), 0, 0}}, {{F(L.prev2w), 0, 0, 8}});               // prev2_w = downsample(state_w) (:8536)
             mfma(RI_DOWN, 1, wh2, ww2, {{F(L.state), 0, 1}}, {{F(L.prev2), 0, 0, 8, 1}});               // prev2 = downsample(state) (:8537)
-            RUN(launch_flow_warp_q4(F(L.carry), 0, F(L.flow2), 0, F(L.carryw), 0, 1, 6, wh2, ww2, 0, 1, s));    // :8538-8547
-            RUN(rt_copy_q4(F(L.prop0), H2, W2, 0, F(L.win), wh2, ww2, 0, 6, wh2, ww2, s));               // cur_win (:8548)
-            const float* offprev = nullptr;
-            for (int l = 0; l < 3; ++l) {
-                const float* cw = F(L.carryw) + 2 * l * P2w;
-                float* f = F(L.offfeat[l]);
-                mfma(it_lvl(l, L_DB0), 1, wh2, ww2, {{F(L.win), 0}, {cw, 0}, {F(L.prev2w), 0}, {F(L.flow2), 0}, {nullptr, 0}}, {{F(L.fa), 0, 0, 8}});
-                if (l == 0) mfma(it_lvl(l, L_DB1), 1, wh2, ww2, {{F(L.fa), 0}}, {}, 0, 0, nullptr, nullptr, f);
-                else {
-                    mfma(it_lvl(l, L_DB1), 1, wh2, ww2, {{F(L.fa), 0}}, {{F(L.fb), 0, 0, 8}});
-                    mfma(it_lvl(l, L_FUSE), 1, wh2, ww2, {{F(L.fb), 0}, {offprev, 0}}, {}, 0, 0, nullptr, nullptr, f);
-                }
-                const Item& om = M.items[it_lvl(l, L_OMF)];
-                const Item& dw = M.items[it_lvl(l, L_DCNW)];
-                DcnFuseArgs fa;
-                memset(&fa, 0, sizeof(fa));
-                fa.feat = f; fa.flow = F(L.flow2);
-                fa.wconv = (const char*)(packed + om.off_s) + conv_split16_offset_bytes(om.c); fa.bconv = packed + om.off_b;
-                fa.x = F(L.prev2); fa.wdcn = packed + dw.off_w + 36 * 2 * 32 * 4; fa.bdcn = packed + dw.off_b;
-                fa.out = F(L.aligned); fa.N = 1; fa.H = wh2; fa.W = ww2; fa.ovf = ovf();
-                RUN(launch_dcn_fused(fa, s));
-                // forward_resblocks_l([cur | carry | aligned], .) -> only the carried 8 channels leave the level (:8571-8599)
-                mfma(it_lvl(l, L_C1), 1, wh2, ww2, {{F(L.win), 0}, {cw, 0}, {F(L.aligned), 0}}, {{F(L.y0), 0, 0, 8}});
-                mfma(it_lvl(l, L_B1), 1, wh2, ww2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 4}});
-                mfma(it_lvl(l, L_B2), 1, wh2, ww2, {{F(L.y1), 0}}, {{F(L.carry) + 2 * l * P2wp, 0, 6, 8, 1}}, 0, 0, F(L.y0));
-                offprev = f;
+            RUN(launch_flow_warp_q4(F(L.carry), 0, F(L.flow2[par]), 0, F(L.carryw), 0, 1, 6, wh2, ww2, 0, 1, s));   // :8538-8547
+            hipEvent_t e_base = rec();
+            // The three levels read the same window features and only hand the offset feature down (:8549-8599): their dcn_block convs
+            // run side by side, conv_fuse of level l waits for level l - 1's feature, and everything behind a level's feature is its own.
+            level_head(0, par, nullptr);
+            hipEvent_t e_off0 = rec();
+            on(2); wait(e_base);
+            level_head(1, par, nullptr);
+            wait(e_off0);
+            level_fuse(1, F(L.offfeat[0]));
+            hipEvent_t e_off1 = rec();
+            level_tail(1, par);
+            e_l[1] = rec();
+            on(3); wait(e_base);
+            level_head(2, par, nullptr);
+            wait(e_off1);
+            level_fuse(2, F(L.offfeat[1]));
+            mfma(RI_POFF, 1, wh2, ww2, {{F(L.offfeat[2]), 0}}, {{F(L.poff), 0, 0, 1}}, wh8, ww8);
+            hipEvent_t e_poff = rec();
+            level_tail(2, par);
+            e_l[2] = rec();
+            on(1); wait(e_off0);
+            level_tail(0, par);
+            e_l[0] = rec();
+            if (i + 1 < t) {   // the next frame's pre-work, into the set frame i - 1 has finished with
+                wait(frame_done[par ^ 1]);
+                frame_pre(i + 1);
+                pre_done[par ^ 1] = rec();
             }
-            mfma(RI_UPP, 1, H2, W2, {{F(L.prop0), 0}}, {{F(L.up_full), 0, 0, 1}}, H8, W8);             // lrelu(upsample_post(.)) (:8602)
-            RUN(rt_copy_q4(F(L.up_full), H8, W8, 0, F(L.upw), wh8, ww8, 0, 1, wh8, ww8, s));
-            mfma(RI_POFF, 1, wh2, ww2, {{offprev, 0}}, {{F(L.poff), 0, 0, 1}}, wh8, ww8);
-            narrow(RI_D3B0, wh8, ww8, {F(L.upw), F(L.state_w), F(L.flow8)}, F(L.g0));
+            on(0);
+            narrow(RI_D3B0, wh8, ww8, {F(L.upw[par]), F(L.state_w), F(L.flow8[par])}, F(L.g0));
             narrow(RI_D3B1, wh8, ww8, {F(L.g0)}, F(L.g1));
+            wait(e_poff);
             narrow(RI_D3FUSE, wh8, ww8, {F(L.g1), F(L.poff)}, F(L.g2));
             const Item& om3 = M.items[RI_D3OM];
             const Item& d3 = M.items[RI_D3W];
-            RUN(launch_dcn3_fused(F(L.state), 0, F(L.g2), 0, F(L.flow8), packed + om3.off_w, packed + om3.off_b, packed + d3.off_w, packed + d3.off_b,
+            RUN(launch_dcn3_fused(F(L.state), 0, F(L.g2), 0, F(L.flow8[par]), packed + om3.off_w, packed + om3.off_b, packed + d3.off_w, packed + d3.off_b,
                                   F(L.al3), 0, 1, wh8, ww8, s));
-            // forward_resblocks_3([upw | aligned], up): conv2 on the full frame, conv1's window result pasted over it (:8607-8609)
-            narrow(RI_R3_C2, H8, W8, {F(L.up_full)}, F(L.featf));
-            narrow(RI_R3_C1, wh8, ww8, {F(L.upw), F(L.al3)}, F(L.tmpw));
-            RUN(rt_copy_q4(F(L.tmpw), wh8, ww8, 0, F(L.featf), H8, W8, 0, 1, wh8, ww8, s));
-            narrow(RI_R3_B1, H8, W8, {F(L.featf)}, F(L.z1));
-            narrow(RI_R3_B2, H8, W8, {F(L.z1)}, feat, F(L.featf));
+            // forward_resblocks_3([upw | aligned], up): conv1's window result pasted over conv2 of the full frame (:8607-8609)
+            narrow(RI_R3_C1, wh8, ww8, {F(L.upw[par]), F(L.al3)}, F(L.tmpw));
+            RUN(rt_copy_q4(F(L.tmpw), wh8, ww8, 0, F(L.featf[par]), H8, W8, 0, 1, wh8, ww8, s));
+            narrow(RI_R3_B1, H8, W8, {F(L.featf[par])}, F(L.z1));
+            narrow(RI_R3_B2, H8, W8, {F(L.z1)}, feat, F(L.featf[par]));
         } else {
-            float* prop = F(L.prop0);
+            const float* x_lr_0 = F(L.x_lr);
+            mfma(RI_UPS, 1, h, w, {{x_lr_0, 0}}, {{F(L.prop0[0]), 0, 0, 6}}, H2, W2);                   // feat_prop_lv0 = upsample(x_lr) (:8524)
+            float* prop = F(L.prop0[0]);
             float* nxt[3] = {F(L.prop_a), F(L.prop_b), F(L.prop_a)};
             for (int l = 0; l < 3; ++l) {   // forward_resblocks_l_(prop) on the full frame (:8617-8633)
                 mfma(it_first(l, 0), 1, H2, W2, {{prop, 0}, {nullptr, 0}}, {{F(L.y0f), 0, 0, 8}});
@@ -451,11 +573,10 @@ struct Runner {
                 RUN(rt_copy_q4(F(L.tmp8f), H2, W2, 0, F(L.carry) + 2 * l * P2wp, wh2, ww2, 1, 2, wh2, ww2, s));
                 prop = nxt[l];
             }
-            (void)P2f;
-            mfma(RI_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up_full), 0, 0, 1}}, H8, W8);                    // :8636
-            narrow(RI_R3F_C1, H8, W8, {F(L.up_full)}, F(L.featf));                                      // forward_resblocks_3_(up) (:8637)
-            narrow(RI_R3F_B1, H8, W8, {F(L.featf)}, F(L.z1));
-            narrow(RI_R3F_B2, H8, W8, {F(L.z1)}, feat, F(L.featf));
+            mfma(RI_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up_full[0]), 0, 0, 1}}, H8, W8);                 // :8636
+            narrow(RI_R3F_C1, H8, W8, {F(L.up_full[0])}, F(L.featf[0]));                                // forward_resblocks_3_(up) (:8637)
+            narrow(RI_R3F_B1, H8, W8, {F(L.featf[0])}, F(L.z1));
+            narrow(RI_R3F_B2, H8, W8, {F(L.z1)}, feat, F(L.featf[0]));
         }
         // conv_tttf on the fovea crop, pasted back, LeakyReLU everywhere (:8645-8648)
         RUN(rt_copy_q4(feat, H8, W8, 0, F(L.fcrop), L.fh, L.fw, 0, 1, L.fh, L.fw, s));
@@ -467,12 +588,15 @@ struct Runner {
             if (hipGetLastError() != hipSuccess) { set_error("rt: lrelu_paste launch failed"); rc = 1; }
         }
         narrow(RI_LAST, H8, W8, {feat}, out, nullptr, nullptr, 0, 0, lr_nchw);                           // conv_last + x8 bilinear LR (:8652-8654)
+        for (int l = 0; l < 3; ++l) wait(e_l[l]);                                                        // the carried features of this frame are complete
         RUN(rt_copy_q4(feat, H8, W8, 0, F(L.state), wh8, ww8, 1, 1, wh8, ww8, s));                        // the carried state = the window (:8650)
+        frame_done[par] = rec();
     }
 #undef RUN
 };
 
 }  // namespace rt
+void rt_shutdown_streams() { for (int d = 0; d < rt::kRtMaxDevices; ++d) rt::g_lanes[d].destroy(); }
 }  // namespace crfp
 
 using namespace crfp;
@@ -558,6 +682,9 @@ int crfp_rt_forward_clip(const void* packed, int flags, const float* lrs, const 
     if (workspace_bytes < L.bytes()) { set_error("rt_forward_clip: workspace %zu < required %zu bytes", workspace_bytes, L.bytes()); return CRFP_E_WORKSPACE; }
     Runner R{model_for(y_only), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     hipStream_t s = (hipStream_t)stream;
+    R.main_s = s;
+    // per-kernel timing brackets launches per stream and CRFP_DSV_SINGLE_STREAM asks for it: everything on the caller's stream
+    R.lanes = (prof_enabled() || (flags & CRFP_DSV_SINGLE_STREAM)) ? nullptr : lanes_for_current_device();
     // pads of the P4 tensors must read as zero; the carried features start at zero
     R.zero(L.status, 256);
     R.zero(L.state, Layout::p4_bytes(1, L.wh8, L.ww8), Layout::p4_guard(L.ww8));
@@ -570,16 +697,25 @@ int crfp_rt_forward_clip(const void* packed, int flags, const float* lrs, const 
     CRFP_CHECK_LAUNCH();
     rc = launch_nchw_to_q4(fvs, R.F(L.fvq), t, 3, fh, fw, 0, s);
     if (rc) return rc;
-    const long long lw = (long long)L.whl * L.wwl * 4;
-    if (t > 1) R.fnet(t - 1, R.F(L.lrw_q4) + lw, R.F(L.lrw_q4));                                         // flows on the LR window (:8487)
-    const long long lf = (long long)h * w * 4;
+    // from here on other streams may hold work of this call: every exit goes through join_all()
+    hipEvent_t e_in = R.rec();
+    const long long lf = (long long)h * w * 4, ff = (long long)fh * fw * 4, lw = (long long)L.whl * L.wwl * 4;
     R.mfma(RI_ENC_LR0, t, h, w, {{R.F(L.lr_q4), lf}}, {{R.F(L.e_lr0), 8 * lf, 0, 8}});
     R.mfma_q(RI_ENC_LR1, t, R.F(L.e_lr0), 8, R.F(L.x_lr), 8, h, w);
-    const long long ff = (long long)fh * fw * 4;
+    hipEvent_t e_enc = R.rec();
+    if (t > 1) {   // lane 1: flows on the LR window (:8487), then frame 1's state-independent work -- beside frame 0 on the caller's stream
+        R.on(1); R.wait(e_in);
+        R.fnet(t - 1, R.F(L.lrw_q4) + lw, R.F(L.lrw_q4));
+        R.wait(e_enc);
+        R.frame_pre(1);
+        R.pre_done[1] = R.rec();
+        R.on(0);
+    }
     R.narrow(RI_EH0, fh, fw, {R.F(L.fvq), R.F(L.fvq)}, R.F(L.eh0), nullptr, nullptr, 0, 0, nullptr, ff, t, ff);   // encoder_hr(cat(fv, fv)) (:8507)
     R.narrow(RI_EH1, fh, fw, {R.F(L.eh0)}, R.F(L.x_hr), nullptr, nullptr, 0, 0, nullptr, ff, t, ff);
     const int co = y_only ? 1 : 3;
-    for (int i = 0; i < t && !R.rc; ++i) R.frame(i, lrs + (long long)i * 3 * h * w, out + (long long)i * co * 64 * h * w);
+    for (int i = 0; i < t && !R.rc; ++i) R.frame(i, t, lrs + (long long)i * 3 * h * w, out + (long long)i * co * 64 * h * w);
+    R.join_all();
     return R.rc;
 }
 

@@ -237,8 +237,8 @@ class RuntimeEngine:
         if self.device.type != "cuda":
             raise RuntimeError("crfp_amd.RuntimeEngine needs a CUDA/HIP device (no CPU path in the product)")
         self.y_only = int(bool(y_only))
+        self.single_stream = False   # True: CRFP_DSV_SINGLE_STREAM (no work on the library's side streams; same bits)
         self._ws = {}
-        self._last_ws = None
         self.pack(state_dict)
 
     @staticmethod
@@ -300,9 +300,10 @@ class RuntimeEngine:
         out = torch.empty(n, t, 1 if self.y_only else 3, 8 * h, 8 * w, dtype=torch.float32, device=self.device)
         L = _lib.lib()
         ovf = torch.zeros(1, dtype=torch.int32, device=self.device) if n > 1 else None
+        flags = self.y_only | (_lib.DSV_SINGLE_STREAM if self.single_stream else 0)
         with torch.cuda.device(self.device):
             for b in range(n):
-                _lib.check(L.crfp_rt_forward_clip(self.packed.data_ptr(), self.y_only, lrs[b].data_ptr(), fvs[b].data_ptr(), out[b].data_ptr(),
+                _lib.check(L.crfp_rt_forward_clip(self.packed.data_ptr(), flags, lrs[b].data_ptr(), fvs[b].data_ptr(), out[b].data_ptr(),
                                                   *key, ws.data_ptr(), ws.numel(), _stream()), "crfp_rt_forward_clip")
                 if ovf is not None:
                     ovf |= ws[:4].view(torch.int32)

@@ -6,8 +6,9 @@ exactly as the reference's last line does (its divisor counts one repetition too
 Two variants:
   regional (default)  what test_runtime.py itself runs: ``MRCF_runtime.MRCF_simple_v18(...)(lr, fv, warp_size=(720, 720))``
                       = crfp_amd/model/CRFP_runtime.py, the mirror of the reference's benchmark-only wiring
-                      (model/CRFP_runtime.py:8364-8682), composed of per-operator C-ABI calls; it prints the reference's
-                      per-stage means (flow / enc / dcn / res / last / total) on every call.
+                      (model/CRFP_runtime.py:8364-8682), as ONE C-ABI call per clip (crfp_rt_forward_clip, csrc/engine_rt.hip).
+                      With --stage-prints it runs the per-operator composition instead and prints the reference's
+                      per-stage means (flow / enc / dcn / res / last / total) on every call (a host sync per stage).
   dsv                 the shipped CRFP_DSV engine (one C-ABI call per clip) over the WHOLE frame with the crop pasted into
                       the warp window -- at least the work of the regional wiring, on the fused path.
 

@@ -252,7 +252,10 @@ int crfp_dsv_debug_fetch(const char* name, int t, int h, int w, const void* work
  * (crfp_rt_param_name), packed once, one workspace, everything enqueued on `stream`.  FNet, the warps and the four DCNs only see the
  * top-left (wp_h, wp_w) window of the 8x frame (multiples of 8, >= 64, inside the frame); fvs is the (fh, fw) fovea crop the
  * reference feeds twice to encoder_hr (:8507) and fuses into the top-left (fh, fw) pixels (:8645-8648).
- * lrs[t,3,h,w], fvs[t,3,fh,fw], out[t,3|1,8h,8w] fp32.  Default (split-fp16) precision only: CRFP_DSV_STRICT_F32 is refused;
+ * lrs[t,3,h,w], fvs[t,3,fh,fw], out[t,3|1,8h,8w] fp32.  flags: CRFP_DSV_Y_ONLY, CRFP_DSV_SINGLE_STREAM.  Default (split-fp16) precision
+ * only: CRFP_DSV_STRICT_F32 is refused.  State kept between calls: three more non-blocking streams + events per (host thread, device)
+ * under the same contract as the CRFP_DSV side stream (the three levels of a frame and the next frame's state-independent work run
+ * beside the recurrent chain; joined before the call returns; CRFP_SIDE_STREAM=0 / CRFP_DSV_SINGLE_STREAM: none; crfp_shutdown() frees them);
  * the overflow word sits at byte 0 of the workspace and poisons the output like the CRFP_DSV engine's. */
 #define CRFP_RT_NUM_PARAMS 158
 const char* crfp_rt_param_name(int index);

@@ -337,6 +337,9 @@ def test_runtime_engine_one_call_vs_reference_golden_and_oracle(orc):
     assert _stats(out, staged.cpu())[0] < 2e-4
     again = m(lrs, fvs, warp_size=warp)                     # same workspace, second clip: the recurrent state is reset per call
     assert torch.equal(out, again)
+    m.engine().single_stream = True                         # the four-stream schedule changes no bit
+    assert torch.equal(out, m(lrs, fvs, warp_size=warp))
+    m.engine().single_stream = False
     P = orc.load_numpy_state(sd)
     rs = np.random.RandomState(5)
     for (t, h, w, fv, wp) in ((2, 16, 40, 48, (128, 192)),     # window = the whole frame in y
