@@ -44,6 +44,14 @@ def main():
             net(lr, fv, warp_size=tuple(a.warp))
         torch.cuda.synchronize()
         wall = 1e3 * (time.perf_counter() - t0) / a.steps
+        enq = []
+        for _ in range(a.steps):            # host time to enqueue one clip (the call returns before the GPU has finished)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            net(lr, fv, warp_size=tuple(a.warp))
+            enq.append(1e3 * (time.perf_counter() - t1))
+        torch.cuda.synchronize()
+        print(f"host enqueue time per clip: min {min(enq):.3f} ms, median {sorted(enq)[len(enq) // 2]:.3f} ms")
         L.crfp_prof_reset(); L.crfp_prof_enable(1)
         for _ in range(a.steps):
             net(lr, fv, warp_size=tuple(a.warp))
