@@ -434,6 +434,7 @@ struct Runner {
     hipStream_t s;
     int rc = 0;
     int strict = 0;     // CRFP_DSV_STRICT_F32: fp32 MFMA for every conv and for dcn_g8's GEMM
+    bool down_done = false;   // one-frame-per-call path: downsample(state) already ran on the side stream, beside FNet
 
     // null in strict mode: no kernel forms fp16 operands, the guard has nothing to watch (the word stays 0)
     unsigned* ovf() const {
@@ -661,7 +662,7 @@ struct Runner {
         if (!first) {
             float* flow2 = F(L.flow2[par]);
             float* flow8 = F(L.flow8[par]);
-            mfma(IT_DOWN, 1, H2, W2, {{F(L.state_hr), 0, 1}}, {{F(L.prev2), 0, 0, 8, 1}});
+            if (!down_done) mfma(IT_DOWN, 1, H2, W2, {{F(L.state_hr), 0, 1}}, {{F(L.prev2), 0, 0, 8, 1}});
             RUN(launch_flow_warp_p4_dual_8_6(F(L.prev2), carry, flow2, F(L.prev2w), F(L.carryw), H2, W2, s));
             RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, 1, s));
             const float* offprev = nullptr;
@@ -984,6 +985,10 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     forked = true;
     R.encode_lr(1, lq, 0);
     R.frame_pre(0, false, lr, fv, mk, nullptr, R.F(L.x_lr), nullptr, 1);
+    // downsample(state) needs nothing of this call: it runs here, beside FNet's small kernels, instead of in front of the recurrent chain
+    // (same box, 24 calls: bf16 27.74 -> 27.40 ms, fp32 45.81 -> 45.23 ms, same bits; profiles/r03_stream_down_side_ab.txt)
+    R.mfma(IT_DOWN, 1, 2 * h, 2 * w, {{R.F(L.state_hr), 0, 1}}, {{R.F(L.prev2), 0, 0, 8, 1}});
+    R.down_done = true;
     if (hipEventRecord(ev_side, ss.s) != hipSuccess) return fail("record");
     R.s = main_s;
     if (hipStreamWaitEvent(main_s, ev_side, 0) != hipSuccess) return fail("join");
