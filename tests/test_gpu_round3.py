@@ -378,3 +378,23 @@ def test_runtime_engine_overflow_poisons_output():
     f = torch.rand(1, 2, 3, 32, 32, device=dev())
     out = m(l, f, warp_size=(64, 64))
     assert m.engine().overflowed() and torch.isnan(out).all()
+
+
+def test_runtime_engine_is_graph_capturable_and_replays_bit_exact():
+    """crfp_rt_forward_clip (four streams, fork / join through events, three memsets) captured into a HIP graph once and replayed on
+    new inputs equals the eager call bit for bit; graph replay is also how a caller removes the 1.1 ms of host enqueue time per clip."""
+    m, _ = _runtime_model(5)
+    rs = np.random.RandomState(8)
+    clips = [(T(rs.rand(1, 3, 3, 24, 40).astype(np.float32)).to(dev()), T(rs.rand(1, 3, 3, 64, 64).astype(np.float32)).to(dev())) for _ in range(2)]
+    eager = [m(l, f, warp_size=(128, 192)).clone() for l, f in clips]     # also creates the library's side streams and events
+    L, Fv = clips[0][0].clone(), clips[0][1].clone()
+    eng = m.engine()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = eng.forward(L, Fv, (128, 192))
+    for i in (0, 1, 0):
+        L.copy_(clips[i][0]); Fv.copy_(clips[i][1])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager[i])
