@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("CRFP_HIP_LIB") or os.path.join(_HERE, "libcrfp_hip.so
 NUM_PARAMS = 118
 RT_NUM_PARAMS = 158   # CRFP_RT_NUM_PARAMS
 DSV_Y_ONLY, DSV_STRICT_F32, DSV_SINGLE_STREAM = 1, 2, 4   # flags of crfp_dsv_forward_clip / crfp_dsv_stream_frame
+DSV_INPUTS_RESIDENT = 8   # crfp_dsv_stream_frame only
 
 c_float_p = C.POINTER(C.c_float)
 

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace CRFP_NS {
@@ -303,7 +304,7 @@ struct Layout {
     // status word (fp16-operand overflow flag), then the persistent recurrent state (stable offsets for streaming)
     size_t status, state_hr, carry;
     // clip-level
-    size_t flow_lr, e_lr0, x_lr, lr_q4;
+    size_t flow_lr, e_lr0, x_lr, lr_q4, lr_keep[2] = {0, 0};
     // FNet
     size_t fa0, fa1, fp1, fb0, fb1, fp2, fc0, fc1, fp3, fd0, fd1, fu1, fe0, fe1, fu2, ff0, ff1, fu3, fg0, fg1;
     // frame-level
@@ -318,7 +319,11 @@ struct Layout {
         status = A.take("status", 1, 0, 1, 32, 1);   // 256 bytes; word 0 = overflow flag
         state_hr = A.take("state_hr", 1, 1, H8, W8, 0, 1);
         carry = A.take("carry", 1, 6, H2, W2, 0, 1);
-        flow_lr = A.take("flow_lr", nb, 1, h, w, 0, 0, true);
+        // one-frame-per-call layout (t == 1): two flow slots and (bf16 build) two kept fp32 copies of the LR frame, indexed by call parity
+        // (CRFP_DSV_INPUTS_RESIDENT: the flow network of call i runs while frame i - 1 still reads the other slot)
+        flow_lr = A.take("flow_lr", t == 1 ? 2 : nb, 1, h, w, 0, 0, true);
+        if (kActBf16 && t == 1)
+            for (int p = 0; p < 2; ++p) lr_keep[p] = A.take(p ? "lr_keep.1" : "lr_keep", 3, 0, h, (w + 1) / 2, 1);   // >= 3 * h * w floats
         lr_q4 = A.take("lr_q4", 2 * t, 1, h, w);   // the LR frames as quads: [0, t) current frames, [t, 2t) previous frames when they are not the same tensor
         e_lr0 = A.take("enc_lr0", t, 8, h, w);
         x_lr = A.take("x_lr", t, 8, h, w);
@@ -390,9 +395,16 @@ struct Layout {
 // forked onto it (fork/join through events recorded on the caller's stream, so the call stays ordered on `stream` and
 // remains graph-capturable).  This is the ONLY state the library keeps between calls (documented in crfp_hip.h);
 // crfp_shutdown() destroys the calling thread's streams and events.
+// host-side note per streamed sequence (keyed by its workspace): what CRFP_DSV_INPUTS_RESIDENT calls need to know about the previous call
+struct StreamCtx {
+    unsigned n = 0;        // calls since the sequence started: parity of the buffer sets
+    bool kept = false;     // the previous call left its LR frame in the workspace
+    bool chained = false;  // the previous call was a two-stream resident call: its side work waited for everything before it on the caller's stream
+};
 struct SideStream {
     hipStream_t s = nullptr;
     std::vector<hipEvent_t> ev;
+    std::unordered_map<const void*, StreamCtx> ctx;
     bool ok = true;
     hipEvent_t event(size_t i) {
         while (ev.size() <= i) {
@@ -405,6 +417,7 @@ struct SideStream {
     void destroy() {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         ev.clear();
+        ctx.clear();
         if (s) (void)hipStreamDestroy(s);
         s = nullptr;
         ok = true;
@@ -414,12 +427,16 @@ constexpr int kMaxDevices = 64;
 static thread_local SideStream g_side[kMaxDevices];
 // streams and events belong to the device that was current when they were created; a device index outside the table
 // gets no side stream (the caller then runs the single-stream schedule) instead of aliasing another device's slot
-static SideStream* side_stream() {
+static SideStream* side_slot() {   // the calling thread's table entry for the current device; creates nothing
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    SideStream& ss = g_side[dev];
-    if (!ss.s && ss.ok && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
-    return ss.ok ? &ss : nullptr;
+    return &g_side[dev];
+}
+static SideStream* side_stream() {
+    SideStream* ss = side_slot();
+    if (!ss) return nullptr;
+    if (!ss->s && ss->ok && hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking) != hipSuccess) ss->ok = false;
+    return ss->ok ? ss : nullptr;
 }
 static bool side_stream_enabled() {
     static const bool on = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);   // read once
@@ -435,6 +452,8 @@ struct Runner {
     int rc = 0;
     int strict = 0;     // CRFP_DSV_STRICT_F32: fp32 MFMA for every conv and for dcn_g8's GEMM
     bool down_done = false;   // one-frame-per-call path: downsample(state) already ran on the side stream, beside FNet
+    int flow_slot = 0;        // one-frame-per-call path: which of the two flow_lr slots FNet writes
+    float* flow_lr_slot() const { return F(L.flow_lr) + (long long)flow_slot * L.h * L.w * 4; }
 
     // null in strict mode: no kernel forms fp16 operands, the guard has nothing to watch (the word stays 0)
     unsigned* ovf() const {
@@ -567,6 +586,7 @@ struct Runner {
         Q4 e0 = q(L.fe0, 32, 2 * L.h3, 2 * L.w3), e1 = q(L.fe1, 32, 2 * L.h3, 2 * L.w3), u2 = q(L.fu2, 32, 4 * L.h3, 4 * L.w3);
         Q4 f0 = q(L.ff0, 16, 4 * L.h3, 4 * L.w3), f1 = q(L.ff1, 16, 4 * L.h3, 4 * L.w3), u3 = q(L.fu3, 16, 8 * L.h3, 8 * L.w3);
         Q4 g0 = q(L.fg0, 8, 8 * L.h3, 8 * L.w3), g1 = q(L.fg1, 1, 8 * L.h3, 8 * L.w3), fl = q(L.flow_lr, 1, h, w);
+        fl.p = flow_lr_slot();
         mfma(IT_F0, nb, h, w, {{cur, cur_bs}, {prev, prev_bs}}, {{a0.p, a0.bs(), 0, 8}});
         mfma_q(IT_F0 + 1, nb, a0, a1);
         RUN(launch_avgpool2_q4(a1.p, a1.bs(), p1.p, p1.bs(), nb, 8, h, w, s));
@@ -949,11 +969,86 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     Layout L(1, h, w);
     int rc = check_common(packed, 1, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
-    if (!lr || !fv || !mk || !out || (!first && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
+    const bool resident = (flags & CRFP_DSV_INPUTS_RESIDENT) != 0;
+    if (!lr || !fv || !mk || !out || (!first && !resident && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
     SideStream* ssp = (!first && side_stream_enabled() && !prof_enabled() && !(flags & CRFP_DSV_SINGLE_STREAM)) ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
+    // per-sequence host note, kept next to the side stream (also when this call runs on one stream)
+    SideStream* tab = side_slot();
+    StreamCtx* ctx = nullptr;
+    if (tab && (resident || tab->ctx.count(workspace))) ctx = &tab->ctx[workspace];
+    if (resident) {
+        // CRFP_DSV_INPUTS_RESIDENT: lr / fv / mk already hold their final values, and the previous frame is the copy the previous call
+        // left in the workspace (the reference keeps `pre_lrs = lrs.clone()` on the model, model/CRFP_test.py:2234-2238).  Buffer sets
+        // alternate with the call parity, so everything of call i that depends on neither the state nor earlier work on `stream` --
+        // FNet, encoder_lr, the fovea blend, encoder_hr, the upsample conv -- is enqueued on the side stream WITHOUT waiting for the
+        // caller's stream: it runs beside frame i - 1's recurrent chain.
+        if (!ctx) { set_error("dsv_stream_frame: CRFP_DSV_INPUTS_RESIDENT needs the per-thread stream table (device index out of range)"); return CRFP_E_UNSUPPORTED; }
+        if (first) *ctx = StreamCtx();
+        else if (!ctx->kept) {
+            set_error("dsv_stream_frame: CRFP_DSV_INPUTS_RESIDENT without a kept previous frame -- start the sequence with first != 0 and the "
+                      "same flag, on this host thread");
+            return CRFP_E_BADARG;
+        }
+        const int par = first ? 0 : (int)(++ctx->n & 1u);
+        const size_t lr_bytes = 3 * (size_t)h * w * sizeof(float);
+        // the kept copy: fp32 build = the Q4 quads FNet reads anyway (slot par of lr_q4); bf16 build = an fp32 NCHW copy (a Q4 copy would be bf16)
+        auto keep_and_get = [&](const float** cur, const float** prev) {
+            if (kActBf16) {
+                if (!R.rc && hipMemcpyAsync(R.F(L.lr_keep[par]), lr, lr_bytes, hipMemcpyDeviceToDevice, R.s) != hipSuccess) { set_error("dsv_stream_frame: hipMemcpyAsync failed"); R.rc = 1; }
+                *cur = lr;
+                *prev = R.F(L.lr_keep[par ^ 1]);
+            } else {
+                *cur = R.lr_to_q4(lr, 1, par);
+                *prev = R.adv(R.F(L.lr_q4), (long long)(par ^ 1) * h * w * 4);
+            }
+        };
+        R.flow_slot = par;
+        const float *cur = nullptr, *prev = nullptr;
+        if (!ssp) {   // one stream (first frame, profiling, CRFP_DSV_SINGLE_STREAM, CRFP_SIDE_STREAM=0): same order, same bits
+            if (first) R.reset_state();
+            keep_and_get(&cur, &prev);
+            if (!first) R.fnet(1, cur, 0, prev, 0);
+            R.encode_lr(1, cur, 0);
+            R.frame_pre(par, first != 0, lr, fv, mk, first ? nullptr : R.flow_lr_slot(), R.F(L.x_lr));
+            R.frame(par, first != 0, lr, mk, out, fg);
+            ctx->kept = R.rc == 0;
+            ctx->chained = false;
+            return R.rc;
+        }
+        SideStream& ss = *ssp;
+        bool forked = false;
+        auto join = [&]() {
+            hipEvent_t ej = ss.event(1);
+            if (forked && ej && hipEventRecord(ej, ss.s) == hipSuccess) (void)hipStreamWaitEvent(main_s, ej, 0);
+        };
+        auto fail = [&](const char* what) { join(); ctx->kept = ctx->chained = false; set_error("dsv_stream_frame: %s failed", what); return 1; };
+        hipEvent_t ev_start = ss.event(0), ev_side = ss.event(1);
+        if (!ss.ok) return fail("hipEventCreate");
+        if (hipEventRecord(ev_start, main_s) != hipSuccess) return fail("record");
+        // Early start is safe only behind a call whose side work waited for ITS fork event: set par was last read by frame i - 2 on the
+        // caller's stream, which that wait ordered in front of everything the side stream did since.
+        const bool early = ctx->chained;
+        R.s = ss.s;
+        forked = true;
+        if (!early && hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
+        keep_and_get(&cur, &prev);
+        R.fnet(1, cur, 0, prev, 0);
+        R.encode_lr(1, cur, 0);
+        R.frame_pre(par, false, lr, fv, mk, R.flow_lr_slot(), R.F(L.x_lr), nullptr, 3);   // incl. the two flow up-samplings (set par as well)
+        if (early && hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
+        R.mfma(IT_DOWN, 1, 2 * h, 2 * w, {{R.F(L.state_hr), 0, 1}}, {{R.F(L.prev2), 0, 0, 8, 1}});   // needs the state frame i - 1 wrote
+        R.down_done = true;
+        if (hipEventRecord(ev_side, ss.s) != hipSuccess) return fail("record");
+        R.s = main_s;
+        if (hipStreamWaitEvent(main_s, ev_side, 0) != hipSuccess) return fail("join");
+        R.frame(par, false, lr, mk, out, fg);
+        ctx->kept = ctx->chained = R.rc == 0;
+        return R.rc;
+    }
+    if (ctx) ctx->kept = ctx->chained = false;   // a call without the flag keeps no frame and orders nothing for a later resident call
     if (!ssp) {
         if (first) R.reset_state();
         const float* lq = R.lr_to_q4(lr, 1, 0);

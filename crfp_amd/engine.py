@@ -37,11 +37,17 @@ class DSVEngine:
             raise RuntimeError("crfp_amd.DSVEngine needs a CUDA/HIP device (no CPU path in the product)")
         self.y_only = int(bool(y_only))
         self.single_stream = False   # True: CRFP_DSV_SINGLE_STREAM on every call (no fork onto the library's side stream)
+        # stream_frame only, CRFP_DSV_INPUTS_RESIDENT: the caller's lr / fv / mk tensors are complete when stream_frame() is called and are
+        # not modified until the stream has drained that call (true for frames that already sit in HBM, e.g. a decoded video held on the
+        # device; NOT true when an earlier kernel or copy on the same stream is still producing them).  The library then keeps the previous
+        # frame itself and runs the state-independent part of each frame beside the previous frame's recurrent chain.  Same bits.
+        self.inputs_resident = False
         self._ws = {}
         self._ovf = None             # int32[1] on the device: status words of the last forward()'s clips, OR-ed (no host sync)
         self._stream_ws = None
         self._stream_prev = None
         self._stream_prev_buf = None
+        self._stream_resident = False
         self._stream_hw = None
         self.pack(state_dict)
 
@@ -167,8 +173,13 @@ class DSVEngine:
     def stream_frame(self, lr, fv, mk, fg=None):
         """lr[3,h,w], fv[3,8h,8w], mk[1,8h,8w], optional regional mask fg[1,8h,8w] -> [3|1,8h,8w]; the first
         call after clear_states() starts a sequence."""
+        if self.inputs_resident:
+            # a conversion here would be a kernel on this stream that is still writing the input when the library starts reading it
+            for name, t_, dt in (("lr", lr, (torch.float32,)), ("fv", fv, (torch.float32,)), ("mk", mk, (torch.bool, torch.uint8))):
+                if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.dtype in dt and t_.is_contiguous()):
+                    raise ValueError(f"crfp_amd: inputs_resident needs `{name}` as a contiguous device tensor of dtype {dt} (no conversion may run)")
         lr, fv = _dev(lr, "lr"), _dev(fv, "fv")
-        mk8 = self._mask_u8(mk)
+        mk8 = mk.view(torch.uint8) if (self.inputs_resident and mk.dtype == torch.bool) else (mk if self.inputs_resident else self._mask_u8(mk))
         fg8 = None if fg is None else self._mask_u8(fg)
         _, h, w = lr.shape
         if self._stream_ws is None or self._stream_hw != (h, w):
@@ -180,16 +191,23 @@ class DSVEngine:
         out = torch.empty((1 if self.y_only else 3, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
         if self.on_overflow == "fallback" and self.precision != "f32":
             raise NotImplementedError("on_overflow='fallback' cannot rewind a streamed sequence: use 'poison' or 'raise'")
+        resident = bool(self.inputs_resident)
+        if not first and resident != self._stream_resident:
+            raise RuntimeError("crfp_amd: inputs_resident changed in the middle of a streamed sequence; call clear_states() first")
+        self._stream_resident = resident
         with torch.cuda.device(self.device):
             _lib.check(self._fn("crfp_dsv_stream_frame")(
-                self.packed.data_ptr(), self._flags(), lr.data_ptr(),
-                None if first else self._stream_prev.data_ptr(), fv.data_ptr(), mk8.data_ptr(),
+                self.packed.data_ptr(), self._flags() | (_lib.DSV_INPUTS_RESIDENT if resident else 0), lr.data_ptr(),
+                None if (first or resident) else self._stream_prev.data_ptr(), fv.data_ptr(), mk8.data_ptr(),
                 None if fg8 is None else fg8.data_ptr(), out.data_ptr(),
                 1 if first else 0, h, w, self._stream_ws.data_ptr(), self._stream_ws.numel(), _stream()),
                 "crfp_dsv_stream_frame")
         self._after(self._stream_ws, (1, h, w), None)
         # the reference keeps a COPY of the frame (model/CRFP_test.py:2234-2238, ``.clone()``): a caller that refills one
         # input buffer in place must not change what the next call sees as the previous frame
+        if resident:            # the library kept the frame inside the workspace
+            self._stream_prev = lr
+            return out
         if self._stream_prev_buf is None or self._stream_prev_buf.shape != lr.shape:
             self._stream_prev_buf = torch.empty_like(lr)
         self._stream_prev_buf.copy_(lr)

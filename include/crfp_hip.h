@@ -182,6 +182,15 @@ size_t crfp_dsv_workspace_bytes(int t, int h, int w);
                                * scheme (fp32-grade, 3 fp16 MFMAs per product, needs |activation|, |weight| < 65504) */
 #define CRFP_DSV_SINGLE_STREAM 4 /* this call enqueues everything on `stream` itself (no fork onto the library's side stream);
                                * same bits, used to measure what the two-stream schedule hides */
+#define CRFP_DSV_INPUTS_RESIDENT 8 /* crfp_dsv_stream_frame only.  The caller promises that lr, fv and mk hold their final values when the call
+                               * is made (no earlier work on `stream` still writes them) and that they stay untouched until `stream` has
+                               * drained this call.  `lr_prev` is ignored (may be NULL): the previous frame is the copy the previous call
+                               * on this workspace left inside it, as the reference's model keeps `pre_lrs = lrs.clone()`
+                               * (model/CRFP_test.py:2234-2238).  Every call of a sequence, from the `first` one on, must carry the flag and
+                               * come from the same host thread (the library keeps a host-side call counter per workspace next to its side
+                               * stream).  In return the state-independent part of frame i (FNet, encoder_lr, fovea blend, encoder_hr, the
+                               * upsample conv) is enqueued on the side stream WITHOUT waiting for `stream` and runs beside frame i - 1's
+                               * recurrent chain (buffer sets alternate with the call parity).  Same bits as without the flag. */
 
 /* Numerics status: a 32-bit word inside the workspace at this byte offset.  Bit 0 is raised (sticky until the next clip
  * / the next `first` streamed frame) when a kernel of the split-fp16 scheme stores a value an fp16 operand cannot hold

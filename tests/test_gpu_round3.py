@@ -398,3 +398,50 @@ def test_runtime_engine_is_graph_capturable_and_replays_bit_exact():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, eager[i])
+
+
+# ------------------------------------------------------------------------------------------------ streaming with resident inputs
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_stream_with_resident_inputs_is_bit_identical(storage):
+    """CRFP_DSV_INPUTS_RESIDENT (engine.inputs_resident): the library keeps the previous LR frame inside the workspace and starts the
+    state-independent part of frame i on its side stream without waiting for the caller's stream, i.e. beside frame i - 1.  Same
+    arithmetic on alternating buffer sets: every frame of a 9-call sequence with a clear_states() in the middle equals the plain
+    one-frame-per-call path bit for bit, on two streams and on one; a sequence that does not start with the flag is refused."""
+    from crfp_amd import _lib, synth
+    sd = synth.make_state_dict(7)
+    t, h, w = 9, 24, 40
+    lrs, fvs, mks = (T(a).to(dev()) for a in synth.make_clip(77, 1, t, h, w, fv_size=64, sigma_t=10.0))
+    mks = mks.bool() if mks.dtype != torch.bool else mks
+
+    def run(resident, single=False):
+        eng = _model(sd, storage=storage).engine()
+        eng.inputs_resident, eng.single_stream = resident, single
+        outs = []
+        for i in range(t):
+            if i == 5:
+                eng.clear_states()
+            outs.append(eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i]).clone())
+        torch.cuda.synchronize()
+        return torch.stack(outs), eng
+
+    base, _ = run(False)
+    res, eng = run(True)
+    assert torch.isfinite(base).all() and torch.equal(base, res)
+    assert torch.equal(base, run(True, single=True)[0])
+    # back-to-back sequences without host synchronisation, outputs checked at the end: the early side work of call i really overlaps call i - 1
+    eng.clear_states()
+    outs = [eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i]) for i in range(5)]
+    assert torch.equal(torch.stack(outs), base[:5])
+    # a float mask would need a conversion kernel on the caller's stream: refused instead of raced
+    with pytest.raises(ValueError, match="inputs_resident"):
+        eng.stream_frame(lrs[0, 5], fvs[0, 5], mks[0, 5].float())
+    # the C-ABI refuses a flagged call on a workspace whose previous call did not keep its frame
+    L = _lib.lib()
+    sfx = "_bf16" if storage == "bf16" else ""
+    nb = getattr(L, "crfp_dsv_workspace_bytes" + sfx)(1, h, w)
+    ws = torch.zeros(nb + 512, dtype=torch.uint8, device=dev())[256:]   # an address no earlier sequence of this thread started at
+    out = torch.empty(3, 8 * h, 8 * w, device=dev())
+    mk8 = mks[0, 1].view(torch.uint8)
+    rc = getattr(L, "crfp_dsv_stream_frame" + sfx)(eng.packed.data_ptr(), _lib.DSV_INPUTS_RESIDENT, lrs[0, 1].data_ptr(), None, fvs[0, 1].data_ptr(),
+                                                   mk8.data_ptr(), None, out.data_ptr(), 0, h, w, ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
+    assert rc < 0 and b"kept previous frame" in L.crfp_last_error_string()   # CRFP_E_BADARG

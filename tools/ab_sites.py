@@ -31,6 +31,7 @@ def child(a):
     eng = m.to(dev).eval().engine()
     lrs, fvs, mks = (torch.from_numpy(x).to(dev) for x in synth.make_clip(1234, 1, a.t, a.h, a.w, fv_size=a.fv, sigma_t=10.0))
     L = _lib.lib()
+    eng.inputs_resident = bool(int(os.environ.get("AB_RESIDENT", "0")))   # CRFP_DSV_INPUTS_RESIDENT (stream mode)
     if a.mode == "stream":      # one frame per call (BASELINE config 3's call pattern), a.t calls per "step"
         mk8 = mks.contiguous()
 
