@@ -132,6 +132,7 @@ def main():
                     "default 1, config 4: 2 -- independent clips fill each other's kernel tails, bit-identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-resident", action="store_true", help="stream mode: do not set CRFP_DSV_INPUTS_RESIDENT")
     ap.add_argument("--no-extras", action="store_true", help="skip strict_f32 / multi-stream / per-op / other-config legs")
     ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short legs of BASELINE configs 3 / 4 / 5")
     ap.add_argument("--cpu-sample-frames", type=int, default=None)
@@ -183,6 +184,9 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_flight)] if n_flight > 1 else None
     if mode == "stream":
         mk8 = data[0][2].contiguous()
+        # the frames already sit in HBM when a step starts (the bench contract), nothing on the stream produces them: CRFP_DSV_INPUTS_RESIDENT
+        # lets the library run the state-independent part of frame i beside frame i - 1 (same bits; --no-resident: the plain call pattern)
+        model.inputs_resident = eng.inputs_resident = not args.no_resident
 
     def step(e=None):
         """one step of this rank; returns the last output tensor(s)"""
@@ -243,7 +247,8 @@ def main():
         "config": {"workload": cfg["name"] + (" [with command-line overrides]" if custom else ""), "baseline_config_index": cfg["index"],
                    "conv_arithmetic": arithmetic, "mode": mode, "frames_per_clip": t, "lr": [h, w], "sr": [8 * h, 8 * w],
                    "fv_size": fv, "sigma_t": cfg["sigma"], "clips_per_gpu_per_step": clips, "clips_in_flight_per_gpu": n_flight,
-                   "storage": storage, "parallelism": f"clip-sharded x{world}"},
+                   "storage": storage, "parallelism": f"clip-sharded x{world}",
+                   **({"inputs_resident": bool(eng.inputs_resident)} if mode == "stream" else {})},
         "per_gpu_frames_per_sec": agg["per_gpu_frames_per_sec"],
         "frames_per_step_per_gpu": frames_per_step,
         "collectives": {"backend": dist.get_backend() if dist is not None else None, "initialised": dist is not None,
@@ -378,6 +383,21 @@ def main():
                                      "side_stream_hidden_ms": single_ms - agg["ms_per_step"],
                                      "note": "FNet + fovea blend + encoder_hr + upsample conv + flow up-sampling run on the library's side "
                                              "stream beside the recurrent chain; bit-identical results"}
+    if rank == 0 and world == 1 and mode == "stream" and eng.inputs_resident:
+        # the same calls without CRFP_DSV_INPUTS_RESIDENT (every call waits for the previous frame before its flow network starts)
+        model.inputs_resident = eng.inputs_resident = False
+        with torch.no_grad():
+            step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            plain_ms = 1e3 * (time.perf_counter() - t0) / 2
+        model.inputs_resident = eng.inputs_resident = True
+        eng.clear_states()
+        result["stream_without_resident_flag"] = {"ms_per_step": plain_ms, "frames_per_sec": 1e3 * frames_per_step / plain_ms,
+                                                  "note": "same bits; the flag is a promise about the INPUT tensors (complete before the call), see include/crfp_hip.h"}
     if extras and mode == "clip" and storage == "f32":
         # the same clip in strict fp32 (plain fp32 MFMA for every conv and the DCN GEMM): what the split-fp16 scheme buys
         model.precision = "f32"

@@ -312,6 +312,7 @@ class CRFP_DSV(nn.Module):
         self.precision = "split"      # "split": split-fp16 MFMA scheme (fp32-grade) | "f32": strict fp32 MFMA
         self.on_overflow = "poison"   # "poison" | "fallback" | "raise" when an activation leaves the fp16 operand range
         self.storage = "f32"          # "f32" | "bf16": activation / state storage in HBM (BASELINE configs 3-5 are bf16)
+        self.inputs_resident = False  # streaming only: the frame tensors are complete before each call (CRFP_DSV_INPUTS_RESIDENT, engine.py)
 
     # ---- engine management: repack whenever a parameter was modified or moved
     def _signature(self):
@@ -345,6 +346,7 @@ class CRFP_DSV(nn.Module):
             raise RuntimeError("crfp_amd: parameters changed without their version counters moving (a write through `.data`?): "
                                "the packed weights are stale -- call model.invalidate_packed() after such writes")
         self._engine.precision, self._engine.on_overflow = self.precision, self.on_overflow
+        self._engine.inputs_resident = bool(self.inputs_resident)
         return self._engine
 
     def compute_flow(self, lrs):
