@@ -291,6 +291,7 @@ def test_runtime_variant_vs_reference_golden(orc, capsys):
     sd = synth.make_state_dict_like({k: tuple(v.shape) for k, v in m.state_dict().items()}, int(g["weights_seed"]))
     m.load_state_dict({k: T(v.copy()) for k, v in sd.items()}, strict=True)
     m = m.to(dev()).eval()
+    m.print_timings = True         # per-operator composition with the reference's stage prints; the default is the one-call engine (round 3)
     out = m(T(g["lrs"]).to(dev()), T(g["fvs"]).to(dev()), warp_size=tuple(int(v) for v in g["warp"]))
     assert maxdiff(out, g["out"]) < 2e-4
     printed = capsys.readouterr().out.split()
