@@ -205,7 +205,8 @@ int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const
 
 /* Streaming: one frame per call, recurrent state kept inside `workspace` (same buffer every call).
  * `first` != 0 resets the state (clear_states of the reference's streaming model). lr_prev may be
- * NULL when first != 0.  fg: optional regional mask [8h,8w] u8 (the reference's `fgs`,
+ * NULL when first != 0, and is ignored under CRFP_DSV_INPUTS_RESIDENT (the library then keeps the previous frame in the
+ * workspace and overlaps the state-independent part of this frame with the previous call's kernels).  fg: optional regional mask [8h,8w] u8 (the reference's `fgs`,
  * model/CRFP_test.py:2296-2298,2361,2375,2389), NULL = all ones. */
 int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
                           const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,

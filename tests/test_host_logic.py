@@ -235,3 +235,37 @@ def test_product_library_carries_no_lab_kernels():
         assert name not in blob, name
     assert b"conv3x3_split_kernel" in blob
     assert os.path.getsize(so) < 4 << 20
+
+
+def test_regional_engine_tables_and_argument_errors(lib):
+    """crfp_rt_* (the one-call schedule of model/CRFP_runtime.py::MRCF_simple_v18): the parameter table is the mirror's (= the
+    reference class's, tests/golden/runtime_small.npz `keys`) state_dict in order; geometry the schedule cannot run is refused by
+    the size query and by the forward call before anything touches the GPU."""
+    from crfp_amd import _lib
+    from crfp_amd.engine import RuntimeEngine
+    from crfp_amd.model import MRCF_runtime
+    from conftest import GOLDEN
+    m = MRCF_runtime.MRCF_simple_v18(mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True, split_ratio=3, device=torch.device("cpu"))
+    names = RuntimeEngine.param_names()
+    assert len(names) == _lib.RT_NUM_PARAMS == 158 and names == list(m.state_dict().keys())
+    assert names == [str(k) for k in np.load(os.path.join(GOLDEN, "runtime_small.npz"))["keys"]]
+    for i, (k, v) in enumerate(m.state_dict().items()):
+        assert lib.crfp_rt_param_numel(i, 0) == v.numel(), k
+    assert lib.crfp_rt_param_numel(names.index("conv_last.weight"), 1) == 1 * 4 * 9
+    assert lib.crfp_rt_param_name(-1) is None and lib.crfp_rt_param_name(158) is None
+    assert 9e6 < lib.crfp_rt_packed_weight_bytes(0) < 60e6
+    rig = lib.crfp_rt_workspace_bytes(5, 135, 240, 96, 96, 720, 720)          # test_runtime.py's geometry
+    assert 3e8 < rig < 3e9
+    for bad in ((5, 135, 240, 96, 96, 724, 720),       # window not a multiple of 8
+                (5, 135, 240, 96, 96, 720, 1928),      # wider than the 1920-pixel frame
+                (5, 135, 240, 96, 96, 56, 720),        # FNet needs an 8 x 8 LR window
+                (5, 135, 240, 2000, 96, 720, 720),     # fovea crop taller than the frame
+                (0, 135, 240, 96, 96, 720, 720), (5, 4, 240, 96, 96, 720, 720)):
+        assert lib.crfp_rt_workspace_bytes(*bad) == 0, bad
+    assert b"warp_size" in lib.crfp_last_error_string() or b"bad clip" in lib.crfp_last_error_string()
+    p16 = ctypes.c_void_p(16)
+    assert lib.crfp_rt_forward_clip(p16, 0, p16, p16, p16, 5, 135, 240, 96, 96, 724, 720, p16, 1 << 40, None) == -1
+    assert lib.crfp_rt_forward_clip(p16, 0, None, p16, p16, 5, 135, 240, 96, 96, 720, 720, p16, 1 << 40, None) == -1
+    assert lib.crfp_rt_forward_clip(p16, 0, p16, p16, p16, 5, 135, 240, 96, 96, 720, 720, p16, 1024, None) == -2     # workspace too small
+    assert lib.crfp_rt_forward_clip(p16, 2, p16, p16, p16, 5, 135, 240, 96, 96, 720, 720, p16, 1 << 40, None) == -3   # CRFP_DSV_STRICT_F32
+    assert lib.crfp_rt_pack_weights(None, 0, p16, 1 << 30, None) == -1
