@@ -978,7 +978,11 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     // per-sequence host note, kept next to the side stream (also when this call runs on one stream)
     SideStream* tab = side_slot();
     StreamCtx* ctx = nullptr;
-    if (tab && (resident || tab->ctx.count(workspace))) ctx = &tab->ctx[workspace];
+    if (tab && (resident || tab->ctx.count(workspace))) {
+        if (tab->ctx.size() > 1024)   // workspaces come and go: drop the notes no resident sequence depends on
+            for (auto it = tab->ctx.begin(); it != tab->ctx.end();) it = (!it->second.kept && it->first != workspace) ? tab->ctx.erase(it) : std::next(it);
+        ctx = &tab->ctx[workspace];
+    }
     if (resident) {
         // CRFP_DSV_INPUTS_RESIDENT: lr / fv / mk already hold their final values, and the previous frame is the copy the previous call
         // left in the workspace (the reference keeps `pre_lrs = lrs.clone()` on the model, model/CRFP_test.py:2234-2238).  Buffer sets
