@@ -190,7 +190,8 @@ size_t crfp_dsv_workspace_bytes(int t, int h, int w);
                                * come from the same host thread (the library keeps a host-side call counter per workspace next to its side
                                * stream).  In return the state-independent part of frame i (FNet, encoder_lr, fovea blend, encoder_hr, the
                                * upsample conv) is enqueued on the side stream WITHOUT waiting for `stream` and runs beside frame i - 1's
-                               * recurrent chain (buffer sets alternate with the call parity).  Same bits as without the flag. */
+                               * recurrent chain (buffer sets alternate with the call parity).  Same bits as without the flag.  Not for
+                               * calls under HIP graph capture: the early side-stream work is, by design, not ordered behind `stream`. */
 
 /* Numerics status: a 32-bit word inside the workspace at this byte offset.  Bit 0 is raised (sticky until the next clip
  * / the next `first` streamed frame) when a kernel of the split-fp16 scheme stores a value an fp16 operand cannot hold
