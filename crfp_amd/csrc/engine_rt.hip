@@ -213,7 +213,7 @@ struct Layout {
     // [2]: written by the state-independent pre-work of frame i into set i & 1 while frame i - 1 still reads the other set; [3]: one per
     // level (the three levels of a frame run on three streams)
     size_t prop0[2], prop_a, prop_b, y0f, y1f, tmp8f, flow2[2], flow8[2], state_w, prev2w, carryw, win[2], fa[3], fb[3], offfeat[3], aligned[3], y0[3], y1[3];
-    size_t up_full[2], upw[2], poff, g0, g1, g2, al3, tmpw, featf[2], z1, feat2, fcrop, tcrop;
+    size_t up_full[2], upw[2], poff, g0, g1, g2, al3, featf[2], z1, feat2, tcrop;
 
     // Q4 tensor of nq quads (pad = 1: P4 planes with a zeroed guard in front, see engine.hip); kind 1 = [H][W][2] floats
     size_t take(int N, int nq, int H, int W, int kind = 0, int pad = 0) {
@@ -265,9 +265,8 @@ struct Layout {
         }
         poff = take(1, 1, wh8, ww8);
         g0 = take(1, 1, wh8, ww8); g1 = take(1, 1, wh8, ww8); g2 = take(1, 1, wh8, ww8); al3 = take(1, 1, wh8, ww8);
-        tmpw = take(1, 1, wh8, ww8);
         z1 = take(1, 1, H8, W8); feat2 = take(1, 1, H8, W8);
-        fcrop = take(1, 1, fh, fw); tcrop = take(1, 1, fh, fw);
+        tcrop = take(1, 1, fh, fw);
     }
     size_t bytes() const { return cur; }
 };
@@ -295,8 +294,9 @@ __global__ void rt_crop_nchw3_kernel(const float* __restrict__ x, int H, int W, 
     out[((long long)n * cH + py) * cW + px] = make_float4(p[0], p[(long long)H * W], p[2LL * H * W], 0.0f);
 }
 // feat = LeakyReLU(feat) outside the top-left fh x fw crop, = tcrop (already activated) inside it (:8645-8648)
+// ... and the top-left sh x sw window of the result is the state the next frame carries (:8650): written to the P4 tensor `state` in the same pass
 __global__ void rt_lrelu_paste_kernel(float4* __restrict__ feat, int H, int W, const float4* __restrict__ tcrop, int fh, int fw,
-                                      unsigned* __restrict__ ovf) {
+                                      float4* __restrict__ state, int sh, int sw, unsigned* __restrict__ ovf) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     float4 v;
@@ -307,6 +307,7 @@ __global__ void rt_lrelu_paste_kernel(float4* __restrict__ feat, int H, int W, c
         v.z = v.z > 0.0f ? v.z : 0.1f * v.z; v.w = v.w > 0.0f ? v.w : 0.1f * v.w;
     }
     feat[(long long)y * W + x] = v;
+    if (x < sw && y < sh) state[(long long)y * (sw + 1) + x] = v;
     const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));   // the state feeds split-fp16 convs
     if (ovf && !(m < 65504.0f)) atomicOr(ovf, 1u);
 }
@@ -519,6 +520,8 @@ struct Runner {
             mfma(RI_DOWN, 1, wh2, ww2, {{F(L.state_w), 0, 0}}, {{F(L.prev2w), 0, 0, 8}});               // prev2_w = downsample(state_w) (:8536)
             mfma(RI_DOWN, 1, wh2, ww2, {{F(L.state), 0, 1}}, {{F(L.prev2), 0, 0, 8, 1}});               // prev2 = downsample(state) (:8537)
             RUN(launch_flow_warp_q4(F(L.carry), 0, F(L.flow2[par]), 0, F(L.carryw), 0, 1, 6, wh2, ww2, 0, 1, s));   // :8538-8547
+            // (running downsample(state) and the carry warp on two other lanes beside these: 0.50 vs 0.49 ms per frame -- every cross-stream
+            // dependency costs a few microseconds of its own, so only long independent chains are worth a lane)
             hipEvent_t e_base = rec();
             // The three levels read the same window features and only hand the offset feature down (:8549-8599): their dcn_block convs
             // run side by side, conv_fuse of level l waits for level l - 1's feature, and everything behind a level's feature is its own.
@@ -557,8 +560,8 @@ struct Runner {
             RUN(launch_dcn3_fused(F(L.state), 0, F(L.g2), 0, F(L.flow8[par]), packed + om3.off_w, packed + om3.off_b, packed + d3.off_w, packed + d3.off_b,
                                   F(L.al3), 0, 1, wh8, ww8, s));
             // forward_resblocks_3([upw | aligned], up): conv1's window result pasted over conv2 of the full frame (:8607-8609)
-            narrow(RI_R3_C1, wh8, ww8, {F(L.upw[par]), F(L.al3)}, F(L.tmpw));
-            RUN(rt_copy_q4(F(L.tmpw), wh8, ww8, 0, F(L.featf[par]), H8, W8, 0, 1, wh8, ww8, s));
+            // (the window result goes straight into the full-frame tensor: destination pitch W8)
+            narrow(RI_R3_C1, wh8, ww8, {F(L.upw[par]), F(L.al3)}, F(L.featf[par]), nullptr, nullptr, 0, W8 - ww8);
             narrow(RI_R3_B1, H8, W8, {F(L.featf[par])}, F(L.z1));
             narrow(RI_R3_B2, H8, W8, {F(L.z1)}, feat, F(L.featf[par]));
         } else {
@@ -579,17 +582,17 @@ struct Runner {
             narrow(RI_R3F_B2, H8, W8, {F(L.z1)}, feat, F(L.featf[0]));
         }
         // conv_tttf on the fovea crop, pasted back, LeakyReLU everywhere (:8645-8648)
-        RUN(rt_copy_q4(feat, H8, W8, 0, F(L.fcrop), L.fh, L.fw, 0, 1, L.fh, L.fw, s));
-        narrow(RI_TTTF, L.fh, L.fw, {F(L.fcrop), F(L.x_hr) + (long long)i * L.fh * L.fw * 4}, F(L.tcrop));
+        // (the crop is read in place: source pitch W8, zero padding at the crop's own border comes from the kernel's validity mask)
+        narrow(RI_TTTF, L.fh, L.fw, {feat, F(L.x_hr) + (long long)i * L.fh * L.fw * 4}, F(L.tcrop), nullptr, nullptr, W8 - L.fw);
         if (!rc) {
             ProfScope prof("rt_lrelu_paste", s, (double)H8 * W8 * 32.0, 0);
             rt_lrelu_paste_kernel<<<dim3((W8 + 63) / 64, (H8 + 3) / 4, 1), 256, 0, s>>>(reinterpret_cast<float4*>(feat), H8, W8,
-                                                                                       reinterpret_cast<const float4*>(F(L.tcrop)), L.fh, L.fw, ovf());
+                                                                                       reinterpret_cast<const float4*>(F(L.tcrop)), L.fh, L.fw,
+                                                                                       reinterpret_cast<float4*>(F(L.state)), wh8, ww8, ovf());
             if (hipGetLastError() != hipSuccess) { set_error("rt: lrelu_paste launch failed"); rc = 1; }
         }
         narrow(RI_LAST, H8, W8, {feat}, out, nullptr, nullptr, 0, 0, lr_nchw);                           // conv_last + x8 bilinear LR (:8652-8654)
         for (int l = 0; l < 3; ++l) wait(e_l[l]);                                                        // the carried features of this frame are complete
-        RUN(rt_copy_q4(feat, H8, W8, 0, F(L.state), wh8, ww8, 1, 1, wh8, ww8, s));                        // the carried state = the window (:8650)
         frame_done[par] = rec();
     }
 #undef RUN
