@@ -412,6 +412,8 @@ def test_stream_with_resident_inputs_is_bit_identical(storage):
     t, h, w = 9, 24, 40
     lrs, fvs, mks = (T(a).to(dev()) for a in synth.make_clip(77, 1, t, h, w, fv_size=64, sigma_t=10.0))
     mks = mks.bool() if mks.dtype != torch.bool else mks
+    fg = torch.zeros(1, 8 * h, 8 * w, dtype=torch.bool, device=dev())
+    fg[:, 40:150, 60:260] = True
 
     def run(resident, single=False):
         eng = _model(sd, storage=storage).engine()
@@ -420,7 +422,7 @@ def test_stream_with_resident_inputs_is_bit_identical(storage):
         for i in range(t):
             if i == 5:
                 eng.clear_states()
-            outs.append(eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i]).clone())
+            outs.append(eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i], fg if i in (3, 7) else None).clone())   # + the regional mask on two frames
         torch.cuda.synchronize()
         return torch.stack(outs), eng
 
@@ -430,7 +432,7 @@ def test_stream_with_resident_inputs_is_bit_identical(storage):
     assert torch.equal(base, run(True, single=True)[0])
     # back-to-back sequences without host synchronisation, outputs checked at the end: the early side work of call i really overlaps call i - 1
     eng.clear_states()
-    outs = [eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i]) for i in range(5)]
+    outs = [eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i], fg if i == 3 else None) for i in range(5)]
     assert torch.equal(torch.stack(outs), base[:5])
     # a float mask would need a conversion kernel on the caller's stream: refused instead of raced
     with pytest.raises(ValueError, match="inputs_resident"):
