@@ -1086,6 +1086,174 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #undef S8_STAMP
 }
 
+#ifdef CRFP_LAB
+// ---------------------------------------------------------------- f16x3s, persistent over 4-row tiles (lab: lost its A/B)
+// Measured, same box, bit-identical output: 32 -> 32 convs 25.0 -> 27.3 us, 64 -> 32 37.2 -> 41.2, block0 43.7 -> 48.8, the pixel-shuffle
+// heads 41.2 -> 40.1; clip 10.74 -> 11.06 ms.  What the cross-tile prefetch hides is less than what half-height tiles cost: 5 instead of
+// 3.5 ds_read_b128 per MFMA triple (one 32-pixel tile per wave re-reads the A fragments twice as often), the 27.6 KB weight stage per
+// 4 rows instead of per 8, a 6 / 4 instead of 10 / 8 halo.  CRFP_S8P=1 selects it in the lab library.
+// Same arithmetic, K order and accumulation order as conv3x3_split8_kernel (so the same bits), other work split: a tile is 4 rows x 64
+// pixels (wave w: row w / 2, pixel half w & 1 -- ONE 32-pixel MFMA tile per wave, 16 accumulator registers), a 360 x 640 map is 900 tiles,
+// and the 512 resident workgroups walk them with the chunk prefetch running ACROSS the tile boundary: the first chunk of tile i + 1 is in
+// flight during the last MFMAs and the stores of tile i, so a workgroup's second tile pays neither the load latency of a prologue nor
+// the store phase of the first one (profiles/r03_conv_split8_timeline.txt: 28 % + 20 % of a one-tile workgroup's lifetime).  Barriers
+// order LDS only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would wait for the previous tile's stores to be acknowledged.
+constexpr int S8P_TH = 4, S8P_LH = S8P_TH + 2, S8P_NEL = S8P_LH * LW, S8P_NT = 512;
+constexpr int S8P_NIN = (S8P_NEL + S8P_NT - 1) / S8P_NT, S8P_NWS = (S8_WPC + S8P_NT - 1) / S8P_NT;
+__device__ __forceinline__ void s8p_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(S8P_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_split8p_kernel(const ConvArgs a, int items) {
+    __shared__ bf16x8 tile[2][2][S8P_NEL];       // [split part][quad pair][halo pixel]   25.3 KB
+    __shared__ bf16x8 wlds[S8_WPC];              // [(tap, image A/B/C)][lane]            27.6 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int row = wave >> 1, half = wave & 1;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int ngrp = a.ctiles;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int G = gridDim.x;                     // a multiple of 8: every item of a workgroup lies in its XCD's band
+    int item = blockIdx.x;
+    if (item >= items) return;
+    const int nchunks = a.kq >> 2;
+    const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit_sa);
+    const EpiCtx ec = epi_ctx(a, n);
+
+    // load side: the (tile, chunk) whose global loads are in flight
+    int ltx0, lty0, lT0;
+    int cgy[S8P_NIN], cgx[S8P_NIN];
+    bool sval[S8P_NIN];
+    f32x4 rq0[S8P_NIN], rq1[S8P_NIN], rq2[S8P_NIN], rq3[S8P_NIN];
+    bf16x8 rws[S8P_NWS];
+    int qm0 = 0, qm1 = 0, qm2 = 0, qm3 = 0;
+#define S8P_SET_TILE(IT)                                                                                  \
+    {                                                                                                     \
+        const int bw_ = xcd_band_tile((IT), items);                                                       \
+        const int bt_ = bw_ / ngrp;                                                                       \
+        ltx0 = (bt_ % tiles_x) * TW; lty0 = (bt_ / tiles_x) * S8P_TH; lT0 = bw_ - bt_ * ngrp;             \
+        _Pragma("unroll") for (int t = 0; t < S8P_NIN; ++t) {                                             \
+            const int idx = min(tid + S8P_NT * t, S8P_NEL - 1);                                           \
+            const int r = idx / LW, c = idx - r * LW;                                                     \
+            const int gy = lty0 + r - 1, gx = ltx0 + c - 1;                                               \
+            sval[t] = tid + S8P_NT * t < S8P_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;               \
+            cgy[t] = min(max(gy, 0), H - 1);                                                              \
+            cgx[t] = min(max(gx, 0), W - 1);                                                              \
+        }                                                                                                 \
+    }
+#define S8P_QDESC(QB_, QRS, QCS, QM, QI, CH)                                                              \
+    const float* QB_; int QRS, QCS;                                                                       \
+    {                                                                                                     \
+        const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
+        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+    }
+#define S8P_ISSUE(CH)                                                                                     \
+    {                                                                                                     \
+        S8P_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) S8P_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                     \
+        S8P_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) S8P_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                     \
+        _Pragma("unroll") for (int t = 0; t < S8P_NIN; ++t) {                                             \
+            rq0[t] = *reinterpret_cast<const f32x4*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
+            rq1[t] = *reinterpret_cast<const f32x4*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
+            rq2[t] = *reinterpret_cast<const f32x4*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
+            rq3[t] = *reinterpret_cast<const f32x4*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
+        }                                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < S8P_NWS; ++k) {                                             \
+            const int idx = min(tid + S8P_NT * k, S8_WPC - 1);                                            \
+            rws[k] = wp[((long long)lT0 * nchunks + (CH)) * S8_WPC + idx];                                \
+        }                                                                                                 \
+    }
+
+    S8P_SET_TILE(item)
+    S8P_ISSUE(0)
+    for (;;) {
+        // compute side: this tile
+        const int tx0 = ltx0, ty0 = lty0, T0 = lT0;
+        f32x16 acc[1][1];
+        {   // the accumulator starts at 2^11 * bias
+            const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bq = bp[T0 * 8 + 2 * g + h];
+                acc[0][0][4 * g + 0] = bq.x * F16_RES_SCALE; acc[0][0][4 * g + 1] = bq.y * F16_RES_SCALE;
+                acc[0][0][4 * g + 2] = bq.z * F16_RES_SCALE; acc[0][0][4 * g + 3] = bq.w * F16_RES_SCALE;
+            }
+        }
+        const int next = item + G;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;
+            s8p_lds_barrier();                   // every wave is done reading the previous stage
+            if (m0 & 16) {   // SRC_S3 chunk (wave-uniform): already split by its producer -- copy, zero outside the image
+#pragma unroll
+                for (int t = 0; t < S8P_NIN; ++t) {
+                    const int idx = tid + S8P_NT * t;
+                    if (idx < S8P_NEL) {
+                        const f32x4 z = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        tile[0][0][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq0[t] : z);
+                        tile[0][1][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq1[t] : z);
+                        tile[1][0][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq2[t] : z);
+                        tile[1][1][idx] = __builtin_bit_cast(bf16x8, sval[t] ? rq3[t] : z);
+                    }
+                }
+            } else if ((m0 & m1 & m2 & m3) == 15) {
+#pragma unroll
+                for (int t = 0; t < S8P_NIN; ++t) {
+                    const int idx = tid + S8P_NT * t;
+                    if (idx < S8P_NEL) {
+                        const float sc = sval[t] ? F16_RES_SCALE : 0.0f;
+                        const unsigned km = sval[t] ? 0xffffffffu : 0u;
+                        bf16x8 pa, pb;
+                        split_f16x8_fast(rq0[t], rq1[t], sc, km, pa, pb);
+                        tile[0][0][idx] = pa; tile[1][0][idx] = pb;
+                        split_f16x8_fast(rq2[t], rq3[t], sc, km, pa, pb);
+                        tile[0][1][idx] = pa; tile[1][1][idx] = pb;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < S8P_NIN; ++t) {
+                    const int idx = tid + S8P_NT * t;
+                    if (idx < S8P_NEL) {
+                        bf16x8 pp[2];
+                        split_parts<2>(mask_quad(rq0[t], sval[t] ? m0 : 0), mask_quad(rq1[t], sval[t] ? m1 : 0), pp);
+                        tile[0][0][idx] = pp[0]; tile[1][0][idx] = pp[1];
+                        split_parts<2>(mask_quad(rq2[t], sval[t] ? m2 : 0), mask_quad(rq3[t], sval[t] ? m3 : 0), pp);
+                        tile[0][1][idx] = pp[0]; tile[1][1][idx] = pp[1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < S8P_NWS; ++k) {
+                const int idx = tid + S8P_NT * k;
+                if (idx < S8_WPC) wlds[idx] = rws[k];
+            }
+            s8p_lds_barrier();
+            if (ch + 1 < nchunks) S8P_ISSUE(ch + 1)
+            else if (next < items) { S8P_SET_TILE(next) S8P_ISSUE(0) }   // the next tile's first chunk: in flight during these MFMAs and the stores below
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const f16x8 wA = __builtin_bit_cast(f16x8, wlds[(tap * 3 + 0) * 64 + lane]);
+                const f16x8 wB = __builtin_bit_cast(f16x8, wlds[(tap * 3 + 1) * 64 + lane]);
+                const f16x8 wC = __builtin_bit_cast(f16x8, wlds[(tap * 3 + 2) * 64 + lane]);
+                const int pix = (row + ky) * LW + half * 32 + j + kx;
+                const f16x8 b0 = __builtin_bit_cast(f16x8, tile[0][h][pix]);
+                const f16x8 b1 = __builtin_bit_cast(f16x8, tile[1][h][pix]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wB, b0, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wC, b1, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wA, b0, acc[0][0], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] *= (1.0f / F16_RES_SCALE);
+        conv_epilogue<1, 1, 1, 2>(ec, acc, T0, tx0 + half * 32, ty0, row, j, h);
+        if (next >= items) break;
+        item = next;
+    }
+#undef S8P_ISSUE
+#undef S8P_QDESC
+#undef S8P_SET_TILE
+}
+#endif  // CRFP_LAB
+
 #endif  // !CRFP_ACT_BF16
 
 #ifdef CRFP_ACT_BF16
@@ -2492,6 +2660,12 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
             constexpr int s8nw = S8_TH;
 #endif
             const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + s8nw - 1) / s8nw);
+#ifdef CRFP_LAB
+            static const int s8p = getenv("CRFP_S8P") ? atoi(getenv("CRFP_S8P")) : 0;   // the persistent 4-row form (lost: see the kernel)
+            const int items4 = tiles * a.ctiles;
+            if (s8p && items4 > 512) conv3x3_split8p_kernel<<<dim3(512, 1, a.N), S8P_NT, 0, s>>>(am, items4);
+            else
+#endif
             conv3x3_split8_kernel<s8nw><<<dim3(tiles8 * a.ctiles, 1, a.N), 64 * s8nw, 0, s>>>(am);
         } else
             conv3x3_split_kernel<1, 1, 2><<<dim3(tiles * a.ctiles, 1, a.N), 256, 0, s>>>(am);
