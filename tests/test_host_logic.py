@@ -269,3 +269,29 @@ def test_regional_engine_tables_and_argument_errors(lib):
     assert lib.crfp_rt_forward_clip(p16, 0, p16, p16, p16, 5, 135, 240, 96, 96, 720, 720, p16, 1024, None) == -2     # workspace too small
     assert lib.crfp_rt_forward_clip(p16, 2, p16, p16, p16, 5, 135, 240, 96, 96, 720, 720, p16, 1 << 40, None) == -3   # CRFP_DSV_STRICT_F32
     assert lib.crfp_rt_pack_weights(None, 0, p16, 1 << 30, None) == -1
+
+
+def _build_c_host(tmp_path):
+    exe = str(tmp_path / "c_host_smoke")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+           os.path.join(ROOT, "examples", "c_host_smoke.c"), "-L", os.path.join(ROOT, "crfp_amd"), "-lcrfp_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "crfp_amd"), "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_c99_and_a_plain_c_host_links(tmp_path):
+    """The drop-in boundary is a C ABI: include/crfp_hip.h compiles as C99 (-Wpedantic clean) and examples/c_host_smoke.c -- a host
+    without Python or torch -- builds with gcc against libcrfp_hip.so (it runs in the -m gpu suite)."""
+    r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", "-Wall", "-Wpedantic", "-Werror", os.path.join(ROOT, "include", "crfp_hip.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(_build_c_host(tmp_path))
+
+
+@pytest.mark.gpu
+def test_plain_c_host_runs_on_the_gpu(tmp_path):
+    """examples/c_host_smoke.c: hipMalloc'ed buffers, crfp_flow_warp_f32 / crfp_upsample_bilinear_f32 / an argument error, from C."""
+    r = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c_host_smoke: OK" in r.stdout, r.stdout + r.stderr
