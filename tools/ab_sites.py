@@ -5,7 +5,7 @@
 
 Every variant runs in its own child process (the library reads its switches once), alternating over --rounds so that box
 drift hits all of them alike.  `lib=<path>` inside a variant selects another build of the C-ABI (CRFP_HIP_LIB); `lab`
-is short for the lab library.  Prints per variant: wall ms per clip (two-stream schedule), kernel-sum ms (single-stream
+is short for the lab library; `AB_RESIDENT=1` sets CRFP_DSV_INPUTS_RESIDENT in --mode stream.  Prints per variant: wall ms per clip (two-stream schedule), kernel-sum ms (single-stream
 instrumented pass) and the avg us of every launch site whose name contains one of --sites, plus a digest of the output."""
 import argparse
 import hashlib
