@@ -330,8 +330,10 @@ int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s);
 int launch_narrow_pair(const NarrowArgs& a, const NarrowArgs& b, const char* name, hipStream_t s);
 // gather.hip
 // src_pad = 1: x is P4 (padded planes, zero pads): validity logic replaced by clamping + hardware range check
+// N > 1: batch strides in elements of each tensor's own type (activations: act_t, flow: float)
+struct WarpDualStrides { long long xa = 0, xb = 0, flow = 0, outa = 0, outb = 0; };
 int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* flow, float* outa, float* outb, int H, int W,
-                                 hipStream_t s);
+                                 hipStream_t s, int N = 1, const WarpDualStrides& bs = WarpDualStrides());
 int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long long fb, float* out, long long ob,
                         int N, int nq, int H, int W, int border, int src_pad, hipStream_t s);
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
@@ -362,7 +364,8 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s);
 int launch_dcn3(const float* x, long long xb, const float* offmask3, long long omb, const float* w_oihw,
                 const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
 int launch_dcn3_fused(const float* x, long long xb, const float* g2, long long gb, const float* flow, const float* wom, const float* bom,
-                      const float* w_oihw, const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s);
+                      const float* w_oihw, const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s,
+                      long long flow_b = 0);
 int launch_dcn_generic(const float* x, const float* offset, const float* mask, const float* w, const float* b,
                        float* out, int N, int cin, int cout, int H, int W, int dg, hipStream_t s);
 // resample.hip
@@ -377,7 +380,9 @@ int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long
 int launch_avgpool2_nchw(const float* x, float* out, int N, int C, int H, int W, hipStream_t s);
 int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W,
                        hipStream_t s);
-int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s);
+// N > 1: lr_b / fv_b / mk_b = elements between the batch items of the three API tensors (frames of different clips), out_b likewise
+int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s, int N = 1,
+                   long long lr_b = 0, long long fv_b = 0, long long mk_b = 0, long long out_b = 0);
 int launch_offmask_nchw_to_q4(const float* offset, const float* mask, float* out, int N, int noff, int nmask, int H,
                               int W, hipStream_t s);
 int launch_fg_prep(const uint8_t* fg, float* fg2, int H8, int W8, hipStream_t s);

@@ -271,20 +271,32 @@ static const Model& model_for(int y_only, bool strict = false) {
 
 // ------------------------------------------------------------------ workspace arena
 struct Buf { std::string name; size_t off; int N, nq, H, W, kind, pad; size_t bytes, guard; bool f32; };  // kind 0 = Q4, 1 = NHW2 (always float)
+// a workspace tensor: byte offset + elements (of the tensor's own type) between two batch items
+struct Ten {
+    size_t off = 0;
+    long long bs = 0;
+    operator size_t() const { return off; }
+};
 struct Arena {
     size_t cur = 0;
     std::vector<Buf> bufs;
     // pad = 1: "P4" planes of (H+1) x (W+1) with zero pad row / column (sources of the gather kernels)
     // f32 = true: a Q4 tensor that stays float in the bf16 build as well (flow, DCN offsets / masks: coordinates)
-    size_t take(const char* name, int N, int nq, int H, int W, int kind = 0, int pad = 0, bool f32 = false) {
-        const size_t elems = kind == 0 ? (size_t)N * nq * (H + pad) * (W + pad) * 4 : (size_t)N * H * W * 2;
+    // The N items are contiguous, so item n > 0 of a P4 tensor finds its guard (one pad row + one element of zeros in front of
+    // plane 0) in the tail of item n - 1: that item's last pad row, preceded by the pad column of its last data row.
+    Ten take(const char* name, int N, int nq, int H, int W, int kind = 0, int pad = 0, bool f32 = false) {
+        const size_t per = kind == 0 ? (size_t)nq * (H + pad) * (W + pad) * 4 : (size_t)H * W * 2;
+        const size_t elems = (size_t)N * per;
         const size_t esz = (kind == 0 && !f32) ? sizeof(act_t) : sizeof(float);
         // P4 tensors carry a zeroed guard (>= one pad row + one element) in front of plane 0
         const size_t guard = pad ? align_up((size_t)(W + 2) * 16, 256) : 0;
         const size_t off = cur + guard;
         cur += guard + align_up(elems * esz, 256);
         bufs.push_back({name, off, N, nq, H, W, kind, pad, elems * esz, guard, kind != 0 || f32});
-        return off;
+        Ten t;
+        t.off = off;
+        t.bs = (long long)per;
+        return t;
     }
     const Buf* find(size_t off) const {
         for (auto& b : bufs) if (b.off == off) return &b;
@@ -298,35 +310,47 @@ struct Q4 {
     long long bs() const { return (long long)nq * H * W * 4; }
 };
 
+// Frames per launch of the clip-level stages (FNet, encoder_lr).  A batch of B clips of t frames whose B * t frames fit kFlatFrames
+// runs them ONCE over the flattened [B * t] frame sequence -- the API tensors' own memory order; the B - 1 "pairs" that straddle two
+// clips are computed and never read.  Longer jobs walk every clip in chunks of kChunkFrames frames, so the workspace does not
+// grow with t (BASELINE config 2-5 shapes are all flat; a 100-frame clip takes 13 chunks of 8).
+constexpr int kFlatFrames = 32, kChunkFrames = 8;
+
 struct Layout {
     Arena A;
-    int t, h, w;
+    int B, t, h, w;
+    bool flat;   // clip-level stages over all B * t frames at once
+    int TC;      // frames per clip held by the clip-level stores (x_lr, flow_lr): t when flat, else kChunkFrames; slot of (clip b, frame i) = b * TC + i % TC
     // status word (fp16-operand overflow flag), then the persistent recurrent state (stable offsets for streaming)
-    size_t status, state_hr, carry;
+    Ten status, state_hr, carry;
     // clip-level
-    size_t flow_lr, e_lr0, x_lr, lr_q4, lr_keep[2] = {0, 0};
+    Ten flow_lr, e_lr0, x_lr, lr_q4, lr_keep[2];
     // FNet
-    size_t fa0, fa1, fp1, fb0, fb1, fp2, fc0, fc1, fp3, fd0, fd1, fu1, fe0, fe1, fu2, ff0, ff1, fu3, fg0, fg1;
+    Ten fa0, fa1, fp1, fb0, fb1, fp2, fc0, fc1, fp3, fd0, fd1, fu1, fe0, fe1, fu2, ff0, ff1, fu3, fg0, fg1;
     // frame-level
-    size_t xin8[2], eh[2], x_hr[2], prop0[2], prop_a, prop_b, flow2[2], flow8[2], prev2, prev2w, prevhrw, carryw, fa, fb, offfeat[3], offmask,
+    Ten xin8[2], eh[2], x_hr[2], prop0[2], prop_a, prop_b, flow2[2], flow8[2], prev2, prev2w, prevhrw, carryw, fa, fb, offfeat[3], offmask,
         aligned, y0, y1, up, poff, g0, g1, g2, om3, al3, z0, z1, feat, fg2, sc_prop, sc_cw, sc_al, sc_up, sc_al3;
     int h1, w1, h2, w2, h3, w3;
+    int fnet_cap;   // pairs one FNet pass can hold
 
-    Layout(int t_, int h_, int w_) : t(t_), h(h_), w(w_) {
-        const int nb = t > 1 ? t - 1 : 1;
+    Layout(int B_, int t_, int h_, int w_) : B(B_), t(t_), h(h_), w(w_) {
+        flat = (long long)B * t <= kFlatFrames;
+        TC = flat ? t : kChunkFrames;
+        const int nb = flat ? (B * t > 1 ? B * t - 1 : 1) : TC;
+        fnet_cap = nb;
         const int H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         h1 = h / 2; w1 = w / 2; h2 = h1 / 2; w2 = w1 / 2; h3 = h2 / 2; w3 = w2 / 2;
         status = A.take("status", 1, 0, 1, 32, 1);   // 256 bytes; word 0 = overflow flag
-        state_hr = A.take("state_hr", 1, 1, H8, W8, 0, 1);
-        carry = A.take("carry", 1, 6, H2, W2, 0, 1);
+        state_hr = A.take("state_hr", B, 1, H8, W8, 0, 1);
+        carry = A.take("carry", B, 6, H2, W2, 0, 1);
         // one-frame-per-call layout (t == 1): two flow slots and (bf16 build) two kept fp32 copies of the LR frame, indexed by call parity
         // (CRFP_DSV_INPUTS_RESIDENT: the flow network of call i runs while frame i - 1 still reads the other slot)
-        flow_lr = A.take("flow_lr", t == 1 ? 2 : nb, 1, h, w, 0, 0, true);
+        flow_lr = A.take("flow_lr", t == 1 ? 2 * B : B * TC, 1, h, w, 0, 0, true);
         if (kActBf16 && t == 1)
             for (int p = 0; p < 2; ++p) lr_keep[p] = A.take(p ? "lr_keep.1" : "lr_keep", 3, 0, h, (w + 1) / 2, 1);   // >= 3 * h * w floats
-        lr_q4 = A.take("lr_q4", 2 * t, 1, h, w);   // the LR frames as quads: [0, t) current frames, [t, 2t) previous frames when they are not the same tensor
-        e_lr0 = A.take("enc_lr0", t, 8, h, w);
-        x_lr = A.take("x_lr", t, 8, h, w);
+        lr_q4 = A.take("lr_q4", 2 * B * t, 1, h, w);   // the LR frames as quads: [0, B t) current frames, [B t, 2 B t) previous frames when they are not the same tensor
+        e_lr0 = A.take("enc_lr0", B * TC, 8, h, w);
+        x_lr = A.take("x_lr", B * TC, 8, h, w);
         fa0 = A.take("fnet.a0", nb, 8, h, w);
         fa1 = A.take("fnet.a1", nb, 8, h, w);
         fp1 = A.take("fnet.p1", nb, 8, h1, w1);
@@ -350,45 +374,49 @@ struct Layout {
         // state-independent per-frame work (fovea blend, encoder_hr, upsample conv, flow upsampling) is
         // produced one or two frames ahead on a side stream -> two buffer sets, indexed by frame parity
         for (int p = 0; p < 2; ++p) {
-            xin8[p] = A.take(p ? "xin8.1" : "xin8", 1, 2, H8, W8);
-            eh[p] = A.take(p ? "enc_hr0.1" : "enc_hr0", 1, 1, H8, W8);
-            x_hr[p] = A.take(p ? "x_hr.1" : "x_hr", 1, 1, H8, W8);
-            prop0[p] = A.take(p ? "prop0.1" : "prop0", 1, 6, H2, W2);
-            flow2[p] = A.take(p ? "flow2.1" : "flow2", 1, 0, H2, W2, 1);
-            flow8[p] = A.take(p ? "flow8.1" : "flow8", 1, 0, H8, W8, 1);
+            xin8[p] = A.take(p ? "xin8.1" : "xin8", B, 2, H8, W8);
+            eh[p] = A.take(p ? "enc_hr0.1" : "enc_hr0", B, 1, H8, W8);
+            x_hr[p] = A.take(p ? "x_hr.1" : "x_hr", B, 1, H8, W8);
+            prop0[p] = A.take(p ? "prop0.1" : "prop0", B, 6, H2, W2);
+            flow2[p] = A.take(p ? "flow2.1" : "flow2", B, 0, H2, W2, 1);
+            flow8[p] = A.take(p ? "flow8.1" : "flow8", B, 0, H8, W8, 1);
         }
-        prop_a = A.take("prop_a", 1, 6, H2, W2);
-        prop_b = A.take("prop_b", 1, 6, H2, W2);
-        prev2 = A.take("prev2", 1, 8, H2, W2, 0, 1);
-        prev2w = A.take("prev2w", 1, 8, H2, W2);
-        prevhrw = A.take("prevhrw", 1, 1, H8, W8);
-        carryw = A.take("carryw", 1, 6, H2, W2);
-        fa = A.take("dcn.fa", 1, 8, H2, W2);
-        fb = A.take("dcn.fb", 1, 8, H2, W2);
-        for (int l = 0; l < 3; ++l) offfeat[l] = A.take(l == 0 ? "offfeat0" : (l == 1 ? "offfeat1" : "offfeat2"), 1, 8, H2, W2);
-        offmask = A.take("offmask", 1, 54, H2, W2, 0, 0, true);
-        aligned = A.take("aligned", 1, 8, H2, W2);
-        y0 = A.take("res.y0", 1, 8, H2, W2);
-        y1 = A.take("res.y1", 1, 8, H2, W2);
-        up = A.take("up", 1, 1, H8, W8);
-        poff = A.take("poff", 1, 1, H8, W8);
-        g0 = A.take("dcn3.g0", 1, 1, H8, W8);
-        g1 = A.take("dcn3.g1", 1, 1, H8, W8);
-        g2 = A.take("dcn3.g2", 1, 1, H8, W8);
-        om3 = A.take("om3", 1, 1, H8, W8, 0, 0, true);
-        al3 = A.take("aligned3", 1, 1, H8, W8);
-        z0 = A.take("res3.z0", 1, 1, H8, W8);
-        z1 = A.take("res3.z1", 1, 1, H8, W8);
-        feat = A.take("feat", 1, 1, H8, W8);
-        // regional-mask (fgs) copies of the streaming variant
-        fg2 = A.take("fg2", 1, 0, H2 / 2, W2, 1);   // H2*W2 floats (kind 1 stores 2 floats per element)
-        sc_prop = A.take("fg.prop", 1, 6, H2, W2);
-        sc_cw = A.take("fg.carry", 1, 2, H2, W2);
-        sc_al = A.take("fg.aligned", 1, 8, H2, W2);
-        sc_up = A.take("fg.up", 1, 1, H8, W8);
-        sc_al3 = A.take("fg.aligned3", 1, 1, H8, W8);
+        prop_a = A.take("prop_a", B, 6, H2, W2);
+        prop_b = A.take("prop_b", B, 6, H2, W2);
+        prev2 = A.take("prev2", B, 8, H2, W2, 0, 1);
+        prev2w = A.take("prev2w", B, 8, H2, W2);
+        prevhrw = A.take("prevhrw", B, 1, H8, W8);
+        carryw = A.take("carryw", B, 6, H2, W2);
+        fa = A.take("dcn.fa", B, 8, H2, W2);
+        fb = A.take("dcn.fb", B, 8, H2, W2);
+        for (int l = 0; l < 3; ++l) offfeat[l] = A.take(l == 0 ? "offfeat0" : (l == 1 ? "offfeat1" : "offfeat2"), B, 8, H2, W2);
+        offmask = A.take("offmask", B, 54, H2, W2, 0, 0, true);
+        aligned = A.take("aligned", B, 8, H2, W2);
+        y0 = A.take("res.y0", B, 8, H2, W2);
+        y1 = A.take("res.y1", B, 8, H2, W2);
+        up = A.take("up", B, 1, H8, W8);
+        poff = A.take("poff", B, 1, H8, W8);
+        g0 = A.take("dcn3.g0", B, 1, H8, W8);
+        g1 = A.take("dcn3.g1", B, 1, H8, W8);
+        g2 = A.take("dcn3.g2", B, 1, H8, W8);
+        om3 = A.take("om3", B, 1, H8, W8, 0, 0, true);
+        al3 = A.take("aligned3", B, 1, H8, W8);
+        z0 = A.take("res3.z0", B, 1, H8, W8);
+        z1 = A.take("res3.z1", B, 1, H8, W8);
+        feat = A.take("feat", B, 1, H8, W8);
+        // regional-mask (fgs) copies of the streaming variant (one frame per call, one sequence per workspace)
+        if (t == 1 && B == 1) {
+            fg2 = A.take("fg2", 1, 0, H2 / 2, W2, 1);   // H2*W2 floats (kind 1 stores 2 floats per element)
+            sc_prop = A.take("fg.prop", 1, 6, H2, W2);
+            sc_cw = A.take("fg.carry", 1, 2, H2, W2);
+            sc_al = A.take("fg.aligned", 1, 8, H2, W2);
+            sc_up = A.take("fg.up", 1, 1, H8, W8);
+            sc_al3 = A.take("fg.aligned3", 1, 1, H8, W8);
+        }
     }
     size_t bytes() const { return A.cur; }
+    // slot of (clip b, frame i) in the clip-level stores
+    long long slot(int b, int i) const { return (long long)b * TC + i % TC; }
 };
 
 // One non-blocking side stream + an event pool per (host thread, device): state-independent work of upcoming frames is
@@ -494,7 +522,7 @@ struct Runner {
     }
     // fills the per-launch fields of a packed MFMA item's plan (what mfma() passes to launch_conv_mfma)
     ConvArgs bind(int id, int N, int H, int W, const std::vector<SrcBind>& srcs, const std::vector<DstBind>& dsts, const float* resid = nullptr,
-                  const float* flow = nullptr) const {
+                  long long resid_bs = 0) const {
         const Item& it = M.items[id];
         ConvArgs a = it.c;
         for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i].p; a.src[i].bstride = srcs[i].bs; a.src[i].pad = srcs[i].pad; }
@@ -504,7 +532,7 @@ struct Runner {
             a.dst[i].pad = dsts[i].pad;
         }
         a.N = N; a.H = H; a.W = W;
-        a.resid = resid; a.flow = flow;
+        a.resid = resid; a.resid_bstride = resid_bs;
         a.wpk = packed + it.off_w; a.bpk = packed + it.off_b; a.wsplit = packed + it.off_s;
         a.ovf = ovf();
         a.strict = strict;
@@ -512,10 +540,10 @@ struct Runner {
     }
 #ifdef CRFP_ACT_BF16
     // conv idA -> conv idB in one launch (conv3x3_bf16_pair_kernel): idA's output has no other reader and is never written
-    void mfma_pair(int idA, int idB, const char* name, int H, int W, std::vector<SrcBind> srcsA, std::vector<DstBind> dstsB,
-                   const float* residB = nullptr) {
+    void mfma_pair(int idA, int idB, const char* name, int N, int H, int W, std::vector<SrcBind> srcsA, std::vector<DstBind> dstsB,
+                   const float* residB = nullptr, long long residB_bs = 0) {
         if (rc) return;
-        const ConvArgs a = bind(idA, 1, H, W, srcsA, {}), b = bind(idB, 1, H, W, {{nullptr, 0}}, dstsB, residB);
+        const ConvArgs a = bind(idA, N, H, W, srcsA, {}), b = bind(idB, N, H, W, {{nullptr, 0}}, dstsB, residB, residB_bs);
         rc = launch_conv_pair(a, b, name, s);
     }
 #endif
@@ -528,32 +556,39 @@ struct Runner {
     void mfma_q(int id, int N, const Q4& in, const Q4& out) {
         mfma(id, N, in.H, in.W, {{in.p, in.bs()}}, {{out.p, out.bs(), 0, out.nq}});
     }
-    void narrow(int id, int H, int W, std::vector<const float*> srcs, float* dst, const float* resid = nullptr,
-                const float* flow = nullptr, const float* base = nullptr, const uint8_t* mask = nullptr,
-                int src0_pad = 0, int dst_pad = 0, const float* base_lr = nullptr) {
+    // 8x-resolution stencils over the B clips of the call.  NB: tensors are {pointer, batch stride in elements of their own type}
+    struct NB { const float* p = nullptr; long long bs = 0; NB() {} NB(const float* p_, long long bs_) : p(p_), bs(bs_) {} };
+    void narrow(int id, int H, int W, std::vector<NB> srcs, NB dst, NB resid = NB(), NB flow = NB(), const uint8_t* mask = nullptr,
+                long long mask_bs = 0, int src0_pad = 0, int dst_pad = 0, NB base_lr = NB()) {
         if (rc) return;
         const Item& it = M.items[id];
         NarrowArgs a = it.nw;
-        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i]; a.src[i].bstride = 0; a.src[i].pad = 0; }
+        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i].p; a.src[i].bstride = srcs[i].bs; a.src[i].pad = 0; }
         a.src[0].pad = src0_pad;
         a.dst_pad = dst_pad;
-        a.N = 1; a.H = H; a.W = W;
-        a.dst = dst; a.resid = resid; a.flow = flow; a.base = base; a.base_lr = base_lr; a.mask = mask;
+        a.N = L.B; a.H = H; a.W = W;
+        a.dst = const_cast<float*>(dst.p); a.dst_bstride = dst.bs;
+        a.resid = resid.p; a.resid_bstride = resid.bs;
+        a.flow = flow.p; a.flow_bstride = flow.bs;
+        a.base = nullptr; a.base_lr = base_lr.p; a.base_bstride = base_lr.bs;
+        a.mask = mask; a.mask_bstride = mask_bs;
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
         a.ovf = ovf();
         rc = launch_narrow(a, it.name, s);
     }
     // two stencils in one pass: item idA (its output has no other reader) feeding item idB (conv_narrow.hip, launch_narrow_pair)
-    void narrow_pair(int idA, int idB, const char* name, int H, int W, std::vector<const float*> srcsA, float* dst,
-                     const float* residB = nullptr, const float* flowB = nullptr) {
+    void narrow_pair(int idA, int idB, const char* name, int H, int W, std::vector<NB> srcsA, NB dst, NB residB = NB(), NB flowB = NB()) {
         if (rc) return;
         NarrowArgs a = M.items[idA].nw, b = M.items[idB].nw;
-        for (size_t i = 0; i < srcsA.size(); ++i) { a.src[i].p = srcsA[i]; a.src[i].bstride = 0; a.src[i].pad = 0; }
-        a.N = b.N = 1; a.H = b.H = H; a.W = b.W = W;
+        for (size_t i = 0; i < srcsA.size(); ++i) { a.src[i].p = srcsA[i].p; a.src[i].bstride = srcsA[i].bs; a.src[i].pad = 0; }
+        a.N = b.N = L.B; a.H = b.H = H; a.W = b.W = W;
         a.wpk = packed + M.items[idA].off_w; a.bpk = packed + M.items[idA].off_b;
         b.wpk = packed + M.items[idB].off_w; b.bpk = packed + M.items[idB].off_b;
-        b.dst = dst; b.resid = residB; b.flow = flowB; b.dst_pad = 0;
+        b.dst = const_cast<float*>(dst.p); b.dst_bstride = dst.bs;
+        b.resid = residB.p; b.resid_bstride = residB.bs;
+        b.flow = flowB.p; b.flow_bstride = flowB.bs;
+        b.dst_pad = 0;
         rc = launch_narrow_pair(a, b, name, s);
     }
     // which 8x-resolution conv pairs run fused (bit 0: encoder_hr.0->.2, 1: dcn_3 conv_fuse->offset/mask, 2: res3 conv1->conv2,
@@ -573,11 +608,16 @@ struct Runner {
         RUN(launch_nchw_to_q4(lrs, dst, n, 3, L.h, L.w, 0, s));
         return dst;
     }
+    // floats between two consecutive frames of what lr_to_q4 returns (fp32 build: a quad plane; bf16 build: the NCHW frame)
+    long long lr_frame_floats() const { return kActBf16 ? 3LL * L.h * L.w : (long long)L.h * L.w * 4 * (long long)sizeof(act_t) / 4; }
     long long lr_bs(long long nchw_bs) const { return kActBf16 ? nchw_bs : (nchw_bs ? (long long)L.h * L.w * 4 : 0); }
 
-    // FNet over nb pairs (reference model/CRFP.py:797-814); cur/prev: 3-channel frames as lr_to_q4 returns them (bs: NCHW batch stride)
-    void fnet(int nb, const float* cur, long long cur_bs, const float* prev, long long prev_bs) {
+    // FNet over nb pairs (reference model/CRFP.py:797-814); cur/prev: 3-channel frames as lr_to_q4 returns them (bs: NCHW batch stride);
+    // flow_out: nb consecutive fp32 flow quads [h][w][4] (component 0 = dx, 1 = dy)
+    void fnet(int nb, const float* cur, long long cur_bs, const float* prev, long long prev_bs, float* flow_out) {
         const int h = L.h, w = L.w;
+        if (!rc && nb > L.fnet_cap) { set_error("dsv: FNet pass of %d pairs exceeds the workspace's %d", nb, L.fnet_cap); rc = CRFP_E_WORKSPACE; }
+        if (rc || nb < 1) return;
         cur_bs = lr_bs(cur_bs); prev_bs = lr_bs(prev_bs);
         Q4 a0 = q(L.fa0, 8, h, w), a1 = q(L.fa1, 8, h, w), p1 = q(L.fp1, 8, L.h1, L.w1);
         Q4 b0 = q(L.fb0, 16, L.h1, L.w1), b1 = q(L.fb1, 16, L.h1, L.w1), p2 = q(L.fp2, 16, L.h2, L.w2);
@@ -586,7 +626,7 @@ struct Runner {
         Q4 e0 = q(L.fe0, 32, 2 * L.h3, 2 * L.w3), e1 = q(L.fe1, 32, 2 * L.h3, 2 * L.w3), u2 = q(L.fu2, 32, 4 * L.h3, 4 * L.w3);
         Q4 f0 = q(L.ff0, 16, 4 * L.h3, 4 * L.w3), f1 = q(L.ff1, 16, 4 * L.h3, 4 * L.w3), u3 = q(L.fu3, 16, 8 * L.h3, 8 * L.w3);
         Q4 g0 = q(L.fg0, 8, 8 * L.h3, 8 * L.w3), g1 = q(L.fg1, 1, 8 * L.h3, 8 * L.w3), fl = q(L.flow_lr, 1, h, w);
-        fl.p = flow_lr_slot();
+        fl.p = flow_out;
         mfma(IT_F0, nb, h, w, {{cur, cur_bs}, {prev, prev_bs}}, {{a0.p, a0.bs(), 0, 8}});
         mfma_q(IT_F0 + 1, nb, a0, a1);
         RUN(launch_avgpool2_q4(a1.p, a1.bs(), p1.p, p1.bs(), nb, 8, h, w, s));
@@ -615,7 +655,7 @@ struct Runner {
     // zero the P4 buffers (pads must read as 0; also gives the zero initial state)
     void reset_state() {
         if (!rc && hipMemsetAsync(ws + L.status, 0, 256, s) != hipSuccess) { set_error("dsv: hipMemsetAsync of the status word failed"); rc = 1; }
-        for (size_t off : {L.state_hr, L.carry, L.prev2}) {
+        for (size_t off : {L.state_hr.off, L.carry.off, L.prev2.off}) {
             const Buf* b = L.A.find(off);
             if (!rc && hipMemsetAsync(ws + off - b->guard, 0, b->bytes + b->guard, s) != hipSuccess) {
                 set_error("dsv: hipMemsetAsync of recurrent state failed");
@@ -624,67 +664,125 @@ struct Runner {
         }
     }
 
-    void encode_lr(int n, const float* lrs, long long bs) {   // lrs as lr_to_q4 returns them
+    // n consecutive LR frames (as lr_to_q4 returns them; bs: NCHW batch stride) -> encoder_lr features in n consecutive x_lr slots from slot0
+    void encode_lr(int n, const float* lrs, long long bs, long long slot0 = 0) {
+        if (rc || n < 1) return;
+        const long long xq = 8LL * L.h * L.w * 4;
         Q4 e0 = q(L.e_lr0, 8, L.h, L.w), x = q(L.x_lr, 8, L.h, L.w);
+        e0.p = adv(e0.p, slot0 * xq); x.p = adv(x.p, slot0 * xq);
         mfma(IT_ENC_LR0, n, L.h, L.w, {{lrs, lr_bs(bs)}}, {{e0.p, e0.bs(), 0, 8}});
         mfma_q(IT_ENC_LR1, n, e0, x);
+    }
+
+    // The clip-level stages for frames [i0, i1) of every clip (Layout::flat: called once with [0, t)): encoder_lr of those frames and
+    // FNet(frame i, frame i - 1) for those of them with i >= 1 (reference model/CRFP.py:1483-1508,1536).  lq: the call's LR frames as
+    // lr_to_q4 returns them, [B][t] in the API tensor's order.  parts: 1 = encoder_lr, 2 = FNet
+    void clip_stage(const float* lq, int i0, int i1, int parts) {
+        const long long lqf = lr_frame_floats(), lr_f = 3LL * L.h * L.w, fq = (long long)L.h * L.w * 4;
+        const int t = L.t, B = L.B;
+        if (L.flat) {   // i0 == 0, i1 == t: one pass over the B * t frames / the B * t - 1 consecutive pairs (B - 1 of them straddle two clips and are never read)
+            if (parts & 1) encode_lr(B * t, lq, lr_f, 0);
+            if ((parts & 2) && B * t > 1) fnet(B * t - 1, lq + lqf, lr_f, lq, lr_f, F(L.flow_lr) + fq);
+            return;
+        }
+        for (int b = 0; b < B && !rc; ++b) {
+            const float* f0 = lq + ((long long)b * t + i0) * lqf;
+            if (parts & 1) encode_lr(i1 - i0, f0, lr_f, L.slot(b, i0));
+            const int j0 = i0 > 0 ? i0 : 1;
+            if ((parts & 2) && i1 > j0)
+                fnet(i1 - j0, lq + ((long long)b * t + j0) * lqf, lr_f, lq + ((long long)b * t + j0 - 1) * lqf, lr_f, F(L.flow_lr) + L.slot(b, j0) * fq);
+        }
     }
 
     // ResidualBlockNoBN of level l (model/CRFP.py:449-481): y0 + conv2(relu(conv1(y0))), the 32 output channels going to the
     // propagated features (24) and the carried ones (8).  bf16 build: one launch, conv1's output stays in LDS.
     void res_block(int l, float* prop_next, float* carry_l, int H2, int W2) {
+        const int B = L.B;
+        const long long P2q = (long long)H2 * W2 * 4, P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;
 #ifdef CRFP_ACT_BF16
         if (pair_convs()) {
-            mfma_pair(it_lvl(l, L_RB1), it_lvl(l, L_RB2), "conv_mfma_pair:res.conv1_conv2_add", H2, W2, {{F(L.y0), 0}},
-                      {{prop_next, 0, 0, 6}, {carry_l, 0, 6, 8, 1}}, F(L.y0));
+            mfma_pair(it_lvl(l, L_RB1), it_lvl(l, L_RB2), "conv_mfma_pair:res.conv1_conv2_add", B, H2, W2, {{F(L.y0), L.y0.bs}},
+                      {{prop_next, 6 * P2q, 0, 6}, {carry_l, 6 * P2qp, 6, 8, 1}}, F(L.y0), L.y0.bs);
             return;
         }
 #endif
-        mfma(it_lvl(l, L_RB1), 1, H2, W2, {{F(L.y0), 0}}, {{F(L.y1), 0, 0, 8}});
-        mfma(it_lvl(l, L_RB2), 1, H2, W2, {{F(L.y1), 0}}, {{prop_next, 0, 0, 6}, {carry_l, 0, 6, 8, 1}}, 0, 0, F(L.y0), 0);
+        mfma(it_lvl(l, L_RB1), B, H2, W2, {{F(L.y0), L.y0.bs}}, {{F(L.y1), L.y1.bs, 0, 8}});
+        mfma(it_lvl(l, L_RB2), B, H2, W2, {{F(L.y1), L.y1.bs}}, {{prop_next, 6 * P2q, 0, 6}, {carry_l, 6 * P2qp, 6, 8, 1}}, 0, 0, F(L.y0), L.y0.bs);
     }
 
-    // one iteration of the recurrent loop (reference model/CRFP.py:1555-1684)
+    // What one frame step reads and writes outside the workspace: frame i of each of the B clips, so every batch stride is
+    // "one clip" of the API tensor (t frames); the clip-level stores hand over their slot of frame i likewise.
+    struct FrameIO {
+        const float* lr = nullptr; long long lr_b = 0;       // [3][h][w] fp32
+        const float* fv = nullptr; long long fv_b = 0;       // [3][8h][8w] fp32
+        const uint8_t* mk = nullptr; long long mk_b = 0;     // [8h][8w] u8
+        float* out = nullptr; long long out_b = 0;           // [3|1][8h][8w] fp32
+        const float* flow_lr = nullptr; long long flow_b = 0;   // FNet's flow quads of this frame (null: first frame)
+        const float* x_lr = nullptr; long long x_b = 0;         // encoder_lr features of this frame
+    };
+    FrameIO frame_io(int i, const float* lrs, const float* fvs, const uint8_t* mks, float* out, int y_only) const {
+        const long long lr_f = 3LL * L.h * L.w, hr_px = 64LL * L.h * L.w, xq = 8LL * L.h * L.w * 4, fq = (long long)L.h * L.w * 4;
+        const int co = y_only ? 1 : 3, t = L.t;
+        FrameIO f;
+        f.lr = lrs + i * lr_f; f.lr_b = t * lr_f;
+        f.fv = fvs + i * 3 * hr_px; f.fv_b = t * 3 * hr_px;
+        f.mk = mks + i * hr_px; f.mk_b = t * hr_px;
+        f.out = out + (long long)i * co * hr_px; f.out_b = (long long)t * co * hr_px;
+        f.flow_lr = i > 0 ? F(L.flow_lr) + L.slot(0, i) * fq : nullptr; f.flow_b = L.TC * fq;
+        f.x_lr = adv(F(L.x_lr), L.slot(0, i) * xq); f.x_b = L.TC * xq;
+        return f;
+    }
+
     // state-independent part of a frame (reference model/CRFP.py:1538-1547,1560,1565-1566): buffer set `par`
     // before_ups: event this stream waits for right before the upsample conv, the only consumer of x_lr here (clip
     // schedule: the fovea blend and encoder_hr of frame 0 then run beside encoder_lr instead of behind it)
     // parts: 1 = fovea blend + encoder_hr + upsample conv (need no flow), 2 = the two flow up-samplings (need FNet)
-    void frame_pre(int par, bool first, const float* lr, const float* fv, const uint8_t* mk, const float* flow_lr_q4,
-                   const float* x_lr_i, hipEvent_t before_ups = nullptr, int parts = 3) {
-        const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
+    void frame_pre(int par, bool first, const FrameIO& io, hipEvent_t before_ups = nullptr, int parts = 3) {
+        const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w, B = L.B;
         const long long P8q = (long long)H8 * W8 * 4;
         if (parts & 1) {
-            RUN(launch_hr_prep(lr, fv, mk, F(L.xin8[par]), h, w, s));
+            const Ten& xin = L.xin8[par];
+            RUN(launch_hr_prep(io.lr, io.fv, io.mk, F(xin), h, w, s, B, io.lr_b, io.fv_b, io.mk_b, xin.bs));
             if (pair_mask() & 1)
-                narrow_pair(IT_EH0, IT_EH1, "conv_narrow_pair:enc_hr", H8, W8, {F(L.xin8[par]), adv(F(L.xin8[par]), P8q)}, F(L.x_hr[par]));
+                narrow_pair(IT_EH0, IT_EH1, "conv_narrow_pair:enc_hr", H8, W8, {{F(xin), xin.bs}, {adv(F(xin), P8q), xin.bs}}, {F(L.x_hr[par]), L.x_hr[par].bs});
             else {
-                narrow(IT_EH0, H8, W8, {F(L.xin8[par]), adv(F(L.xin8[par]), P8q)}, F(L.eh[par]));
-                narrow(IT_EH1, H8, W8, {F(L.eh[par])}, F(L.x_hr[par]));
+                narrow(IT_EH0, H8, W8, {{F(xin), xin.bs}, {adv(F(xin), P8q), xin.bs}}, {F(L.eh[par]), L.eh[par].bs});
+                narrow(IT_EH1, H8, W8, {{F(L.eh[par]), L.eh[par].bs}}, {F(L.x_hr[par]), L.x_hr[par].bs});
             }
             if (before_ups && !rc && hipStreamWaitEvent(s, before_ups, 0) != hipSuccess) { set_error("dsv: hipStreamWaitEvent failed"); rc = 1; }
-            mfma(IT_UPS, 1, h, w, {{x_lr_i, 0}}, {{F(L.prop0[par]), 0, 0, 6}}, H2, W2);
+            mfma(IT_UPS, B, h, w, {{io.x_lr, io.x_b}}, {{F(L.prop0[par]), L.prop0[par].bs, 0, 6}}, H2, W2);
         }
         if (!first && (parts & 2)) {
-            RUN(crfp::launch_upflow(flow_lr_q4, 0, F(L.flow2[par]), 0, 1, h, w, 2, s));
-            RUN(crfp::launch_upflow(flow_lr_q4, 0, F(L.flow8[par]), 0, 1, h, w, 8, s));
+            RUN(crfp::launch_upflow(io.flow_lr, io.flow_b, F(L.flow2[par]), L.flow2[par].bs, B, h, w, 2, s));
+            RUN(crfp::launch_upflow(io.flow_lr, io.flow_b, F(L.flow8[par]), L.flow8[par].bs, B, h, w, 8, s));
         }
     }
 
-    // recurrent part of a frame (reference model/CRFP.py:1562-1684)
-    void frame(int par, bool first, const float* lr, const uint8_t* mk, float* out, const uint8_t* fg = nullptr) {
-        const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
+    // downsample(state) -> prev2 (model/CRFP.py:1569)
+    void downsample_state() {
+        mfma(IT_DOWN, L.B, 2 * L.h, 2 * L.w, {{F(L.state_hr), L.state_hr.bs, 1}}, {{F(L.prev2), L.prev2.bs, 0, 8, 1}});
+    }
+
+    // recurrent part of a frame (reference model/CRFP.py:1562-1684), all B clips of the call in lock-step: one launch per layer
+    void frame(int par, bool first, const FrameIO& io, const uint8_t* fg = nullptr) {
+        const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w, B = L.B;
         const long long P2q = (long long)H2 * W2 * 4;
         const long long P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;   // padded (P4) plane at 2x resolution
+        const long long bs6 = 6 * P2q, bs8 = 8 * P2q;
         float* prop = F(L.prop0[par]);
         float* prop_next = F(L.prop_a);
         float* prop_other = F(L.prop_b);
         float* carry = F(L.carry);
+        auto nb = [&](const Ten& tn) { return NB(F(tn), tn.bs); };
         if (!first) {
             float* flow2 = F(L.flow2[par]);
             float* flow8 = F(L.flow8[par]);
-            if (!down_done) mfma(IT_DOWN, 1, H2, W2, {{F(L.state_hr), 0, 1}}, {{F(L.prev2), 0, 0, 8, 1}});
-            RUN(launch_flow_warp_p4_dual_8_6(F(L.prev2), carry, flow2, F(L.prev2w), F(L.carryw), H2, W2, s));
-            RUN(launch_flow_warp_q4(F(L.state_hr), 0, flow8, 0, F(L.prevhrw), 0, 1, 1, H8, W8, 0, 1, s));
+            const long long f2b = L.flow2[par].bs, f8b = L.flow8[par].bs;
+            if (!down_done) downsample_state();
+            WarpDualStrides wb;
+            wb.xa = L.prev2.bs; wb.xb = L.carry.bs; wb.flow = f2b; wb.outa = L.prev2w.bs; wb.outb = L.carryw.bs;
+            RUN(launch_flow_warp_p4_dual_8_6(F(L.prev2), carry, flow2, F(L.prev2w), F(L.carryw), H2, W2, s, B, wb));
+            RUN(launch_flow_warp_q4(F(L.state_hr), L.state_hr.bs, flow8, f8b, F(L.prevhrw), L.prevhrw.bs, B, 1, H8, W8, 0, 1, s));
             const float* offprev = nullptr;
             if (fg) RUN(crfp::launch_fg_prep(fg, F(L.fg2), H8, W8, s));
             for (int l = 0; l < 3; ++l) {
@@ -693,22 +791,22 @@ struct Runner {
                 const bool s3 = M.use_s3;   // f holds the SRC_S3 image (same size) instead of fp32 Q4
 #ifdef CRFP_ACT_BF16
                 if (pair_convs())   // dcn_block.0 -> .2 in one launch, the 32-channel tensor between them stays in LDS
-                    mfma_pair(it_lvl(l, L_DB0), it_lvl(l, L_DB1), "conv_mfma_pair:dcn.block0_block2", H2, W2,
-                              {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}}, {{l == 0 ? f : F(L.fb), 0, 0, 8}});
+                    mfma_pair(it_lvl(l, L_DB0), it_lvl(l, L_DB1), "conv_mfma_pair:dcn.block0_block2", B, H2, W2,
+                              {{prop, bs6}, {cw, bs6}, {F(L.prev2w), bs8}, {flow2, f2b}, {nullptr, 0}}, {{l == 0 ? f : F(L.fb), bs8, 0, 8}});
                 else
 #endif
                 {
-                mfma(it_lvl(l, L_DB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.prev2w), 0}, {flow2, 0}, {nullptr, 0}},
-                     {{F(L.fa), 0, 0, 8}});
+                mfma(it_lvl(l, L_DB0), B, H2, W2, {{prop, bs6}, {cw, bs6}, {F(L.prev2w), bs8}, {flow2, f2b}, {nullptr, 0}},
+                     {{F(L.fa), bs8, 0, 8}});
                 if (l == 0) {
-                    if (s3) mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, 0);
-                    else mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{f, 0, 0, 8}});
+                    if (s3) mfma(it_lvl(l, L_DB1), B, H2, W2, {{F(L.fa), bs8}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, bs8);
+                    else mfma(it_lvl(l, L_DB1), B, H2, W2, {{F(L.fa), bs8}}, {{f, bs8, 0, 8}});
                 } else
-                    mfma(it_lvl(l, L_DB1), 1, H2, W2, {{F(L.fa), 0}}, {{F(L.fb), 0, 0, 8}});
+                    mfma(it_lvl(l, L_DB1), B, H2, W2, {{F(L.fa), bs8}}, {{F(L.fb), bs8, 0, 8}});
                 }
                 if (l > 0) {
-                    if (s3) mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, 0);
-                    else mfma(it_lvl(l, L_FUSE), 1, H2, W2, {{F(L.fb), 0}, {offprev, 0}}, {{f, 0, 0, 8}});
+                    if (s3) mfma(it_lvl(l, L_FUSE), B, H2, W2, {{F(L.fb), bs8}, {offprev, bs8}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, bs8);
+                    else mfma(it_lvl(l, L_FUSE), B, H2, W2, {{F(L.fb), bs8}, {offprev, bs8}}, {{f, bs8, 0, 8}});
                 }
                 const Item& dw = M.items[it_lvl(l, L_DCNW)];
                 const bool f16 = !strict && dcn_g8_use_f16();
@@ -716,79 +814,80 @@ struct Runner {
                     const Item& om = M.items[it_lvl(l, L_OMF)];
                     DcnFuseArgs fa;
                     memset(&fa, 0, sizeof(fa));
-                    fa.feat = f; fa.feat_b = 0; fa.flow = flow2; fa.flow_b = 0;
+                    fa.feat = f; fa.feat_b = bs8; fa.flow = flow2; fa.flow_b = f2b;
                     fa.wconv = (const char*)(packed + om.off_s) + conv_split16_offset_bytes(om.c); fa.bconv = packed + om.off_b;
-                    fa.x = F(L.prev2); fa.xb = 0;
+                    fa.x = F(L.prev2); fa.xb = L.prev2.bs;
                     fa.wdcn = packed + dw.off_w + 36 * 2 * 32 * 4; fa.bdcn = packed + dw.off_b;
-                    fa.out = F(L.aligned); fa.ob = 0; fa.N = 1; fa.H = H2; fa.W = W2; fa.ovf = ovf();
+                    fa.out = F(L.aligned); fa.ob = bs8; fa.N = B; fa.H = H2; fa.W = W2; fa.ovf = ovf();
                     RUN(launch_dcn_fused(fa, s));
                 } else {
-                    mfma(it_lvl(l, L_OM), 1, H2, W2, {{f, 0}}, {{F(L.offmask), 0, 0, 54}}, 0, 0, nullptr, 0, flow2, 0);
-                    RUN(launch_dcn_g8(F(L.prev2), 0, F(L.offmask), 0, packed + dw.off_w + (f16 ? 36 * 2 * 32 * 4 : 0), packed + dw.off_b,
-                                      F(L.aligned), 0, 1, H2, W2, s, f16, ovf()));
+                    mfma(it_lvl(l, L_OM), B, H2, W2, {{f, bs8}}, {{F(L.offmask), L.offmask.bs, 0, 54}}, 0, 0, nullptr, 0, flow2, f2b);
+                    RUN(launch_dcn_g8(F(L.prev2), L.prev2.bs, F(L.offmask), L.offmask.bs, packed + dw.off_w + (f16 ? 36 * 2 * 32 * 4 : 0), packed + dw.off_b,
+                                      F(L.aligned), bs8, B, H2, W2, s, f16, ovf()));
                 }
-                if (fg && l > 0) {  // model/CRFP_test.py:2361,2375: resblock input * fg (x0.25) for levels 1, 2
+                if (fg && l > 0) {  // model/CRFP_test.py:2361,2375: resblock input * fg (x0.25) for levels 1, 2   (one sequence per workspace: B == 1)
                     RUN(launch_scale_q4(prop, 0, F(L.sc_prop), 6, H2, W2, F(L.fg2), nullptr, s));
                     RUN(launch_scale_q4(cw, 0, F(L.sc_cw), 2, H2, W2, F(L.fg2), nullptr, s));
                     RUN(launch_scale_q4(F(L.aligned), 0, F(L.sc_al), 8, H2, W2, F(L.fg2), nullptr, s));
                     mfma(it_lvl(l, L_RB0), 1, H2, W2, {{F(L.sc_prop), 0}, {F(L.sc_cw), 0}, {F(L.sc_al), 0}}, {{F(L.y0), 0, 0, 8}});
                 } else
-                    mfma(it_lvl(l, L_RB0), 1, H2, W2, {{prop, 0}, {cw, 0}, {F(L.aligned), 0}}, {{F(L.y0), 0, 0, 8}});
+                    mfma(it_lvl(l, L_RB0), B, H2, W2, {{prop, bs6}, {cw, bs6}, {F(L.aligned), bs8}}, {{F(L.y0), bs8, 0, 8}});
                 res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2);
                 prop = prop_next;
                 std::swap(prop_next, prop_other);
                 offprev = f;
             }
-            mfma(IT_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up), 0, 0, 1}}, H8, W8);
-            mfma(IT_POFF, 1, H2, W2, {{offprev, 0}}, {{F(L.poff), 0, 0, 1}}, H8, W8);
+            mfma(IT_UPP, B, H2, W2, {{prop, bs6}}, {{F(L.up), L.up.bs, 0, 1}}, H8, W8);
+            mfma(IT_POFF, B, H2, W2, {{offprev, bs8}}, {{F(L.poff), L.poff.bs, 0, 1}}, H8, W8);
+            const NB fl8(flow8, f8b);
             if (pair_mask() & 8)
-                narrow_pair(IT_D3B0, IT_D3B1, "conv_narrow_pair:dcn3.block", H8, W8, {F(L.up), F(L.prevhrw), flow8}, F(L.g1));
+                narrow_pair(IT_D3B0, IT_D3B1, "conv_narrow_pair:dcn3.block", H8, W8, {nb(L.up), nb(L.prevhrw), fl8}, nb(L.g1));
             else {
-                narrow(IT_D3B0, H8, W8, {F(L.up), F(L.prevhrw), flow8}, F(L.g0));
-                narrow(IT_D3B1, H8, W8, {F(L.g0)}, F(L.g1));
+                narrow(IT_D3B0, H8, W8, {nb(L.up), nb(L.prevhrw), fl8}, nb(L.g0));
+                narrow(IT_D3B1, H8, W8, {nb(L.g0)}, nb(L.g1));
             }
             if (pair_mask() & 2)
-                narrow_pair(IT_D3FUSE, IT_D3OM, "conv_narrow_pair:dcn3.fuse_offmask", H8, W8, {F(L.g1), F(L.poff)}, F(L.om3), nullptr, flow8);
+                narrow_pair(IT_D3FUSE, IT_D3OM, "conv_narrow_pair:dcn3.fuse_offmask", H8, W8, {nb(L.g1), nb(L.poff)}, nb(L.om3), NB(), fl8);
             else
-                narrow(IT_D3FUSE, H8, W8, {F(L.g1), F(L.poff)}, F(L.g2));
+                narrow(IT_D3FUSE, H8, W8, {nb(L.g1), nb(L.poff)}, nb(L.g2));
             const Item& d3 = M.items[IT_D3W];
             // dcn_3 with its offset / mask conv inside (gather.hip dcn3_kernel<true>): fp32 build 94.0 vs 73.7 + 37.3 us same-box, bit-identical;
             // the bf16 build keeps two kernels (its stand-alone conv runs on the bf16 MFMA: 84.8 vs 59.8 + 28.4 us, not worth the changed bits)
             if (!kActBf16 && !(pair_mask() & 2) && dcn_fused_enabled()) {
                 const Item& om = M.items[IT_D3OM];
-                RUN(launch_dcn3_fused(F(L.state_hr), 0, F(L.g2), 0, flow8, packed + om.off_w, packed + om.off_b, packed + d3.off_w, packed + d3.off_b,
-                                      F(L.al3), 0, 1, H8, W8, s));
+                RUN(launch_dcn3_fused(F(L.state_hr), L.state_hr.bs, F(L.g2), L.g2.bs, flow8, packed + om.off_w, packed + om.off_b, packed + d3.off_w,
+                                      packed + d3.off_b, F(L.al3), L.al3.bs, B, H8, W8, s, f8b));
             } else {
-                if (!(pair_mask() & 2)) narrow(IT_D3OM, H8, W8, {F(L.g2)}, F(L.om3), nullptr, flow8);
-                RUN(launch_dcn3(F(L.state_hr), 0, F(L.om3), 0, packed + d3.off_w, packed + d3.off_b, F(L.al3), 0, 1, H8, W8, s));
+                if (!(pair_mask() & 2)) narrow(IT_D3OM, H8, W8, {nb(L.g2)}, nb(L.om3), NB(), fl8);
+                RUN(launch_dcn3(F(L.state_hr), L.state_hr.bs, F(L.om3), L.om3.bs, packed + d3.off_w, packed + d3.off_b, F(L.al3), L.al3.bs, B, H8, W8, s));
             }
             if (fg) {           // model/CRFP_test.py:2389
                 RUN(launch_scale_q4(F(L.up), 0, F(L.sc_up), 1, H8, W8, nullptr, fg, s));
                 RUN(launch_scale_q4(F(L.al3), 0, F(L.sc_al3), 1, H8, W8, nullptr, fg, s));
-                narrow(IT_R3_0, H8, W8, {F(L.sc_up), F(L.sc_al3)}, F(L.z0));
+                narrow(IT_R3_0, H8, W8, {nb(L.sc_up), nb(L.sc_al3)}, nb(L.z0));
             } else
-                narrow(IT_R3_0, H8, W8, {F(L.up), F(L.al3)}, F(L.z0));
+                narrow(IT_R3_0, H8, W8, {nb(L.up), nb(L.al3)}, nb(L.z0));
         } else {
             for (int l = 0; l < 3; ++l) {
-                mfma(it_lvl(l, L_RB0F), 1, H2, W2, {{prop, 0}, {nullptr, 0}}, {{F(L.y0), 0, 0, 8}});
+                mfma(it_lvl(l, L_RB0F), B, H2, W2, {{prop, bs6}, {nullptr, 0}}, {{F(L.y0), bs8, 0, 8}});
                 res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2);
                 prop = prop_next;
                 std::swap(prop_next, prop_other);
             }
-            mfma(IT_UPP, 1, H2, W2, {{prop, 0}}, {{F(L.up), 0, 0, 1}}, H8, W8);
-            narrow(IT_R3_0F, H8, W8, {F(L.up)}, F(L.z0));
+            mfma(IT_UPP, B, H2, W2, {{prop, bs6}}, {{F(L.up), L.up.bs, 0, 1}}, H8, W8);
+            narrow(IT_R3_0F, H8, W8, {nb(L.up)}, nb(L.z0));
         }
         if (pair_mask() & 4)
-            narrow_pair(IT_R3_1, IT_R3_2, "conv_narrow_pair:res3.conv1_conv2_add", H8, W8, {F(L.z0)}, F(L.feat), F(L.z0));
+            narrow_pair(IT_R3_1, IT_R3_2, "conv_narrow_pair:res3.conv1_conv2_add", H8, W8, {nb(L.z0)}, nb(L.feat), nb(L.z0));
         else {
-            narrow(IT_R3_1, H8, W8, {F(L.z0)}, F(L.z1));
-            narrow(IT_R3_2, H8, W8, {F(L.z1)}, F(L.feat), F(L.z0));
+            narrow(IT_R3_1, H8, W8, {nb(L.z0)}, nb(L.z1));
+            narrow(IT_R3_2, H8, W8, {nb(L.z1)}, nb(L.feat), nb(L.z0));
         }
-        narrow(IT_TTTF, H8, W8, {F(L.feat), F(L.x_hr[par])}, F(L.state_hr), nullptr, nullptr, nullptr, mk, 0, 1);
+        narrow(IT_TTTF, H8, W8, {nb(L.feat), nb(L.x_hr[par])}, nb(L.state_hr), NB(), NB(), io.mk, io.mk_b, 0, 1);
         // output head: conv_last(state) + x8 bilinear LR;
         // the x8 bilinear base is recomputed from the LR frame in both builds (fp32: 39.0 vs 41.3 us against reading the quad hr_prep
         // stored -- identical values, 59 MB less traffic; bf16: a stored bf16 base would cost 2^-9 of the output range)
-        narrow(IT_LAST, H8, W8, {F(L.state_hr)}, out, nullptr, nullptr, nullptr, nullptr, 1, 0, lr);
+        narrow(IT_LAST, H8, W8, {nb(L.state_hr)}, NB(io.out, io.out_b), NB(), NB(), nullptr, 0, 1, 0, NB(io.lr, io.lr_b));
     }
 };
 
@@ -870,49 +969,57 @@ int CRFP_API(crfp_dsv_pack_weights)(const float* const* params, int y_only, void
     return 0;
 }
 
-size_t CRFP_API(crfp_dsv_workspace_bytes)(int t, int h, int w) {
-    if (t < 1 || h < 8 || w < 8) return 0;
-    return Layout(t, h, w).bytes();
-}
+static bool dims_ok(int n, int t, int h, int w) { return n >= 1 && t >= 1 && h >= 8 && w >= 8 && (long long)n * t <= (1 << 20); }
 
-static int check_common(const void* packed, int t, int h, int w, void* ws, size_t ws_bytes, const Layout& L) {
+size_t CRFP_API(crfp_dsv_batch_workspace_bytes)(int n, int t, int h, int w) {
+    if (!dims_ok(n, t, h, w)) return 0;
+    return Layout(n, t, h, w).bytes();
+}
+size_t CRFP_API(crfp_dsv_workspace_bytes)(int t, int h, int w) { return CRFP_API(crfp_dsv_batch_workspace_bytes)(1, t, h, w); }
+
+static int check_common(const void* packed, int n, int t, int h, int w, void* ws, size_t ws_bytes, const Layout& L) {
     if (!packed || !ws) { set_error("dsv: null packed weights or workspace"); return CRFP_E_BADARG; }
-    if (t < 1 || h < 8 || w < 8) { set_error("dsv: need t>=1, h,w>=8 (got %d,%d,%d)", t, h, w); return CRFP_E_BADARG; }
+    if (!dims_ok(n, t, h, w)) { set_error("dsv: need n,t>=1, h,w>=8 (got %d,%d,%d,%d)", n, t, h, w); return CRFP_E_BADARG; }
     if (ws_bytes < L.bytes()) { set_error("dsv: workspace %zu < required %zu bytes", ws_bytes, L.bytes()); return CRFP_E_WORKSPACE; }
     return 0;
 }
 
-size_t CRFP_API(crfp_dsv_status_offset)(int t, int h, int w) {
-    if (t < 1 || h < 8 || w < 8) return 0;
-    return Layout(t, h, w).status;
+size_t CRFP_API(crfp_dsv_batch_status_offset)(int n, int t, int h, int w) {
+    if (!dims_ok(n, t, h, w)) return 0;
+    return Layout(n, t, h, w).status;
 }
+size_t CRFP_API(crfp_dsv_status_offset)(int t, int h, int w) { return CRFP_API(crfp_dsv_batch_status_offset)(1, t, h, w); }
 
-int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
-                          float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+// n clips in lock-step through the recurrent chain (reference model/CRFP.py:1510-1535: every op of forward() carries the batch
+// axis n): ONE launch per layer and frame step over all n clips, so a 360 x 640 map that is a single round of workgroups for one
+// clip becomes n rounds whose load / MFMA / store phases overlap.  Per clip the arithmetic is that of a one-clip call, bit for bit.
+int CRFP_API(crfp_dsv_forward_batch)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                           float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
     const int y_only = flags & CRFP_DSV_Y_ONLY;
     if (kActBf16 && (flags & CRFP_DSV_STRICT_F32)) { set_error("dsv (bf16 storage): CRFP_DSV_STRICT_F32 belongs to the fp32 entry points"); return CRFP_E_UNSUPPORTED; }
-    Layout L(t, h, w);
-    int rc = check_common(packed, t, h, w, workspace, workspace_bytes, L);
+    if (!dims_ok(n, t, h, w)) { set_error("dsv: need n,t>=1, h,w>=8 (got %d,%d,%d,%d)", n, t, h, w); return CRFP_E_BADARG; }
+    Layout L(n, t, h, w);
+    int rc = check_common(packed, n, t, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     if (!lrs || !fvs || !mks || !out) { set_error("dsv_forward_clip: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
-    const long long lr_f = 3LL * h * w, hr_px = 64LL * h * w;
-    const int co = y_only ? 1 : 3;
-    const long long xq = 8LL * h * w * 4, fq = 1LL * h * w * 4;
+    const int TC = L.TC;
     SideStream* ssp = side_stream_enabled() && !prof_enabled() && !(flags & CRFP_DSV_SINGLE_STREAM) ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
     if (!ssp) {
         // single-stream schedule (also used while per-kernel timing is on: events bracket launches per stream)
         R.reset_state();
-        const float* lq = R.lr_to_q4(lrs, t, 0);
-        const long long lq_f = kActBf16 ? lr_f : (long long)h * w * 4 * (long long)sizeof(act_t) / 4;   // floats between frames
-        if (t > 1) R.fnet(t - 1, lq + lq_f, lr_f, lq, lr_f);
-        R.encode_lr(t, lq, lr_f);
+        const float* lq = R.lr_to_q4(lrs, n * t, 0);
         for (int i = 0; i < t && !R.rc; ++i) {
-            R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
-                        i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.adv(R.F(L.x_lr), i * xq));
-            R.frame(i & 1, i == 0, lrs + i * lr_f, mks + i * hr_px, out + (long long)i * co * hr_px);
+            if (i % TC == 0) {   // flat: once, FNet first (the order of the one-clip engine of rounds 1-3)
+                const int i1 = i + TC < t ? i + TC : t;
+                R.clip_stage(lq, i, i1, 2);
+                R.clip_stage(lq, i, i1, 1);
+            }
+            const Runner::FrameIO io = R.frame_io(i, lrs, fvs, mks, out, y_only);
+            R.frame_pre(i & 1, i == 0, io);
+            R.frame(i & 1, i == 0, io);
         }
         return R.rc;
     }
@@ -932,12 +1039,11 @@ int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* 
     // the status word and the recurrent state are cleared BEFORE the fork: the side stream's first kernel (frame 0's fovea
     // blend) may raise the overflow bit, and a memset racing with it on the other stream could wipe that
     R.reset_state();
-    const float* lq = R.lr_to_q4(lrs, t, 0);   // before the fork: FNet on the side stream reads it as well
-    const long long lq_f = kActBf16 ? lr_f : (long long)h * w * 4 * (long long)sizeof(act_t) / 4;
+    const float* lq = R.lr_to_q4(lrs, n * t, 0);   // before the fork: FNet on the side stream reads it as well
     if (R.rc) return R.rc;
     if (hipEventRecord(ev_start, main_s) != hipSuccess || hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
     forked = true;
-    R.encode_lr(t, lq, lr_f);
+    R.clip_stage(lq, 0, TC < t ? TC : t, 1);   // encoder_lr of the first chunk (flat: of every frame) on the caller's stream, beside frame 0's fovea blend
     if (hipEventRecord(ev_xlr, main_s) != hipSuccess) return fail("record");
     for (int i = 0; i < t && !R.rc; ++i) {
         hipEvent_t pre_done = ss.event(2 + 2 * i), main_done = ss.event(3 + 2 * i);
@@ -947,19 +1053,27 @@ int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* 
         // FNet (all pairs, 0.7 ms) goes BEHIND frame 0's pre-work: frame 0 needs no flow, and with FNet first the caller's
         // stream sat idle for FNet + pre(0) at the start of every clip.  It now runs beside frame 0's recurrent part.
         // (running the one pair frame 1 needs first and the other pairs beside frame 1 changes nothing: 10.62 vs 10.57 ms fp32, 6.31 vs 6.29 bf16)
-        if (i == 1) R.fnet(t - 1, lq + lq_f, lr_f, lq, lr_f);
+        if (i == 1) R.clip_stage(lq, 0, TC < t ? TC : t, 2);
+        // later chunks of a long clip: both clip-level stages on the side stream, in front of the chunk's first frame (the stores'
+        // previous contents were last read by this stream's own earlier pre-work)
+        if (i > 0 && i % TC == 0) R.clip_stage(lq, i, i + TC < t ? i + TC : t, 3);
         if (i >= 2 && hipStreamWaitEvent(ss.s, ss.event(3 + 2 * (i - 2)), 0) != hipSuccess) return fail("wait");
-        R.frame_pre(i & 1, i == 0, lrs + i * lr_f, fvs + i * 3 * hr_px, mks + i * hr_px,
-                    i > 0 ? R.F(L.flow_lr) + (i - 1) * fq : nullptr, R.adv(R.F(L.x_lr), i * xq), i == 0 ? ev_xlr : nullptr);
+        const Runner::FrameIO io = R.frame_io(i, lrs, fvs, mks, out, y_only);
+        R.frame_pre(i & 1, i == 0, io, i == 0 ? ev_xlr : nullptr);
         if (hipEventRecord(pre_done, ss.s) != hipSuccess) return fail("record");
         // main: recurrent part of frame i
         R.s = main_s;
         if (hipStreamWaitEvent(main_s, pre_done, 0) != hipSuccess) return fail("wait");
-        R.frame(i & 1, i == 0, lrs + i * lr_f, mks + i * hr_px, out + (long long)i * co * hr_px);
+        R.frame(i & 1, i == 0, io);
         if (hipEventRecord(main_done, main_s) != hipSuccess) return fail("record");
     }
     if (R.rc) join();   // a launch failed mid-clip: the last pre_done wait may not have been enqueued
     return R.rc;
+}
+
+int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                          float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    return CRFP_API(crfp_dsv_forward_batch)(packed, flags, lrs, fvs, mks, out, 1, t, h, w, workspace, workspace_bytes, stream);
 }
 
 int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
@@ -967,13 +1081,16 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
                           size_t workspace_bytes, void* stream) {
     const int y_only = flags & CRFP_DSV_Y_ONLY;
     if (kActBf16 && (flags & CRFP_DSV_STRICT_F32)) { set_error("dsv (bf16 storage): CRFP_DSV_STRICT_F32 belongs to the fp32 entry points"); return CRFP_E_UNSUPPORTED; }
-    Layout L(1, h, w);
-    int rc = check_common(packed, 1, h, w, workspace, workspace_bytes, L);
+    Layout L(1, 1, h, w);
+    int rc = check_common(packed, 1, 1, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     const bool resident = (flags & CRFP_DSV_INPUTS_RESIDENT) != 0;
     if (!lr || !fv || !mk || !out || (!first && !resident && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
+    // one frame of one sequence: the frame's tensors ARE the call's arguments; its flow and encoder_lr features sit in slot 0 / the parity slot
+    Runner::FrameIO io;
+    io.lr = lr; io.fv = fv; io.mk = mk; io.out = out; io.x_lr = R.F(L.x_lr);
     SideStream* ssp = (!first && side_stream_enabled() && !prof_enabled() && !(flags & CRFP_DSV_SINGLE_STREAM)) ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
     // per-sequence host note, kept next to the side stream (also when this call runs on one stream)
@@ -1015,10 +1132,11 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
         if (!ssp) {   // one stream (first frame, profiling, CRFP_DSV_SINGLE_STREAM, CRFP_SIDE_STREAM=0): same order, same bits
             if (first) R.reset_state();
             keep_and_get(&cur, &prev);
-            if (!first) R.fnet(1, cur, 0, prev, 0);
+            if (!first) R.fnet(1, cur, 0, prev, 0, R.flow_lr_slot());
             R.encode_lr(1, cur, 0);
-            R.frame_pre(par, first != 0, lr, fv, mk, first ? nullptr : R.flow_lr_slot(), R.F(L.x_lr));
-            R.frame(par, first != 0, lr, mk, out, fg);
+            io.flow_lr = first ? nullptr : R.flow_lr_slot();
+            R.frame_pre(par, first != 0, io);
+            R.frame(par, first != 0, io, fg);
             ctx->kept = R.rc == 0;
             ctx->chained = false;
             return R.rc;
@@ -1040,16 +1158,17 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
         forked = true;
         if (!early && hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
         keep_and_get(&cur, &prev);
-        R.fnet(1, cur, 0, prev, 0);
+        R.fnet(1, cur, 0, prev, 0, R.flow_lr_slot());
         R.encode_lr(1, cur, 0);
-        R.frame_pre(par, false, lr, fv, mk, R.flow_lr_slot(), R.F(L.x_lr), nullptr, 3);   // incl. the two flow up-samplings (set par as well)
+        io.flow_lr = R.flow_lr_slot();
+        R.frame_pre(par, false, io, nullptr, 3);   // incl. the two flow up-samplings (set par as well)
         if (early && hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
-        R.mfma(IT_DOWN, 1, 2 * h, 2 * w, {{R.F(L.state_hr), 0, 1}}, {{R.F(L.prev2), 0, 0, 8, 1}});   // needs the state frame i - 1 wrote
+        R.downsample_state();   // needs the state frame i - 1 wrote
         R.down_done = true;
         if (hipEventRecord(ev_side, ss.s) != hipSuccess) return fail("record");
         R.s = main_s;
         if (hipStreamWaitEvent(main_s, ev_side, 0) != hipSuccess) return fail("join");
-        R.frame(par, false, lr, mk, out, fg);
+        R.frame(par, false, io, fg);
         ctx->kept = ctx->chained = R.rc == 0;
         return R.rc;
     }
@@ -1057,10 +1176,11 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     if (!ssp) {
         if (first) R.reset_state();
         const float* lq = R.lr_to_q4(lr, 1, 0);
-        if (!first) R.fnet(1, lq, 0, R.lr_to_q4(lr_prev, 1, 1), 0);
+        if (!first) R.fnet(1, lq, 0, R.lr_to_q4(lr_prev, 1, 1), 0, R.F(L.flow_lr));
         R.encode_lr(1, lq, 0);
-        R.frame_pre(0, first != 0, lr, fv, mk, first ? nullptr : R.F(L.flow_lr), R.F(L.x_lr));
-        R.frame(0, first != 0, lr, mk, out, fg);
+        io.flow_lr = first ? nullptr : R.F(L.flow_lr);
+        R.frame_pre(0, first != 0, io);
+        R.frame(0, first != 0, io, fg);
         return R.rc;
     }
     // two streams: FNet (one pair, small launch-latency-bound kernels, 0.45 ms) and the flow up-samplings stay on the
@@ -1078,21 +1198,22 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     const float* lq = R.lr_to_q4(lr, 1, 0);   // before the fork: read on both streams
     const float* lqp = R.lr_to_q4(lr_prev, 1, 1);
     if (hipEventRecord(ev_start, main_s) != hipSuccess) return fail("record");
-    R.fnet(1, lq, 0, lqp, 0);
-    R.frame_pre(0, false, lr, fv, mk, R.F(L.flow_lr), R.F(L.x_lr), nullptr, 2);
+    R.fnet(1, lq, 0, lqp, 0, R.F(L.flow_lr));
+    io.flow_lr = R.F(L.flow_lr);
+    R.frame_pre(0, false, io, nullptr, 2);
     R.s = ss.s;
     if (hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
     forked = true;
     R.encode_lr(1, lq, 0);
-    R.frame_pre(0, false, lr, fv, mk, nullptr, R.F(L.x_lr), nullptr, 1);
+    R.frame_pre(0, false, io, nullptr, 1);
     // downsample(state) needs nothing of this call: it runs here, beside FNet's small kernels, instead of in front of the recurrent chain
     // (same box, 24 calls: bf16 27.74 -> 27.40 ms, fp32 45.81 -> 45.23 ms, same bits; profiles/r03_stream_down_side_ab.txt)
-    R.mfma(IT_DOWN, 1, 2 * h, 2 * w, {{R.F(L.state_hr), 0, 1}}, {{R.F(L.prev2), 0, 0, 8, 1}});
+    R.downsample_state();
     R.down_done = true;
     if (hipEventRecord(ev_side, ss.s) != hipSuccess) return fail("record");
     R.s = main_s;
     if (hipStreamWaitEvent(main_s, ev_side, 0) != hipSuccess) return fail("join");
-    R.frame(0, false, lr, mk, out, fg);
+    R.frame(0, false, io, fg);
     return R.rc;
 }
 
@@ -1107,20 +1228,27 @@ int crfp_shutdown(void) {
 
 int CRFP_API(crfp_fnet_forward)(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
                       void* workspace, size_t workspace_bytes, void* stream) {
-    Layout L(n + 1, h, w);
-    int rc = check_common(packed, n + 1, h, w, workspace, workspace_bytes, L);
+    if (n < 1) { set_error("fnet_forward: n = %d", n); return CRFP_E_BADARG; }
+    Layout L(1, n + 1, h, w);
+    int rc = check_common(packed, 1, n + 1, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     if (!cur || !prev || !flow) { set_error("fnet_forward: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(0), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
-    R.fnet(n, R.lr_to_q4(cur, n, 0), 3LL * h * w, R.lr_to_q4(prev, n, n + 1), 3LL * h * w);
-    if (!R.rc) R.rc = crfp::launch_q4_to_nchw(R.F(L.flow_lr), flow, n, 2, h, w, 0, (hipStream_t)stream);
+    const long long lr_f = 3LL * h * w, lqf = R.lr_frame_floats();
+    const float* cq = R.lr_to_q4(cur, n, 0);
+    const float* pq = R.lr_to_q4(prev, n, n + 1);
+    for (int p0 = 0; p0 < n && !R.rc; p0 += L.fnet_cap) {   // the workspace holds fnet_cap pairs at a time
+        const int cnt = n - p0 < L.fnet_cap ? n - p0 : L.fnet_cap;
+        R.fnet(cnt, cq + p0 * lqf, lr_f, pq + p0 * lqf, lr_f, R.F(L.flow_lr));
+        if (!R.rc) R.rc = crfp::launch_q4_to_nchw(R.F(L.flow_lr), flow + (long long)p0 * 2 * h * w, cnt, 2, h, w, 0, (hipStream_t)stream);
+    }
     return R.rc;
 }
 
 int CRFP_API(crfp_dsv_debug_fetch)(const char* name, int t, int h, int w, const void* workspace, float* out_nchw, int* c_out,
                          int* h_out, int* w_out, void* stream) {
     if (!name || !workspace) return CRFP_E_BADARG;
-    Layout L(t, h, w);
+    Layout L(1, t, h, w);
     for (auto& b : L.A.bufs)
         if (b.name == name) {
             const float* p = reinterpret_cast<const float*>((const char*)workspace + b.off);

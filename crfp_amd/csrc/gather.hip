@@ -195,10 +195,12 @@ __device__ __forceinline__ void warp_quads(__amdgpu_buffer_rsrc_t r, int voff, i
 template <int NQA, int NQB, int NW>
 __global__ __launch_bounds__(64 * NW) void flow_warp_p4_dual_kernel(const float* __restrict__ xa, const float* __restrict__ xb_,
                                                                     const float* __restrict__ flow, float* __restrict__ outa,
-                                                                    float* __restrict__ outb, int H, int W) {
+                                                                    float* __restrict__ outb, int H, int W, const WarpDualStrides bs) {
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * NW + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
+    const long long n = blockIdx.z;   // batch item: strides in elements of each tensor's own type
+    flow += n * bs.flow;
     const long long pix = (long long)py * W + px;
     const float2 f = ldnt2(flow + pix * 2);
     const float dw = (float)(W - 1 > 1 ? W - 1 : 1), dh = (float)(H - 1 > 1 ? H - 1 : 1);
@@ -215,30 +217,30 @@ __global__ __launch_bounds__(64 * NW) void flow_warp_p4_dual_kernel(const float*
     const int guard = pitch + QB;   // see flow_warp_p4_kernel
     const int voff = ((int)fy * PW + (int)fx) * QB + guard;
     const long long oplane = (long long)H * W * 4;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((char*)const_cast<act_t*>(as_act(xa)) - guard, 0,
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((char*)const_cast<act_t*>(as_act(xa) + n * bs.xa) - guard, 0,
                                                                         NQA * plane_b + guard, 0x00020000);
-    warp_quads<NQA>(ra, voff, pitch, plane_b, w00, w01, w10, w11, as_act(outa) + pix * 4, oplane);
+    warp_quads<NQA>(ra, voff, pitch, plane_b, w00, w01, w10, w11, as_act(outa) + n * bs.outa + pix * 4, oplane);
     if (NQB > 0) {
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((char*)const_cast<act_t*>(as_act(xb_)) - guard, 0,
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((char*)const_cast<act_t*>(as_act(xb_) + n * bs.xb) - guard, 0,
                                                                             NQB * plane_b + guard, 0x00020000);
-        warp_quads<NQB>(rb, voff, pitch, plane_b, w00, w01, w10, w11, as_act(outb) + pix * 4, oplane);
+        warp_quads<NQB>(rb, voff, pitch, plane_b, w00, w01, w10, w11, as_act(outb) + n * bs.outb + pix * 4, oplane);
     }
 }
 
 // prev2 (8 quads) + carry (6 quads) by flow2, one launch; zeros padding, P4 sources
 int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* flow, float* outa, float* outb, int H, int W,
-                                 hipStream_t s) {
-    const double px = (double)H * W;
+                                 hipStream_t s, int N, const WarpDualStrides& bs) {
+    const double px = (double)N * H * W;
     ProfScope prof("flow_warp_q4_c32+c24", s, px * (2.0 * 14 * 4 * sizeof(act_t) + 8), px * 14 * 4 * 7.0);
 #ifdef CRFP_LAB
     static const int nw8 = getenv("CRFP_WARP_NW") && atoi(getenv("CRFP_WARP_NW")) == 8;
     if (nw8) {   // 8-row tiles (window 1.14x instead of 1.27x the tile): 26.5 vs 26.0-26.4 us same box @A -- not the traffic
-        flow_warp_p4_dual_kernel<8, 6, 8><<<dim3((W + 63) / 64, (H + 7) / 8, 1), 512, 0, s>>>(xa, xb, flow, outa, outb, H, W);
+        flow_warp_p4_dual_kernel<8, 6, 8><<<dim3((W + 63) / 64, (H + 7) / 8, N), 512, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
         CRFP_CHECK_LAUNCH();
         return 0;
     }
 #endif
-    flow_warp_p4_dual_kernel<8, 6, 4><<<dim3((W + 63) / 64, (H + 3) / 4, 1), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W);
+    flow_warp_p4_dual_kernel<8, 6, 4><<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1723,7 +1725,7 @@ __global__ __launch_bounds__(256) DCN3_WPE_ATTR void dcn3_kernel(const float* __
                                                    const float* __restrict__ w, const float* __restrict__ bias,
                                                    float* __restrict__ out, long long ob, int H, int W,
                                                    const float* __restrict__ flow, const float* __restrict__ wom,
-                                                   const float* __restrict__ bom) {
+                                                   const float* __restrict__ bom, long long fb) {
     constexpr int TR = 4 * NT;                       // rows of the strip
     __shared__ f32x4 wmix[36];                       // dcn weight: [tap][cout] -> float4 over the 4 input channels
     __shared__ f32x4 gt[FUSE ? TR + 2 : 1][66];      // FUSE: halo tile of the offset feature
@@ -1749,7 +1751,7 @@ __global__ __launch_bounds__(256) DCN3_WPE_ATTR void dcn3_kernel(const float* __
     for (int k = 0; k < NT; ++k) {
         const int cpy = min(by0 + 4 * k + ty, H - 1);
         const long long pix = (long long)cpy * W + cpx;
-        if constexpr (FUSE) fl[k] = ldnt2(flow + pix * 2);
+        if constexpr (FUSE) fl[k] = ldnt2(flow + (long long)n * fb + pix * 2);
         else omq[k] = ldg4(offmask3 + (long long)n * omb + pix * 4);   // read once: non-temporal
     }
     if constexpr (FUSE) {
@@ -1871,20 +1873,20 @@ int launch_dcn3(const float* x, long long xb, const float* offmask3, long long o
     ProfScope prof("dcnv2_shared_c4", s, px * ((4 + 4) * sizeof(act_t) + (2 + 1) * 4.0), px * (2.0 * 4 * 4 * 9 + 36 * 7));
 #ifdef CRFP_LAB
     if (dcn3_nt_env() == 1) {
-        dcn3_kernel<false, 1><<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W, nullptr, nullptr, nullptr);
+        dcn3_kernel<false, 1><<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W, nullptr, nullptr, nullptr, 0);
         CRFP_CHECK_LAUNCH();
         return 0;
     }
 #endif
     dim3 grid((W + 63) / 64, (H + 4 * DCN3_NT - 1) / (4 * DCN3_NT), N);
-    dcn3_kernel<false, DCN3_NT><<<grid, 256, 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W, nullptr, nullptr, nullptr);
+    dcn3_kernel<false, DCN3_NT><<<grid, 256, 0, s>>>(x, xb, offmask3, omb, w, bias, out, ob, H, W, nullptr, nullptr, nullptr, 0);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
 
 // dcn_3 with its offset / mask conv inside: g2 = the conv's input (one Q4 quad), wom / bom = its narrow-packed weights and bias
 int launch_dcn3_fused(const float* x, long long xb, const float* g2, long long gb, const float* flow, const float* wom, const float* bom,
-                      const float* w, const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s) {
+                      const float* w, const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, long long fb) {
 #ifdef CRFP_LAB
     static const bool r2 = getenv("CRFP_DCN3_R2") && atoi(getenv("CRFP_DCN3_R2"));
     if (r2) return launch_dcn3_fused_r2(x, xb, g2, gb, flow, wom, bom, w, bias, out, ob, N, H, W, s);
@@ -1894,15 +1896,15 @@ int launch_dcn3_fused(const float* x, long long xb, const float* g2, long long g
 #ifdef CRFP_LAB
     if (dcn3_nt_env() != DCN3_NT) {
         const int nt = dcn3_nt_env();
-        if (nt == 1) dcn3_kernel<true, 1><<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, flow, wom, bom);
-        else if (nt == 2) dcn3_kernel<true, 2><<<dim3((W + 63) / 64, (H + 7) / 8, N), 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, flow, wom, bom);
-        else dcn3_kernel<true, 6><<<dim3((W + 63) / 64, (H + 23) / 24, N), 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, flow, wom, bom);
+        if (nt == 1) dcn3_kernel<true, 1><<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, flow, wom, bom, fb);
+        else if (nt == 2) dcn3_kernel<true, 2><<<dim3((W + 63) / 64, (H + 7) / 8, N), 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, flow, wom, bom, fb);
+        else dcn3_kernel<true, 6><<<dim3((W + 63) / 64, (H + 23) / 24, N), 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, flow, wom, bom, fb);
         CRFP_CHECK_LAUNCH();
         return 0;
     }
 #endif
     dim3 grid((W + 63) / 64, (H + 4 * DCN3_NT - 1) / (4 * DCN3_NT), N);
-    dcn3_kernel<true, DCN3_NT><<<grid, 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, flow, wom, bom);
+    dcn3_kernel<true, DCN3_NT><<<grid, 256, 0, s>>>(x, xb, g2, gb, w, bias, out, ob, H, W, flow, wom, bom, fb);
     CRFP_CHECK_LAUNCH();
     return 0;
 }

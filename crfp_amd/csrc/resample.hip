@@ -236,8 +236,11 @@ int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, i
 //   quad 0 = (mk ? fv : up8(lr)) rgb, 0     (fvs*mk + lrs_lv3*(1-mk) with mk in {0,1} is a select)
 //   quad 1 = up8(lr) rgb, 0                 (also the base of the output head)
 __global__ void hr_prep_kernel(const float* __restrict__ lr, const float* __restrict__ fv,
-                               const uint8_t* __restrict__ mk, act_t* __restrict__ out, int h, int w) {
+                               const uint8_t* __restrict__ mk, act_t* __restrict__ out, int h, int w, long long lr_b,
+                               long long fv_b, long long mk_b, long long out_b) {
     const int OH = 8 * h, OW = 8 * w;
+    const long long n = blockIdx.z;
+    lr += n * lr_b; fv += n * fv_b; mk += n * mk_b; out += n * out_b;
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= OW || oy >= OH) return;
@@ -259,10 +262,11 @@ __global__ void hr_prep_kernel(const float* __restrict__ lr, const float* __rest
     stq(out + (plane + pix) * 4, cf32x4{u[0], u[1], u[2], 0.0f});
 }
 
-int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s) {
-    ProfScope prof("hr_prep_up8_blend", s, (double)64 * h * w * (12 + 1 + 32.0), 0);
-    dim3 grid((8 * w + 63) / 64, (8 * h + 3) / 4, 1);
-    hr_prep_kernel<<<grid, 256, 0, s>>>(lr, fv, mk, as_act(out_q4), h, w);
+int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s, int N, long long lr_b,
+                   long long fv_b, long long mk_b, long long out_b) {
+    ProfScope prof("hr_prep_up8_blend", s, (double)N * 64 * h * w * (12 + 1 + 32.0), 0);
+    dim3 grid((8 * w + 63) / 64, (8 * h + 3) / 4, N);
+    hr_prep_kernel<<<grid, 256, 0, s>>>(lr, fv, mk, as_act(out_q4), h, w, lr_b, fv_b, mk_b, out_b);
     CRFP_CHECK_LAUNCH();
     return 0;
 }

@@ -42,6 +42,9 @@ class DSVEngine:
         # device; NOT true when an earlier kernel or copy on the same stream is still producing them).  The library then keeps the previous
         # frame itself and runs the state-independent part of each frame beside the previous frame's recurrent chain.  Same bits.
         self.inputs_resident = False
+        # forward() on n > 1 clips: "lockstep" (default) = ONE crfp_dsv_forward_batch call, every layer launched once over all n clips;
+        # "loop" = n one-clip calls in turn (rounds 1-3; what "lockstep" is bit-identical to, clip by clip)
+        self.batch_mode = "lockstep"
         self._ws = {}
         self._ovf = None             # int32[1] on the device: status words of the last forward()'s clips, OR-ed (no host sync)
         self._stream_ws = None
@@ -85,14 +88,14 @@ class DSVEngine:
                        "crfp_dsv_pack_weights")
             torch.cuda.current_stream().synchronize()   # `keep` may be freed after this point
 
-    def _workspace(self, t, h, w):
-        key = (t, h, w)
+    def _workspace(self, t, h, w, n=1):
+        key = (n, t, h, w)
         if key not in self._ws:
-            nb = self._fn("crfp_dsv_workspace_bytes")(t, h, w)
+            nb = self._fn("crfp_dsv_batch_workspace_bytes")(n, t, h, w)
             if nb == 0:
-                raise ValueError(f"unsupported clip shape t={t} h={h} w={w}")
+                raise ValueError(f"unsupported clip shape n={n} t={t} h={h} w={w}")
             ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
-            off = self._fn("crfp_dsv_status_offset")(t, h, w)
+            off = self._fn("crfp_dsv_batch_status_offset")(n, t, h, w)
             ws[off:off + 256].zero_()   # a fresh workspace starts with a clear status word (crfp_fnet_forward never writes it)
             self._ws = {key: ws}        # keep one shape alive
         return self._ws[key]
@@ -115,8 +118,8 @@ class DSVEngine:
                              "(CRFP_DSV_STRICT_F32)")
         return self.y_only | (_lib.DSV_STRICT_F32 if strict else 0) | (_lib.DSV_SINGLE_STREAM if self.single_stream else 0)
 
-    def _status(self, ws, t, h, w) -> int:
-        off = self._fn("crfp_dsv_status_offset")(t, h, w)
+    def _status(self, ws, t, h, w, n=1) -> int:
+        off = self._fn("crfp_dsv_batch_status_offset")(n, t, h, w)
         return int(ws[off:off + 4].view(torch.int32).item())   # synchronises
 
     def overflowed(self, stream: bool = False) -> bool:
@@ -146,23 +149,32 @@ class DSVEngine:
         n, t, c, h, w = lrs.shape
         assert c == 3 and tuple(fvs.shape) == (n, t, 3, 8 * h, 8 * w) and tuple(mk8.shape) == (n, t, 1, 8 * h, 8 * w)
         out = torch.empty((n, t, 1 if self.y_only else 3, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
-        ws = self._workspace(t, h, w)
-        L = _lib.lib()
+        if self.batch_mode not in ("lockstep", "loop"):
+            raise ValueError(f"batch_mode {self.batch_mode!r}")
+        lock = n > 1 and self.batch_mode == "lockstep"
+        nb = n if lock else 1
+        ws = self._workspace(t, h, w, nb)
 
         def run(b, strict=None):
-            _lib.check(self._fn("crfp_dsv_forward_clip")(self.packed.data_ptr(), self._flags(strict), lrs[b].data_ptr(),
-                                               fvs[b].data_ptr(), mk8[b].data_ptr(), out[b].data_ptr(), t, h, w,
-                                               ws.data_ptr(), ws.numel(), _stream()), "crfp_dsv_forward_clip")
+            if lock:   # all n clips in one call: lrs / fvs / mks / out are the reference's [n, t, ...] tensors as they lie
+                _lib.check(self._fn("crfp_dsv_forward_batch")(self.packed.data_ptr(), self._flags(strict), lrs.data_ptr(), fvs.data_ptr(),
+                                                              mk8.data_ptr(), out.data_ptr(), n, t, h, w, ws.data_ptr(), ws.numel(),
+                                                              _stream()), "crfp_dsv_forward_batch")
+            else:
+                _lib.check(self._fn("crfp_dsv_forward_clip")(self.packed.data_ptr(), self._flags(strict), lrs[b].data_ptr(),
+                                                             fvs[b].data_ptr(), mk8[b].data_ptr(), out[b].data_ptr(), t, h, w,
+                                                             ws.data_ptr(), ws.numel(), _stream()), "crfp_dsv_forward_clip")
 
-        off = self._fn("crfp_dsv_status_offset")(t, h, w)
+        off = self._fn("crfp_dsv_batch_status_offset")(nb, t, h, w)
         word = ws[off:off + 4].view(torch.int32)
         with torch.cuda.device(self.device):
             if self._ovf is None:
                 self._ovf = torch.zeros(1, dtype=torch.int32, device=self.device)
-            for b in range(n):
+            for b in range(1 if lock else n):
                 run(b)
-                self._after(ws, (t, h, w), lambda b=b: run(b, strict=True))
-                # every clip resets the workspace's status word: keep the OR over the batch (stream-ordered, no host sync)
+                # "fallback" under lockstep reruns the whole batch in strict fp32: the status word is shared by its clips
+                self._after(ws, (t, h, w, nb), lambda b=b: run(b, strict=True))
+                # every call resets the workspace's status word: keep the OR over the batch (stream-ordered, no host sync)
                 self._ovf.copy_(word) if b == 0 else self._ovf.bitwise_or_(word)
         return out
 
@@ -202,7 +214,7 @@ class DSVEngine:
                 None if fg8 is None else fg8.data_ptr(), out.data_ptr(),
                 1 if first else 0, h, w, self._stream_ws.data_ptr(), self._stream_ws.numel(), _stream()),
                 "crfp_dsv_stream_frame")
-        self._after(self._stream_ws, (1, h, w), None)
+        self._after(self._stream_ws, (1, h, w, 1), None)
         # the reference keeps a COPY of the frame (model/CRFP_test.py:2234-2238, ``.clone()``): a caller that refills one
         # input buffer in place must not change what the next call sees as the previous frame
         if resident:            # the library kept the frame inside the workspace

@@ -200,9 +200,23 @@ size_t crfp_dsv_workspace_bytes(int t, int h, int w);
 size_t crfp_dsv_status_offset(int t, int h, int w);
 
 /* One clip: lrs[t,3,h,w], fvs[t,3,8h,8w] f32, mks[t,1,8h,8w] u8 (bool), out[t,3|1,8h,8w].
- * Zero initial state; flows from FNet(frame i, frame i-1).  Batches of clips: call once per clip. */
+ * Zero initial state; flows from FNet(frame i, frame i-1).  (= crfp_dsv_forward_batch with n = 1.) */
 int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                           float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+
+/* A batch of n independent clips, the reference's own tensor shapes (model/CRFP.py:1510-1535: forward(lrs, fvs, mks) carries the
+ * batch axis n through every op; main.py:37-38 scatters batches): lrs[n,t,3,h,w], fvs[n,t,3,8h,8w], mks[n,t,1,8h,8w] u8,
+ * out[n,t,3|1,8h,8w].  The n clips walk the recurrent chain in lock-step -- ONE launch per layer and frame step over all n clips --
+ * so a 2x-resolution map that is a single round of workgroups for one clip becomes n rounds whose load / MFMA / store phases
+ * overlap.  Per clip the arithmetic is that of crfp_dsv_forward_clip: outputs are bit-identical to n one-clip calls.  The workspace
+ * holds n recurrent states (query crfp_dsv_batch_workspace_bytes); the status word is shared: an fp16-operand overflow in ANY clip
+ * poisons every output frame of the call (rerun with CRFP_DSV_STRICT_F32, or clip by clip to find it).  The clip-level stages
+ * (FNet, encoder_lr) run once over all n * t frames when n * t <= 32 and in chunks of 8 frames per clip otherwise, so the
+ * workspace does not grow with t. */
+size_t crfp_dsv_batch_workspace_bytes(int n, int t, int h, int w);
+size_t crfp_dsv_batch_status_offset(int n, int t, int h, int w);
+int crfp_dsv_forward_batch(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                           float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Streaming: one frame per call, recurrent state kept inside `workspace` (same buffer every call).
  * `first` != 0 resets the state (clear_states of the reference's streaming model). lr_prev may be
@@ -226,6 +240,10 @@ size_t crfp_dsv_workspace_bytes_bf16(int t, int h, int w);
 size_t crfp_dsv_status_offset_bf16(int t, int h, int w);
 int crfp_dsv_forward_clip_bf16(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                                float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+size_t crfp_dsv_batch_workspace_bytes_bf16(int n, int t, int h, int w);
+size_t crfp_dsv_batch_status_offset_bf16(int n, int t, int h, int w);
+int crfp_dsv_forward_batch_bf16(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                                float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 int crfp_dsv_stream_frame_bf16(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
                                const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
                                size_t workspace_bytes, void* stream);

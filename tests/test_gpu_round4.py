@@ -1,0 +1,157 @@
+"""GPU (-m gpu), round 4: n clips in lock-step inside the library (crfp_dsv_forward_batch, the reference's own batch axis,
+model/CRFP.py:1510-1535) -- bit-identical, clip by clip, to n one-clip calls in both storage modes and both schedules -- and the
+chunked clip-level stages of long clips (workspace independent of t)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import crfp_oracle
+    return crfp_oracle
+
+
+@pytest.fixture(autouse=True)
+def _nograd():
+    with torch.no_grad():
+        yield
+
+
+def _batch(seeds, t, h, w, fv):
+    from crfp_amd import synth
+    clips = [synth.make_clip(s, 1, t, h, w, fv_size=fv) for s in seeds]
+    return tuple(T(np.concatenate([c[k] for c in clips], axis=0)).to(dev()) for k in range(3))
+
+
+def _engine(storage="f32", y_only=False, seed=7):
+    from crfp_amd import synth
+    from crfp_amd.engine import DSVEngine
+    sd = synth.make_state_dict(seed, y_only=y_only)
+    return DSVEngine({k: T(v.copy()) for k, v in sd.items()}, dev(), y_only=y_only, storage=storage), sd
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("n,t,h,w", [(3, 4, 24, 40), (4, 3, 36, 64), (2, 5, 27, 45)])
+def test_lockstep_batch_is_bit_identical_to_one_clip_calls(storage, n, t, h, w):
+    """crfp_dsv_forward_batch (one launch per layer over all n clips) against n crfp_dsv_forward_clip calls: same bits per clip,
+    on the two-stream and on the single-stream schedule; odd sizes exercise ragged tiles and the P4 guard between batch items."""
+    eng, _ = _engine(storage)
+    lrs, fvs, mks = _batch(range(40, 40 + n), t, h, w, 64)
+    eng.batch_mode = "loop"
+    ref = eng.forward(lrs, fvs, mks).clone()
+    for single in (False, True):
+        eng.single_stream = single
+        eng.batch_mode = "lockstep"
+        got = eng.forward(lrs, fvs, mks).clone()
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, ref), f"lockstep != loop (single_stream={single}): max diff {float((got - ref).abs().max()):.3e}"
+    # a second call on the same workspace (stale state of the previous batch must not leak)
+    again = eng.forward(lrs, fvs, mks)
+    assert torch.equal(again, ref)
+    assert not eng.overflowed()
+
+
+def test_lockstep_batch_matches_the_oracle(orc):
+    """The batch path against the oracle itself (not only against our own one-clip path): 2 clips x 3 frames, fp32."""
+    eng, sd = _engine("f32")
+    lrs, fvs, mks = _batch((51, 52), 3, 24, 40, 64)
+    got = eng.forward(lrs, fvs, mks).cpu()
+    P = orc.load_numpy_state(sd)
+    ref = orc.crfp_dsv_forward(P, lrs.cpu(), fvs.cpu(), mks.cpu())
+    d = float((got - ref).abs().max())
+    assert d < 2e-4, d
+
+
+def test_lockstep_batch_y_only():
+    eng, _ = _engine("f32", y_only=True)
+    lrs, fvs, mks = _batch((61, 62, 63), 3, 24, 40, 64)
+    eng.batch_mode = "loop"
+    ref = eng.forward(lrs, fvs, mks).clone()
+    eng.batch_mode = "lockstep"
+    got = eng.forward(lrs, fvs, mks)
+    assert got.shape == (3, 3, 1, 192, 320) and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_long_clips_run_in_chunks_with_the_same_bits(storage):
+    """n * t > 32 frames: FNet / encoder_lr walk every clip in chunks of 8 frames (Layout::flat == false).  A 2 x 20 batch
+    (chunked, per-clip passes) must equal the two 20-frame one-clip calls (flat: one pass over all frames), and a 35-frame
+    single clip (chunked) the concatenation property of a causal recurrence: its first 20 frames are the 20-frame clip's."""
+    eng, _ = _engine(storage)
+    lrs, fvs, mks = _batch((71, 72), 20, 16, 24, 48)
+    eng.batch_mode = "loop"
+    ref = eng.forward(lrs, fvs, mks).clone()
+    for single in (False, True):
+        eng.single_stream = single
+        eng.batch_mode = "lockstep"
+        got = eng.forward(lrs, fvs, mks)
+        assert torch.equal(got, ref), f"chunked batch != flat clips (single_stream={single})"
+    eng.single_stream = False
+    l35, f35, m35 = _batch((71,), 35, 16, 24, 48)
+    assert torch.equal(l35[:, :20], lrs[:1])   # synth clips are prefix-stable in t
+    got35 = eng.forward(l35, f35, m35)
+    assert torch.isfinite(got35).all()
+    assert torch.equal(got35[:, :20], ref[:1]), "35-frame chunked clip: first 20 frames differ from the 20-frame clip"
+
+
+def test_long_clip_chunked_vs_oracle(orc):
+    """The chunked schedule against the oracle: 34 frames (5 chunks, the last one ragged) at 16 x 24."""
+    eng, sd = _engine("f32")
+    lrs, fvs, mks = _batch((81,), 34, 16, 24, 48)
+    got = eng.forward(lrs, fvs, mks).cpu()
+    ref = orc.crfp_dsv_forward(orc.load_numpy_state(sd), lrs.cpu(), fvs.cpu(), mks.cpu())
+    d = float((got - ref).abs().max())
+    assert d < 2e-4, d
+
+
+def test_workspace_does_not_grow_with_t():
+    """11.2 GB at t = 100 -> bounded (the clip-level stages hold 8 frames per clip beyond 32 frames)."""
+    from crfp_amd import _lib
+    L = _lib.lib()
+    w7, w100, w1000 = (L.crfp_dsv_workspace_bytes(t, 180, 320) for t in (7, 100, 1000))
+    assert w100 <= 3 * 2 ** 30, w100
+    # what still scales with t is the Q4 copy of the LR frames (0.9 MB per frame)
+    assert w1000 - w100 < 900 * 2 * 180 * 320 * 16 + 2 ** 20
+    assert L.crfp_dsv_batch_workspace_bytes(1, 7, 180, 320) == w7
+    assert L.crfp_dsv_batch_workspace_bytes(4, 7, 180, 320) < 4.2 * w7   # + the 3 never-read pairs that straddle clips in the flat FNet pass
+
+
+def test_fnet_forward_more_pairs_than_one_pass():
+    """crfp_fnet_forward with more pairs than the workspace's FNet capacity walks them in passes: same flows as pair by pair."""
+    eng, _ = _engine("f32")
+    g = torch.Generator().manual_seed(5)
+    cur = torch.rand(40, 3, 16, 24, generator=g).to(dev())
+    prev = torch.rand(40, 3, 16, 24, generator=g).to(dev())
+    all_ = eng.compute_flow(cur, prev).clone()
+    for i in (0, 7, 8, 31, 39):
+        one = eng.compute_flow(cur[i:i + 1], prev[i:i + 1])
+        assert torch.equal(one[0], all_[i]), i
+
+
+def test_batch_overflow_poisons_the_whole_call_and_is_reported():
+    """The status word is shared by the clips of a lock-step call: an fp16-operand overflow in one clip turns every frame of the
+    call into NaN (never a finite wrong frame) and overflowed() says why."""
+    eng, _ = _engine("f32")
+    lrs, fvs, mks = _batch((91, 92), 3, 24, 40, 64)
+    lrs = lrs.clone()
+    lrs[1] *= 1e6
+    out = eng.forward(lrs, fvs * 1.0, mks)
+    assert eng.overflowed()
+    assert torch.isnan(out).all()
+    eng.on_overflow = "fallback"
+    out2 = eng.forward(lrs, fvs, mks)
+    assert torch.isfinite(out2[0]).all()
