@@ -33,3 +33,27 @@ def aggregate(world: int, steps: int, frames_per_step_per_gpu: int, elapsed: flo
     return {"value": world * steps * frames_per_step_per_gpu / elapsed,
             "per_gpu_frames_per_sec": steps * frames_per_step_per_gpu / elapsed,
             "ms_per_step": 1e3 * elapsed / steps}
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config")
+
+
+def contract_line(agg: dict, world: int, steps: int, warmup: int, storage: str, config: dict, dist=None) -> dict:
+    """The driver-contract part of bench.py's JSON line, identical for N = 1 and N > 1 (rank 0 adds roofline / cpu_baseline /
+    psnr_reduce on top at every world size)."""
+    return {
+        "metric": "sr_frames_per_sec", "value": agg["value"], "unit": "frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": agg["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if storage == "f32" else "bf16",
+        "data": "synthetic", "config": config,
+        "per_gpu_frames_per_sec": agg["per_gpu_frames_per_sec"],
+        "collectives": {"backend": dist.get_backend() if dist is not None else None, "initialised": dist is not None,
+                        "world_size": dist.get_world_size() if dist is not None else 1,
+                        "ops": ["barrier", "all_reduce(MAX) of the step time", "all_reduce(SUM) of the PSNR sums"]},
+    }
+
+
+def psnr_reduce_record(vec, world: int) -> dict:
+    """What the one data-path-free collective produced: SUMs over all ranks; `frames` = frames per step over the whole job."""
+    return {"sum_sq_err": float(vec[0]), "sum_sq_err_y": float(vec[1]), "frames": float(vec[2]), "ranks": world}

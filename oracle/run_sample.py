@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--clip-seed", type=int, default=1234)
     ap.add_argument("--clip-frames", type=int, default=7)
     ap.add_argument("--weights-seed", type=int, default=7)
+    ap.add_argument("--offset-std", type=float, default=None, help="synth.make_state_dict(offset_std=): 0.02 = SURVEY 8(d)'s N(0, 0.02) DCN heads")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--storage", choices=("f32", "bf16"), default="f32", help="bf16: the storage-rounding twin")
     ap.add_argument("--warmup", type=int, default=0, help="untimed passes before the timed one (BASELINE.md section 4: 1)")
@@ -45,7 +46,7 @@ def main():
     # every usable CPU (affinity / cgroup quota); beyond ~64 threads the small 180x320 convs stop scaling
     threads = a.threads or min(64, usable_cpus())
     torch.set_num_threads(threads)
-    sd = synth.make_state_dict(a.weights_seed)
+    sd = synth.make_state_dict(a.weights_seed, offset_std=a.offset_std)
     lrs, fvs, mks = synth.make_clip(a.clip_seed, 1, a.clip_frames, a.h, a.w, fv_size=a.fv_size, sigma_t=a.sigma_t)
     P = orc.load_numpy_state(sd)
     T = torch.from_numpy

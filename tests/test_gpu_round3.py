@@ -116,7 +116,8 @@ def test_bench_config4_under_torchrun_initialises_rccl_with_one_rank():
     j = json.loads(line)
     assert j["collectives"]["backend"] == "nccl" and j["collectives"]["initialised"] and j["collectives"]["world_size"] == 1
     assert j["n_gpus"] == 1 and j["dtype"] == "bf16" and j["config"]["clips_per_gpu_per_step"] == 4
-    assert j["config"]["clips_in_flight_per_gpu"] == 2 and j["value"] > 0
+    # round 4: the 4 clips of a rank go through ONE crfp_dsv_forward_batch call (lock-step), no longer two one-clip calls in flight
+    assert j["config"]["clips_per_call"] == 4 and j["config"]["calls_in_flight_per_gpu"] == 1 and j["value"] > 0
     assert j["psnr_reduce"]["ranks"] == 1 and j["psnr_reduce"]["frames"] == 28.0 and np.isfinite(j["psnr_reduce"]["sum_sq_err"])
 
 

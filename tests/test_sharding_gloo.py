@@ -2,6 +2,7 @@
 all-reduce of metric sums).  The per-clip compute is stubbed with a deterministic function of the
 clip index because the real compute is GPU-only; what is under test is that every clip is
 processed exactly once and that the reduced means equal the single-process result."""
+import json
 import os
 import socket
 import sys
@@ -73,12 +74,16 @@ def bench_worker(rank, world, port, q):
     seeds = benchutil.rank_clip_seeds(rank, clips)
     elapsed = benchutil.reduce_elapsed(0.10 + 0.03 * rank, dist)            # the slower rank defines the step
     vec = benchutil.reduce_sums(torch.tensor([100.0 + rank, 10.0 * (rank + 1), float(t * clips)], dtype=torch.float64), dist)
-    q.put((rank, seeds, elapsed, vec.tolist(), benchutil.aggregate(world, steps, t * clips, elapsed)))
+    agg = benchutil.aggregate(world, steps, t * clips, elapsed)
+    line = benchutil.contract_line(agg, world, steps, 2, "bf16", {"workload": "stub", "clips_per_gpu_per_step": clips}, dist)
+    line["psnr_reduce"] = benchutil.psnr_reduce_record(vec, world)
+    q.put((rank, seeds, elapsed, vec.tolist(), agg, line))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_bench_reduction_path_two_ranks():
+    from crfp_amd import benchutil
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -92,7 +97,12 @@ def test_bench_reduction_path_two_ranks():
         assert p.exitcode == 0
     all_seeds = sum((g[1] for g in got), [])
     assert len(set(all_seeds)) == 8 and all_seeds == list(range(1234, 1242))      # 2 ranks x 4 clips, all distinct
-    for _, _, elapsed, vec, agg in got:
+    for _, _, elapsed, vec, agg, line in got:
+        # the JSON line an N > 1 run prints: the driver's contract keys, whole-job value, RCCL's N visible
+        assert all(k in line for k in benchutil.CONTRACT_KEYS) and json.dumps(line)
+        assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] == agg["value"] and line["dtype"] == "bf16"
+        assert line["collectives"] == {"backend": "gloo", "initialised": True, "world_size": 2, "ops": line["collectives"]["ops"]}
+        assert line["psnr_reduce"]["ranks"] == 2 and line["psnr_reduce"]["frames"] == 56.0
         assert abs(elapsed - 0.13) < 1e-12                                          # MAX over ranks
         assert vec == [201.0, 30.0, 56.0]                                           # SUM over ranks
         assert abs(agg["value"] - 2 * 5 * 28 / 0.13) < 1e-9 and abs(agg["per_gpu_frames_per_sec"] - 5 * 28 / 0.13) < 1e-9
