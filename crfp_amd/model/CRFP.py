@@ -277,9 +277,9 @@ class CRFP_DSV(nn.Module):
 
     def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, spynet_pretrained=None):
         super().__init__()
-        if mid_channels != 32 or not hr_dcn or not offset_prop:
-            raise NotImplementedError("crfp_amd implements the reference's shipped configuration: "
-                                      "mid_channels=32, hr_dcn=True, offset_prop=True (main.py:34, eval.sh)")
+        if mid_channels < 8 or mid_channels % 8:
+            raise ValueError(f"mid_channels = {mid_channels}: the reference's own table needs a multiple of 8 (last_channels = "
+                             "mid_channels // 8, 8 deformable groups; model/CRFP.py:1393-1395)")
         self.device = device
         self.mid_channels, self.last_channels = mid_channels, mid_channels // 8
         self.dg_num, self.dk, self.max_residue_magnitude = 8, 3, 10
@@ -289,17 +289,23 @@ class CRFP_DSV(nn.Module):
         self.spynet = FNet(in_nc=3)
         if spynet_pretrained is not None:
             self.spynet.load_state_dict(torch.load(spynet_pretrained, map_location="cpu"))
+        # the module table of model/CRFP.py:1409-1435 for every flag combination (state_dict keys and shapes pinned against the imported
+        # reference by tests/golden/make_flags_golden.py).  hr_dcn=False swaps dcn_3 / forward_resblocks_3 for mid-channel modules that the
+        # reference's own forward then feeds last_channels-wide tensors -- it raises on the first frame there, and so does this class.
         self.dcn_0 = DCN_module(m, 8, 3, 10)
-        self.dcn_1 = DCN_module(m, 8, 3, 10, pre_offset=True, interpolate='none')
-        self.dcn_2 = DCN_module(m, 8, 3, 10, pre_offset=True, interpolate='none')
-        self.dcn_3 = DCN_module(l, 1, 3, 10, repeat=True, pre_offset=True, interpolate='pixelshuffle')
+        self.dcn_1 = DCN_module(m, 8, 3, 10, pre_offset=offset_prop, interpolate='none')
+        self.dcn_2 = DCN_module(m, 8, 3, 10, pre_offset=offset_prop, interpolate='none')
+        if hr_dcn:
+            self.dcn_3 = DCN_module(l, 1, 3, 10, repeat=True, pre_offset=offset_prop, interpolate='pixelshuffle')
+        else:
+            self.dcn_3 = DCN_module(m, 8, 3, 10, pre_offset=offset_prop, interpolate='none')
         self.encoder_lr = LTE.LTE_simple_lr(m)
         self.encoder_hr = LTE.LTE_simple_hr_single(l)
         self.conv_tttf = conv3x3(l * 2, l)
         self.forward_resblocks_0 = ResidualBlocksWithInputConv(m * 2, m, 1)
         self.forward_resblocks_1 = ResidualBlocksWithInputConv(m * 2, m, 1)
         self.forward_resblocks_2 = ResidualBlocksWithInputConv(m * 2, m, 1)
-        self.forward_resblocks_3 = ResidualBlocksWithInputConv(l * 2, l, 1)
+        self.forward_resblocks_3 = ResidualBlocksWithInputConv(l * 2, l, 1) if hr_dcn else ResidualBlocksWithInputConv(m * 2, m, 1)
         self.downsample = PixelUnShufflePack_v2(l, m, 4, downsample_kernel=3)
         self.upsample = PixelShufflePack(m, (m * self.split_ratio) // 4, 2, upsample_kernel=3)
         self.upsample_post = PixelShufflePack((m * self.split_ratio) // 4, l, 4, upsample_kernel=3)
@@ -333,7 +339,15 @@ class CRFP_DSV(nn.Module):
         writing parameters through ``.data`` (see ``_signature``)."""
         self._engine_sig = None
 
+    def has_engine(self) -> bool:
+        """The one-call C++ schedule (csrc/engine.hip) exists for the configuration the reference ships and evaluates (main.py:34 with
+        eval.sh's flags: mid_channels=32, hr_dcn, offset_prop); every other flag combination runs ``forward_composed``."""
+        return self.mid_channels == 32 and bool(self.hr_dcn) and bool(self.offset_prop)
+
     def engine(self) -> DSVEngine:
+        if not self.has_engine():
+            raise RuntimeError(f"crfp_amd: no one-call engine for mid_channels={self.mid_channels}, hr_dcn={self.hr_dcn}, "
+                               f"offset_prop={self.offset_prop}: this model runs through forward_composed (per-operator HIP calls)")
         dev = next(self.parameters()).device
         sig = self._signature()
         check = os.environ.get("CRFP_CHECK_PACKED") == "1"
@@ -353,11 +367,78 @@ class CRFP_DSV(nn.Module):
         n, t, c, h, w = lrs.shape
         cur = lrs[:, 1:].reshape(-1, c, h, w)
         prev = lrs[:, :-1].reshape(-1, c, h, w)
+        if not self.has_engine():   # FNet has no mid_channels in it: the per-operator composition of the same network
+            return self.spynet(cur.contiguous(), prev.contiguous()).view(n, t - 1, 2, h, w), None
         return self.engine().compute_flow(cur, prev).view(n, t - 1, 2, h, w), None
 
     @torch.no_grad()
     def forward(self, lrs, fvs, mks):
+        if not self.has_engine():
+            return self.forward_composed(lrs, fvs, mks)
         return self.engine().forward(lrs, fvs, mks)
+
+    @torch.no_grad()
+    def forward_composed(self, lrs, fvs, mks):
+        """The recurrence of model/CRFP.py:1510-1686 as a composition of this file's module mirrors -- every convolution, warp, resize and
+        deformable convolution a per-operator HIP call -- for the flag combinations without a one-call engine: any mid_channels (the
+        ctor default is 16), ``offset_prop=False`` and ``hr_dcn=False``.  It inherits the reference's behaviour on the last two exactly:
+        ``offset_prop=False`` builds dcn_1..3 without ``conv_fuse`` while forward() still hands the offset feature down, so clips of more
+        than one frame end in AttributeError (:336); ``hr_dcn=False`` builds 32-channel dcn_3 / forward_resblocks_3 and feeds them
+        last_channels-wide tensors, a channel-count RuntimeError on the first frame (:1668).  Tensors between operators are NCHW torch
+        tensors on the device; concatenations ride as the second input of the consuming conv where the operator has one."""
+        if lrs.dim() != 5 or not lrs.is_cuda:
+            raise RuntimeError("crfp_amd: forward_composed needs CUDA/HIP tensors lrs[n,t,3,h,w], fvs[n,t,3,8h,8w], mks[n,t,1,8h,8w]")
+        n, t, _, h, w = lrs.shape
+        m, l = self.mid_channels, self.last_channels
+        lrs = lrs.float().contiguous()
+        mkf = mks.to(torch.float32)
+        flows, _ = self.compute_flow(lrs) if t > 1 else (None, None)
+        flat = lrs.reshape(n * t, 3, h, w)
+        up8_all = ops.upsample_bilinear(flat, scale_factor=8)                               # :1538
+        x_lr = self.encoder_lr(flat, islr=True)[2].view(n, t, m, h, w)                      # :1540
+        fov = fvs.float() * mkf + up8_all.view(n, t, 3, 8 * h, 8 * w) * (1.0 - mkf)         # :1543-1544
+        x_hr = self.encoder_hr(torch.cat((fov.reshape(n * t, 3, 8 * h, 8 * w), up8_all), 1), islr=True)[2].view(n, t, l, 8 * h, 8 * w)
+        levels = ((self.dcn_0, self.forward_resblocks_0), (self.dcn_1, self.forward_resblocks_1), (self.dcn_2, self.forward_resblocks_2))
+        keep = (m * self.split_ratio) // 4                      # channels that propagate to the next level; the rest is carried over time
+        state2 = lrs.new_zeros(n, m, 2 * h, 2 * w)              # the 2x-resolution view of the state (zero before the first frame)
+        state8 = lrs.new_zeros(n, l, 8 * h, 8 * w)
+        carry = [lrs.new_zeros(n, m - keep, 2 * h, 2 * w) for _ in levels]
+        outs = []
+        for i in range(t):
+            cur = self.upsample(x_lr[:, i].contiguous())
+            if i == 0:
+                # no history yet: [features | zero state | zero carry] through each level's residual block (:1634-1667)
+                for k, (_, block) in enumerate(levels):
+                    y = block(torch.cat((cur, state2, carry[k]), 1))
+                    cur, carry[k] = y[:, :keep].contiguous(), y[:, keep:].contiguous()
+                up = torch.nn.functional.leaky_relu(self.upsample_post(cur), 0.1)
+                state = self.forward_resblocks_3(torch.cat((up, state8), 1))
+            else:
+                flow = flows[:, i - 1].contiguous()
+                f2 = ops.upsample_bilinear(flow, scale_factor=2, mul=2.0).permute(0, 2, 3, 1).contiguous()     # [n, 2h, 2w, 2], (x, y)
+                f8 = ops.upsample_bilinear(flow, scale_factor=8, mul=8.0).permute(0, 2, 3, 1).contiguous()
+                prev8 = state
+                prev2 = self.downsample(prev8)
+                prev2_w, prev8_w = flow_warp(prev2, f2), flow_warp(prev8, f8)
+                carry = list(torch.chunk(flow_warp(torch.cat(carry, 1), f2), 3, dim=1))
+                f2c, f8c = f2.permute(0, 3, 1, 2).contiguous(), f8.permute(0, 3, 1, 2).contiguous()
+                offset = None
+                for k, (dcn, block) in enumerate(levels):
+                    cur = torch.cat((cur, carry[k]), 1)
+                    aligned, offset = dcn(cur, prev2, prev2_w, f2c) if k == 0 else dcn(cur, prev2, prev2_w, f2c, offset)
+                    y = block(torch.cat((cur, aligned), 1))
+                    cur, carry[k] = y[:, :keep].contiguous(), y[:, keep:].contiguous()
+                up = torch.nn.functional.leaky_relu(self.upsample_post(cur), 0.1)
+                aligned, _ = self.dcn_3(up, prev8, prev8_w, f8c, offset)
+                state = self.forward_resblocks_3(torch.cat((up, aligned), 1))
+            # fovea fusion and output head (:1672-1684)
+            fused = ops.conv3x3_ex(state, self.conv_tttf.weight, self.conv_tttf.bias, x2=x_hr[:, i].contiguous())
+            mk = mkf[:, i]
+            state = torch.nn.functional.leaky_relu(mk * fused + (1.0 - mk) * state, 0.1)
+            lr = lrs[:, i]
+            base = (0.299 * lr[:, 0] + 0.587 * lr[:, 1] + 0.114 * lr[:, 2]).unsqueeze(1) if self.y_only else lr
+            outs.append(_run(self.conv_last, state) + ops.upsample_bilinear(base.contiguous(), scale_factor=8))
+        return torch.stack(outs, dim=1)
 
     # ---- streaming interface of the reference's one-frame-per-call variant (model/CRFP_test.py:2216-2478)
     def clear_states(self):
@@ -369,6 +450,9 @@ class CRFP_DSV(nn.Module):
         """lrs[1,t,3,h,w], fvs[1,t,3,8h,8w], mks / fgs[1,t,1,8h,8w] -> [1,t,3|1,8h,8w]; recurrent state and
         the previous LR frame persist between calls (reference model/CRFP_test.py:2234-2239,2438-2441)."""
         assert lrs.shape[0] == 1, "streaming runs one sequence at a time"
+        if not self.has_engine():
+            raise NotImplementedError("crfp_amd: the one-frame-per-call interface exists for mid_channels=32, hr_dcn=True, offset_prop=True "
+                                      "(the configuration test_video.py / test_runtime.py build)")
         eng = self.engine()
         outs = [eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i], None if fgs is None else fgs[0, i])
                 for i in range(lrs.shape[1])]

@@ -172,7 +172,9 @@ def dcnv2_shared(x, offset, mask, weight, bias):
 def conv3x3(x, weight, bias=None, act="none", post_scale=1.0):
     """3x3 stride-1 pad-1 convolution + bias + activation on the fp32 MFMA path (weights repacked by this call)."""
     x, weight = _dev(x, "x"), _dev(weight, "weight")
-    assert tuple(weight.shape) == (weight.shape[0], x.shape[1], 3, 3), "conv3x3: weight must be [cout, cin, 3, 3]"
+    if tuple(weight.shape) != (weight.shape[0], x.shape[1], 3, 3):   # nn.Conv2d's own error class and wording (the reference's callers see a RuntimeError)
+        raise RuntimeError(f"conv3x3: weight of size {list(weight.shape)}, expected input{list(x.shape)} to have {weight.shape[1]} channels, "
+                           f"but got {x.shape[1]} channels instead")
     with _on(x, weight):
         return conv3x3_packed(x, pack_conv3x3(weight, bias), act, post_scale)
 
@@ -194,7 +196,9 @@ def conv3x3_ex(x, weight, bias=None, x2=None, residual=None, act="none", post_sc
         cin2 = x2.shape[1]
         assert tuple(x2.shape) == (n, cin2, h, w), "conv3x3_ex: x2 must match x in n, h, w"
     cout = weight.shape[0]
-    assert tuple(weight.shape) == (cout, cin + cin2, 3, 3), "conv3x3_ex: weight must be [cout, cin + cin2, 3, 3]"
+    if tuple(weight.shape) != (cout, cin + cin2, 3, 3):
+        raise RuntimeError(f"conv3x3_ex: weight of size {list(weight.shape)}, expected input to have {weight.shape[1]} channels, "
+                           f"but got {cin + cin2} channels instead")
     bias = torch.zeros(cout, dtype=torch.float32, device=x.device) if bias is None else _dev(bias, "bias")
     if residual is not None:
         residual = _dev(residual, "residual")

@@ -90,8 +90,11 @@ def test_module_mirror_keys_and_shapes():
         assert list(m.state_dict().keys()) == list(sd.keys())
         m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
         assert any("spynet" in k for k, _ in m.named_parameters())        # trainer.py:131-141 relies on it
-    with pytest.raises(NotImplementedError):
-        CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=16)
+    # round 4: every flag combination constructs (tests/test_flags.py pins the tables); only the shipped one has the one-call engine
+    assert not CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=16).has_engine()
+    assert CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=32).has_engine()
+    with pytest.raises(ValueError):
+        CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=20)
 
 
 def test_dcn_module_init_matches_reference_contract():
