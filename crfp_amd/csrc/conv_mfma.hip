@@ -207,7 +207,7 @@ __device__ __forceinline__ EpiCtx epi_ctx(const ConvArgs& a, int n) {
     }
     e.single = a.ndst == 1 && a.dst[0].q0 == 0 && a.dst[0].q1 >= e.ncq;
     e.dbg = a.stamps;
-    e.ovf = a.ovf;
+    e.ovf = ovf_word(a.ovf, a.ovf_div, a.ovf_add, n, a.ovf_skip0);
     return e;
 }
 
@@ -2644,7 +2644,8 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // 15.1 us, conv2(+x) 17.7 -> 17.0, conv_fuse 22.2 -> 21.6, identical values; block0 (5 chunks: a half-empty last stage) 25.4 -> 26.0,
         // so odd chunk counts keep the 4-wave kernel
         // (for layers with several cout tiles it loses: FNet dec2a 36 -> 43 us, enc3b 22 -> 26, the pixel-shuffle heads +0..1 us)
-        if (a.ctiles == 1 && ((a.kq >> 2) & 1) == 0) {
+        static const int x8_max_wgs = getenv("CRFP_BF16_X8_MAX_WGS") ? atoi(getenv("CRFP_BF16_X8_MAX_WGS")) : (1 << 30);   // A/B knob (round 4)
+        if (a.ctiles == 1 && ((a.kq >> 2) & 1) == 0 && (long long)a.N * ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH) <= x8_max_wgs) {
             const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH);
             conv3x3_bf16x8_kernel<<<dim3(tiles8 * a.ctiles, 1, a.N), B8_NT, 0, s>>>(am);
         } else
@@ -2720,7 +2721,7 @@ int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, const char* name, hip
     pb.bpk = b.bpk; pb.resid = b.resid; pb.resid_bstride = b.resid_bstride;
     for (int d = 0; d < CRFP_MAX_DST; ++d) pb.dst[d] = b.dst[d];
     pb.ndst = b.ndst; pb.cout = b.cout; pb.act = b.act; pb.post_scale = b.post_scale;
-    am.ovf = b.ovf;
+    am.ovf = b.ovf; am.ovf_div = b.ovf_div; am.ovf_add = b.ovf_add;
     const int tiles = ((a.W + P2_OW - 1) / P2_OW) * ((a.H + 7) / 8);
     conv3x3_bf16_pair_kernel<<<dim3(tiles, 1, a.N), P2_NT, 0, s>>>(am, pb);
     CRFP_CHECK_LAUNCH();

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     const act_t* const basep = EPI == NE_LAST && a.base ? as_act(a.base) + (long long)n * a.base_bstride : nullptr;
     const float* const baselr = EPI == NE_LAST && !a.base ? a.base_lr + (long long)n * a.base_bstride : nullptr;
     // fp16-operand range guard (ConvArgs::ovf): the output head turns the frame into NaN once the sticky word is set
-    const bool poison = EPI == NE_LAST && a.ovf && *a.ovf != 0;
+    unsigned* const ovfw = ovf_word(a.ovf, a.ovf_div, a.ovf_add, n);
+    const bool poison = EPI == NE_LAST && ovfw && *ovfw != 0;
     float vmax = 0.0f;
     const float* const flowp = EPI == NE_OFFMASK3 ? a.flow + (long long)n * a.flow_bstride : nullptr;
     const bool y_only = a.y_only != 0;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                 }
             }
         }
-        if (EPI == NE_BLEND && a.ovf && !(vmax < 65504.0f)) { atomicOr(a.ovf, 1u); vmax = 0.0f; }
+        if (EPI == NE_BLEND && ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
         if (t_next >= band1) break;
         t_cur = t_next;
         // every wave is done reading the tile before it is overwritten.  LDS-only barrier: __syncthreads() would also

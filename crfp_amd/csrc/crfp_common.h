@@ -175,6 +175,8 @@ struct ConvArgs {
     // dcn_g8, the state-producing stencil) ORs 1 into *ovf when it stores |v| >= 65504; the output head turns the frame into
     // NaN when the word is set (sticky per clip / stream).  Null: not tracked (per-op API, strict fp32).
     unsigned* ovf;
+    int ovf_div, ovf_add;   // which status word batch item n of the launch raises: ovf[(n + ovf_add) / ovf_div]; ovf_div == 0: ovf[0] (ovf_word())
+    int ovf_skip0;          // 1: items with (n + ovf_add) % ovf_div == 0 raise nothing (FNet's never-read pairs that straddle two clips)
     int strict;         // 1: plain fp32 MFMA for this launch (CRFP_DSV_STRICT_F32)
     int dst_f32;        // bf16 build, ST_Q4, one destination: store float quads (FNet's flow output stays fp32)
     int ksplit;         // fp32-MFMA kernel only: > 0 = blockIdx.z enumerates (batch item, K slice): slice z % ksplit covers K-quads
@@ -273,6 +275,7 @@ struct NarrowArgs {
     int dst_pad, rsv;
     long long* stamps;  // diagnostic builds (-DCRFP_NARROW_STAMPS) only
     unsigned* ovf;      // fp16-operand range guard (see ConvArgs::ovf): NE_BLEND raises it, NE_LAST poisons the frame when set
+    int ovf_div, ovf_add;   // see ConvArgs
 };
 
 // Activations of the offset/mask heads (DCN modules, model/CRFP.py:338-340): hardware exp2/rcp, ~1 ulp each.
@@ -282,6 +285,16 @@ __device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn
 __device__ __forceinline__ float tanh10_plus(float v, float c10f) {
     const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f));
     return __builtin_fmaf(r, -20.0f, c10f);
+}
+
+// One status word per clip of a lock-step batch (engine.hip): batch item n of a launch belongs to clip (n + add) / div -- div = 1 for the
+// per-frame launches (n = clip), div = t for the clip-level stages that run over the flattened [B * t] frame sequence; div = 0 keeps
+// the single word of a one-clip call.  A clip's overflow then poisons that clip's frames only, as with one call per clip.
+__device__ __forceinline__ unsigned* ovf_word(unsigned* base, int div, int add, int n, int skip0 = 0) {
+    if (!base) return nullptr;
+    if (!div) return base;
+    const int g = n + add, q = g / div;
+    return (skip0 && g == q * div) ? nullptr : base + q;
 }
 
 // ------------------------------------------------------------------ XCD-aware tile order
@@ -338,7 +351,7 @@ int launch_flow_warp_q4(const float* x, long long xb, const float* flow, long lo
                         int N, int nq, int H, int W, int border, int src_pad, hipStream_t s);
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
                   const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16 = false,
-                  unsigned* ovf = nullptr);
+                  unsigned* ovf = nullptr, int ovf_div = 0);
 int launch_dcn_g8_pack(const float* w_oihw, float* wpk, hipStream_t s, bool f16 = false);  // fp32 [36][2][32][4] or split-fp16 image
 bool dcn_g8_use_f16();   // engine: split-fp16 DCN GEMM unless CRFP_DCN_MODE=f32
 // offset / mask conv (32 -> 216, model/CRFP.py:337-340) + dcn_g8 in ONE kernel: the 199 MB offset / mask tensor never exists
@@ -357,6 +370,7 @@ struct DcnFuseArgs {
     long long ob;
     int N, H, W;
     unsigned* ovf;
+    int ovf_div;            // 0: one status word; 1: batch item n raises ovf[n]
     int probe;              // lab library only: timing experiments
 };
 bool dcn_fused_enabled();   // default on; CRFP_DCN_FUSED=0 keeps the two-kernel path
@@ -369,7 +383,9 @@ int launch_dcn3_fused(const float* x, long long xb, const float* g2, long long g
 int launch_dcn_generic(const float* x, const float* offset, const float* mask, const float* w, const float* b,
                        float* out, int N, int cin, int cout, int H, int W, int dg, hipStream_t s);
 // resample.hip
-int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s);
+// ovf: the range guard on an API tensor that becomes an fp16 operand as it is (the LR frames): item n raises ovf[n / ovf_div] (ovf_div 0: ovf[0])
+// when a value is >= 65504, inf or NaN -- a producer-side check cannot see those, and inf operands turn into NaN, which v_max drops
+int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s, unsigned* ovf = nullptr, int ovf_div = 0);
 int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s);
 int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
                        int OW, float sh, float sw, float mul, hipStream_t s);

@@ -340,7 +340,7 @@ struct Layout {
         fnet_cap = nb;
         const int H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         h1 = h / 2; w1 = w / 2; h2 = h1 / 2; w2 = w1 / 2; h3 = h2 / 2; w3 = w2 / 2;
-        status = A.take("status", 1, 0, 1, 32, 1);   // 256 bytes; word 0 = overflow flag
+        status = A.take("status", 1, 0, 1, B > 64 ? (B + 1) / 2 : 32, 1);   // >= 256 bytes; word b = overflow flag of clip b
         state_hr = A.take("state_hr", B, 1, H8, W8, 0, 1);
         carry = A.take("carry", B, 6, H2, W2, 0, 1);
         // one-frame-per-call layout (t == 1): two flow slots and (bf16 build) two kept fp32 copies of the LR frame, indexed by call parity
@@ -483,10 +483,13 @@ struct Runner {
     int flow_slot = 0;        // one-frame-per-call path: which of the two flow_lr slots FNet writes
     float* flow_lr_slot() const { return F(L.flow_lr) + (long long)flow_slot * L.h * L.w * 4; }
 
-    // null in strict mode: no kernel forms fp16 operands, the guard has nothing to watch (the word stays 0)
+    // Status words: one per clip of the call.  Batch item n of a launch raises word ovf_off + (n + ovf_add) / ovf_div (ovf_word(),
+    // crfp_common.h): the per-frame launches carry one item per clip (div 1); the clip-level stages set their own mapping (clip_stage).
+    int ovf_div = 1, ovf_add = 0, ovf_off = 0, ovf_skip0 = 0;
+    // null in strict mode: no kernel forms fp16 operands, the guard has nothing to watch (the words stay 0)
     unsigned* ovf() const {
         static const bool env_strict = precision_env_strict("CRFP_CONV_MODE");
-        return strict || env_strict ? nullptr : reinterpret_cast<unsigned*>(ws + L.status);
+        return strict || env_strict ? nullptr : reinterpret_cast<unsigned*>(ws + L.status) + ovf_off;
     }
     float* F(size_t off) const { return reinterpret_cast<float*>(ws + off); }
     // activation pointers are opaque float* at this level: advance by ELEMENTS of the storage type
@@ -516,7 +519,7 @@ struct Runner {
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
         a.wsplit = packed + it.off_s;
-        a.ovf = ovf();
+        a.ovf = ovf(); a.ovf_div = ovf_div; a.ovf_add = ovf_add; a.ovf_skip0 = ovf_skip0;
         a.strict = strict;
         rc = launch_conv_mfma(a, it.name, s);
     }
@@ -534,7 +537,7 @@ struct Runner {
         a.N = N; a.H = H; a.W = W;
         a.resid = resid; a.resid_bstride = resid_bs;
         a.wpk = packed + it.off_w; a.bpk = packed + it.off_b; a.wsplit = packed + it.off_s;
-        a.ovf = ovf();
+        a.ovf = ovf(); a.ovf_div = ovf_div; a.ovf_add = ovf_add;
         a.strict = strict;
         return a;
     }
@@ -574,7 +577,7 @@ struct Runner {
         a.mask = mask; a.mask_bstride = mask_bs;
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
-        a.ovf = ovf();
+        a.ovf = ovf(); a.ovf_div = ovf_div; a.ovf_add = ovf_add;
         rc = launch_narrow(a, it.name, s);
     }
     // two stencils in one pass: item idA (its output has no other reader) feeding item idB (conv_narrow.hip, launch_narrow_pair)
@@ -602,10 +605,12 @@ struct Runner {
 #define RUN(expr) do { if (!rc) rc = (expr); } while (0)
 
     // fp32 build: n NCHW LR frames -> Q4 quads in slot s0.. of lr_q4 (see the Model); the bf16 build reads the fp32 frames directly
-    const float* lr_to_q4(const float* lrs, int n, int s0) {
+    // check_div: the frames are the call's own LR input, frame f of clip f / check_div (0: one sequence): values an fp16 operand cannot
+    // hold (>= 65504, inf, NaN) raise that clip's status word here -- the producer-side guard of the kernels never sees an API tensor
+    const float* lr_to_q4(const float* lrs, int n, int s0, int check_div = -1) {
         if (kActBf16) return lrs;
         float* dst = adv(F(L.lr_q4), (long long)s0 * L.h * L.w * 4);
-        RUN(launch_nchw_to_q4(lrs, dst, n, 3, L.h, L.w, 0, s));
+        RUN(launch_nchw_to_q4(lrs, dst, n, 3, L.h, L.w, 0, s, check_div >= 0 ? ovf() : nullptr, check_div));
         return dst;
     }
     // floats between two consecutive frames of what lr_to_q4 returns (fp32 build: a quad plane; bf16 build: the NCHW frame)
@@ -654,7 +659,7 @@ struct Runner {
 
     // zero the P4 buffers (pads must read as 0; also gives the zero initial state)
     void reset_state() {
-        if (!rc && hipMemsetAsync(ws + L.status, 0, 256, s) != hipSuccess) { set_error("dsv: hipMemsetAsync of the status word failed"); rc = 1; }
+        if (!rc && hipMemsetAsync(ws + L.status, 0, L.A.find(L.status.off)->bytes, s) != hipSuccess) { set_error("dsv: hipMemsetAsync of the status words failed"); rc = 1; }
         for (size_t off : {L.state_hr.off, L.carry.off, L.prev2.off}) {
             const Buf* b = L.A.find(off);
             if (!rc && hipMemsetAsync(ws + off - b->guard, 0, b->bytes + b->guard, s) != hipSuccess) {
@@ -680,12 +685,19 @@ struct Runner {
     void clip_stage(const float* lq, int i0, int i1, int parts) {
         const long long lqf = lr_frame_floats(), lr_f = 3LL * L.h * L.w, fq = (long long)L.h * L.w * 4;
         const int t = L.t, B = L.B;
+        struct Restore { Runner& r; int d, a, o; ~Restore() { r.ovf_div = d; r.ovf_add = a; r.ovf_off = o; r.ovf_skip0 = 0; } } restore{*this, ovf_div, ovf_add, ovf_off};
         if (L.flat) {   // i0 == 0, i1 == t: one pass over the B * t frames / the B * t - 1 consecutive pairs (B - 1 of them straddle two clips and are never read)
+            ovf_div = t;           // item n of these launches is frame n (encoder_lr) / frame n + 1 (FNet's pair n) of the flattened sequence
+            ovf_add = 0;
             if (parts & 1) encode_lr(B * t, lq, lr_f, 0);
+            ovf_add = 1;
+            ovf_skip0 = 1;         // the pair whose current frame opens a clip straddles two clips: never read, raises nothing
             if ((parts & 2) && B * t > 1) fnet(B * t - 1, lq + lqf, lr_f, lq, lr_f, F(L.flow_lr) + fq);
             return;
         }
+        ovf_div = 0;               // per-clip passes: every item of a launch belongs to clip b
         for (int b = 0; b < B && !rc; ++b) {
+            ovf_off = b;
             const float* f0 = lq + ((long long)b * t + i0) * lqf;
             if (parts & 1) encode_lr(i1 - i0, f0, lr_f, L.slot(b, i0));
             const int j0 = i0 > 0 ? i0 : 1;
@@ -818,12 +830,12 @@ struct Runner {
                     fa.wconv = (const char*)(packed + om.off_s) + conv_split16_offset_bytes(om.c); fa.bconv = packed + om.off_b;
                     fa.x = F(L.prev2); fa.xb = L.prev2.bs;
                     fa.wdcn = packed + dw.off_w + 36 * 2 * 32 * 4; fa.bdcn = packed + dw.off_b;
-                    fa.out = F(L.aligned); fa.ob = bs8; fa.N = B; fa.H = H2; fa.W = W2; fa.ovf = ovf();
+                    fa.out = F(L.aligned); fa.ob = bs8; fa.N = B; fa.H = H2; fa.W = W2; fa.ovf = ovf(); fa.ovf_div = ovf_div;
                     RUN(launch_dcn_fused(fa, s));
                 } else {
                     mfma(it_lvl(l, L_OM), B, H2, W2, {{f, bs8}}, {{F(L.offmask), L.offmask.bs, 0, 54}}, 0, 0, nullptr, 0, flow2, f2b);
                     RUN(launch_dcn_g8(F(L.prev2), L.prev2.bs, F(L.offmask), L.offmask.bs, packed + dw.off_w + (f16 ? 36 * 2 * 32 * 4 : 0), packed + dw.off_b,
-                                      F(L.aligned), bs8, B, H2, W2, s, f16, ovf()));
+                                      F(L.aligned), bs8, B, H2, W2, s, f16, ovf(), ovf_div));
                 }
                 if (fg && l > 0) {  // model/CRFP_test.py:2361,2375: resblock input * fg (x0.25) for levels 1, 2   (one sequence per workspace: B == 1)
                     RUN(launch_scale_q4(prop, 0, F(L.sc_prop), 6, H2, W2, F(L.fg2), nullptr, s));
@@ -1010,7 +1022,7 @@ int CRFP_API(crfp_dsv_forward_batch)(const void* packed, int flags, const float*
     if (!ssp) {
         // single-stream schedule (also used while per-kernel timing is on: events bracket launches per stream)
         R.reset_state();
-        const float* lq = R.lr_to_q4(lrs, n * t, 0);
+        const float* lq = R.lr_to_q4(lrs, n * t, 0, t);
         for (int i = 0; i < t && !R.rc; ++i) {
             if (i % TC == 0) {   // flat: once, FNet first (the order of the one-clip engine of rounds 1-3)
                 const int i1 = i + TC < t ? i + TC : t;
@@ -1039,7 +1051,7 @@ int CRFP_API(crfp_dsv_forward_batch)(const void* packed, int flags, const float*
     // the status word and the recurrent state are cleared BEFORE the fork: the side stream's first kernel (frame 0's fovea
     // blend) may raise the overflow bit, and a memset racing with it on the other stream could wipe that
     R.reset_state();
-    const float* lq = R.lr_to_q4(lrs, n * t, 0);   // before the fork: FNet on the side stream reads it as well
+    const float* lq = R.lr_to_q4(lrs, n * t, 0, t);   // before the fork: FNet on the side stream reads it as well
     if (R.rc) return R.rc;
     if (hipEventRecord(ev_start, main_s) != hipSuccess || hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
     forked = true;
@@ -1123,7 +1135,7 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
                 *cur = lr;
                 *prev = R.F(L.lr_keep[par ^ 1]);
             } else {
-                *cur = R.lr_to_q4(lr, 1, par);
+                *cur = R.lr_to_q4(lr, 1, par, 0);
                 *prev = R.adv(R.F(L.lr_q4), (long long)(par ^ 1) * h * w * 4);
             }
         };
@@ -1175,8 +1187,8 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     if (ctx) ctx->kept = ctx->chained = false;   // a call without the flag keeps no frame and orders nothing for a later resident call
     if (!ssp) {
         if (first) R.reset_state();
-        const float* lq = R.lr_to_q4(lr, 1, 0);
-        if (!first) R.fnet(1, lq, 0, R.lr_to_q4(lr_prev, 1, 1), 0, R.F(L.flow_lr));
+        const float* lq = R.lr_to_q4(lr, 1, 0, 0);
+        if (!first) R.fnet(1, lq, 0, R.lr_to_q4(lr_prev, 1, 1, 0), 0, R.F(L.flow_lr));
         R.encode_lr(1, lq, 0);
         io.flow_lr = first ? nullptr : R.F(L.flow_lr);
         R.frame_pre(0, first != 0, io);
@@ -1195,8 +1207,8 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     auto fail = [&](const char* what) { join(); set_error("dsv_stream_frame: %s failed", what); return 1; };
     hipEvent_t ev_start = ss.event(0), ev_side = ss.event(1);
     if (!ss.ok) return fail("hipEventCreate");
-    const float* lq = R.lr_to_q4(lr, 1, 0);   // before the fork: read on both streams
-    const float* lqp = R.lr_to_q4(lr_prev, 1, 1);
+    const float* lq = R.lr_to_q4(lr, 1, 0, 0);   // before the fork: read on both streams
+    const float* lqp = R.lr_to_q4(lr_prev, 1, 1, 0);
     if (hipEventRecord(ev_start, main_s) != hipSuccess) return fail("record");
     R.fnet(1, lq, 0, lqp, 0, R.F(L.flow_lr));
     io.flow_lr = R.F(L.flow_lr);
@@ -1234,6 +1246,7 @@ int CRFP_API(crfp_fnet_forward)(const void* packed, const float* cur, const floa
     if (rc) return rc;
     if (!cur || !prev || !flow) { set_error("fnet_forward: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(0), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    R.ovf_div = 0;   // pairs, not clips: one status word
     const long long lr_f = 3LL * h * w, lqf = R.lr_frame_floats();
     const float* cq = R.lr_to_q4(cur, n, 0);
     const float* pq = R.lr_to_q4(prev, n, n + 1);
@@ -1252,13 +1265,16 @@ int CRFP_API(crfp_dsv_debug_fetch)(const char* name, int t, int h, int w, const 
     for (auto& b : L.A.bufs)
         if (b.name == name) {
             const float* p = reinterpret_cast<const float*>((const char*)workspace + b.off);
+            int bN = b.N;
+            // the flow of frame i lives in slot i of the store (slot 0 belongs to frame 0, which has none): present frames 1 .. t - 1
+            if (b.name == "flow_lr" && t > 1 && L.flat) { p += (size_t)b.H * b.W * 4; bN = t - 1; }
             if (c_out) *c_out = b.kind == 0 ? b.nq * 4 : 2;
             if (h_out) *h_out = b.H;
             if (w_out) *w_out = b.W;
-            if (!out_nchw) return b.N;
-            if (b.kind == 0 && b.f32) return crfp::launch_q4_to_nchw(p, out_nchw, b.N, b.nq * 4, b.H, b.W, b.pad, (hipStream_t)stream);
-            if (b.kind == 0) return launch_q4_to_nchw(p, out_nchw, b.N, b.nq * 4, b.H, b.W, b.pad, (hipStream_t)stream);
-            return hipMemcpyAsync(out_nchw, p, (size_t)b.N * b.H * b.W * 2 * sizeof(float), hipMemcpyDeviceToDevice,
+            if (!out_nchw) return bN;
+            if (b.kind == 0 && b.f32) return crfp::launch_q4_to_nchw(p, out_nchw, bN, b.nq * 4, b.H, b.W, b.pad, (hipStream_t)stream);
+            if (b.kind == 0) return launch_q4_to_nchw(p, out_nchw, bN, b.nq * 4, b.H, b.W, b.pad, (hipStream_t)stream);
+            return hipMemcpyAsync(out_nchw, p, (size_t)bN * b.H * b.W * 2 * sizeof(float), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream) == hipSuccess ? 0 : 1;
         }
     set_error("debug_fetch: unknown buffer '%s'", name);

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
                                                              const float* __restrict__ offmask, long long omb,
                                                              const float* __restrict__ wpk, const float* __restrict__ bias,
                                                              float* __restrict__ out, long long ob, int H, int W,
-                                                             unsigned* __restrict__ ovf, int probe) {
+                                                             unsigned* __restrict__ ovf, int probe, int ovf_div) {
     __shared__ f32x4 wl[36 * 64];   // split-fp16 weight image (36 KB), shared by the 4 waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 36 * 64; i += 256) wl[i] = reinterpret_cast<const f32x4*>(wpk)[i];
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
     }
-    if (ovf && !(vmax < 65504.0f)) atomicOr(ovf, 1u);
+    if (ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(ovf, ovf_div, 0, n), 1u);
 }
 
 
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
     }
-    if (a.ovf && !(vmax < 65504.0f)) atomicOr(a.ovf, 1u);
+    if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
 }
 
 // ---------------------------------------------------------------- round 3: the same fusion with ROLE-SPECIALISED waves
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(D2_NT, 1) void dcn_fused2_kernel(const DcnFuseArgs 
         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
     }
-    if (a.ovf && !(vmax < 65504.0f)) atomicOr(a.ovf, 1u);
+    if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
 }
 
 bool dcn_fused_enabled() {
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
     }
-    if (a.ovf && !(vmax < 65504.0f)) atomicOr(a.ovf, 1u);
+    if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
 }
 
 bool dcn_fused_enabled() {
@@ -1372,7 +1372,7 @@ int launch_dcn_g8_pack(const float* w, float* wpk, hipStream_t s, bool f16) {
 }
 
 int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long omb, const float* wpk,
-                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16, unsigned* ovf) {
+                  const float* bias, float* out, long long ob, int N, int H, int W, hipStream_t s, bool f16, unsigned* ovf, int ovf_div) {
     if ((long long)(H + 1) * (W + 1) >= (1ll << 24)) { set_error("dcn_g8: plane of %d x %d exceeds the sampler's 2^24-element index range", H, W); return CRFP_E_UNSUPPORTED; }
     const double px = (double)N * H * W;
     ProfScope prof("dcnv2_g8_c32", s, px * ((32 + 32) * sizeof(act_t) + (144 + 72) * 4.0) + 32.0 * 32 * 9 * 4, 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
@@ -1404,10 +1404,10 @@ int launch_dcn_g8(const float* x, long long xb, const float* offmask, long long 
 #endif
 #ifdef CRFP_ACT_BF16
     if (!f16) { set_error("dcn_g8: the bf16 build has the split-fp16 GEMM only"); return CRFP_E_UNSUPPORTED; }
-    dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf, probe);
+    dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf, probe, ovf_div);
 #else
     if (f16)
-        dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf, probe);
+        dcn_g8_pipe_kernel<<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W, ovf, probe, ovf_div);
     else
         dcn_g8_kernel<4, 2, 4, false><<<dim3((W + 31) / 32, (H + 3) / 4, N), 256, 0, s>>>(x, xb, offmask, omb, wpk, bias, out, ob, H, W);
 #endif

@@ -20,7 +20,8 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int
 }
 
 // pad = 1: destination / source planes are (H+1) x (W+1) ("P4"); pads are not touched here
-__global__ void nchw_to_q4_kernel(const float* __restrict__ x, act_t* __restrict__ out, int C, int H, int W, int pad) {
+__global__ void nchw_to_q4_kernel(const float* __restrict__ x, act_t* __restrict__ out, int C, int H, int W, int pad, unsigned* __restrict__ ovf,
+                                  int ovf_div) {
     const long long HW = (long long)H * W, PHW = (long long)(H + pad) * (W + pad);
     const int nq = (C + 3) / 4;
     const long long total = (long long)nq * HW;
@@ -34,6 +35,8 @@ __global__ void nchw_to_q4_kernel(const float* __restrict__ x, act_t* __restrict
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = 4 * q + c < C ? x[((long long)n * C + 4 * q + c) * HW + pix] : 0.0f;
         stq(out + (((long long)n * nq + q) * PHW + y * (W + pad) + xx) * 4, cf32x4{v[0], v[1], v[2], v[3]});
+        if (ovf && !(fabsf(v[0]) < 65504.0f && fabsf(v[1]) < 65504.0f && fabsf(v[2]) < 65504.0f && fabsf(v[3]) < 65504.0f))
+            atomicOr(ovf_word(ovf, ovf_div, 0, n), 1u);   // also true for NaN
     }
 }
 
@@ -60,10 +63,10 @@ static inline int grid_for(long long total) {
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s) {
+int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s, unsigned* ovf, int ovf_div) {
     const long long total = (long long)((C + 3) / 4) * H * W;
     ProfScope prof("nchw_to_q4", s, (double)N * H * W * (C + 4.0 * ((C + 3) / 4)) * 4.0, 0);
-    nchw_to_q4_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, as_act(out), C, H, W, pad);
+    nchw_to_q4_kernel<<<dim3(grid_for(total), N), 256, 0, s>>>(x, as_act(out), C, H, W, pad, ovf, ovf_div);
     CRFP_CHECK_LAUNCH();
     return 0;
 }

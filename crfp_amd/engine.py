@@ -119,8 +119,9 @@ class DSVEngine:
         return self.y_only | (_lib.DSV_STRICT_F32 if strict else 0) | (_lib.DSV_SINGLE_STREAM if self.single_stream else 0)
 
     def _status(self, ws, t, h, w, n=1) -> int:
+        """OR of the call's status words (one per clip of a lock-step batch).  Synchronises."""
         off = self._fn("crfp_dsv_batch_status_offset")(n, t, h, w)
-        return int(ws[off:off + 4].view(torch.int32).item())   # synchronises
+        return int(ws[off:off + 4 * n].view(torch.int32).max().item())
 
     def overflowed(self, stream: bool = False) -> bool:
         """True when the split-fp16 range guard fired in the last clip forward (or, stream=True, in the running
@@ -166,16 +167,16 @@ class DSVEngine:
                                                              ws.data_ptr(), ws.numel(), _stream()), "crfp_dsv_forward_clip")
 
         off = self._fn("crfp_dsv_batch_status_offset")(nb, t, h, w)
-        word = ws[off:off + 4].view(torch.int32)
+        words = ws[off:off + 4 * nb].view(torch.int32)   # one status word per clip of the call: a clip's overflow poisons that clip only
         with torch.cuda.device(self.device):
             if self._ovf is None:
                 self._ovf = torch.zeros(1, dtype=torch.int32, device=self.device)
             for b in range(1 if lock else n):
                 run(b)
-                # "fallback" under lockstep reruns the whole batch in strict fp32: the status word is shared by its clips
+                # "fallback" under lockstep reruns the whole batch in strict fp32
                 self._after(ws, (t, h, w, nb), lambda b=b: run(b, strict=True))
                 # every call resets the workspace's status word: keep the OR over the batch (stream-ordered, no host sync)
-                self._ovf.copy_(word) if b == 0 else self._ovf.bitwise_or_(word)
+                self._ovf.copy_(words.max().reshape(1)) if b == 0 else self._ovf.bitwise_or_(words.max().reshape(1))
         return out
 
     # ---- streaming: one frame per call, state lives in a dedicated workspace

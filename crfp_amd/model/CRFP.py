@@ -397,7 +397,7 @@ class CRFP_DSV(nn.Module):
         up8_all = ops.upsample_bilinear(flat, scale_factor=8)                               # :1538
         x_lr = self.encoder_lr(flat, islr=True)[2].view(n, t, m, h, w)                      # :1540
         fov = fvs.float() * mkf + up8_all.view(n, t, 3, 8 * h, 8 * w) * (1.0 - mkf)         # :1543-1544
-        x_hr = self.encoder_hr(torch.cat((fov.reshape(n * t, 3, 8 * h, 8 * w), up8_all), 1), islr=True)[2].view(n, t, l, 8 * h, 8 * w)
+        x_hr, side = self._encode_hr(torch.cat((fov.reshape(n * t, 3, 8 * h, 8 * w), up8_all), 1), n, t)
         levels = ((self.dcn_0, self.forward_resblocks_0), (self.dcn_1, self.forward_resblocks_1), (self.dcn_2, self.forward_resblocks_2))
         keep = (m * self.split_ratio) // 4                      # channels that propagate to the next level; the rest is carried over time
         state2 = lrs.new_zeros(n, m, 2 * h, 2 * w)              # the 2x-resolution view of the state (zero before the first frame)
@@ -409,7 +409,7 @@ class CRFP_DSV(nn.Module):
             if i == 0:
                 # no history yet: [features | zero state | zero carry] through each level's residual block (:1634-1667)
                 for k, (_, block) in enumerate(levels):
-                    y = block(torch.cat((cur, state2, carry[k]), 1))
+                    y = self._after_level(k, block(torch.cat((cur, state2, carry[k]), 1)), side, i, mkf)
                     cur, carry[k] = y[:, :keep].contiguous(), y[:, keep:].contiguous()
                 up = torch.nn.functional.leaky_relu(self.upsample_post(cur), 0.1)
                 state = self.forward_resblocks_3(torch.cat((up, state8), 1))
@@ -426,7 +426,7 @@ class CRFP_DSV(nn.Module):
                 for k, (dcn, block) in enumerate(levels):
                     cur = torch.cat((cur, carry[k]), 1)
                     aligned, offset = dcn(cur, prev2, prev2_w, f2c) if k == 0 else dcn(cur, prev2, prev2_w, f2c, offset)
-                    y = block(torch.cat((cur, aligned), 1))
+                    y = self._after_level(k, block(torch.cat((cur, aligned), 1)), side, i, mkf)
                     cur, carry[k] = y[:, :keep].contiguous(), y[:, keep:].contiguous()
                 up = torch.nn.functional.leaky_relu(self.upsample_post(cur), 0.1)
                 aligned, _ = self.dcn_3(up, prev8, prev8_w, f8c, offset)
@@ -439,6 +439,15 @@ class CRFP_DSV(nn.Module):
             base = (0.299 * lr[:, 0] + 0.587 * lr[:, 1] + 0.114 * lr[:, 2]).unsqueeze(1) if self.y_only else lr
             outs.append(_run(self.conv_last, state) + ops.upsample_bilinear(base.contiguous(), scale_factor=8))
         return torch.stack(outs, dim=1)
+
+    # hooks of forward_composed that the CRFP_DSV_CRA wiring overrides
+    def _encode_hr(self, x6, n, t):
+        """encoder_hr on the [n * t, 6, 8h, 8w] stack of (blended fovea | x8 LR) -> (x_hr [n, t, last, 8h, 8w], side inputs)"""
+        f = self.encoder_hr(x6, islr=True)[2]
+        return f.view(n, t, f.shape[1], f.shape[2], f.shape[3]), None
+
+    def _after_level(self, k, y, side, i, mkf):
+        return y
 
     # ---- streaming interface of the reference's one-frame-per-call variant (model/CRFP_test.py:2216-2478)
     def clear_states(self):
@@ -466,6 +475,45 @@ class CRFP_DSV(nn.Module):
             self.load_state_dict(sd, strict=strict)
         elif pretrained is not None:
             raise TypeError(f'"pretrained" must be a str or None. But received {type(pretrained)}.')
+
+
+class CRFP_DSV_CRA(CRFP_DSV):
+    """The reference's CRFP_DSV_CRA (model/CRFP.py:2314-2664; eval.sh's run name ends in ``_cra``, main.py:35 holds its commented-out
+    factory line): CRFP_DSV plus a cross-resolution fusion of the fovea into every 2x level.  ``encoder_hr`` is the four-level
+    ``LTE_simple_hr_ps``; after each level's residual block the 32 features are replaced, under the x0.25-resampled fovea mask, by
+    ``conv_tttf_k(cat(features, fovea level k))`` (:2533-2535,2549-2551,2565-2567 and the first-frame twins).  Same constructor,
+    same state_dict table as the reference (tests/golden/dsv_flags.npz).  Runs as a composition of per-operator HIP calls
+    (``forward_composed``): there is no one-call engine schedule for this ablation wiring."""
+
+    def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, spynet_pretrained=None):
+        super().__init__(device, mid_channels, y_only, hr_dcn, offset_prop, spynet_pretrained)
+        m, l = self.mid_channels, self.last_channels
+        # the reference's registration order (:2347-2353): encoder_hr, conv_tttf, conv_tttf_0..2 sit between encoder_lr and the
+        # propagation branches -- rebuild the module table in that order so that state_dict() enumerates the same key sequence
+        mods = dict(self._modules)
+        for k in list(self._modules):
+            del self._modules[k]
+        for k, v in mods.items():
+            if k == "encoder_hr":
+                v = LTE.LTE_simple_hr_ps(l)
+            self._modules[k] = v
+            if k == "conv_tttf":
+                for j in range(3):
+                    self._modules[f"conv_tttf_{j}"] = conv3x3(m + l * 4, m)
+
+    def has_engine(self) -> bool:
+        return False
+
+    def _encode_hr(self, x6, n, t):
+        lv0, lv1, lv2, lv3 = self.encoder_hr(x6)
+        v = lambda f: f.view(n, t, f.shape[1], f.shape[2], f.shape[3])   # noqa: E731
+        return v(lv3), (v(lv0), v(lv1), v(lv2))
+
+    def _after_level(self, k, y, side, i, mkf):
+        conv = (self.conv_tttf_0, self.conv_tttf_1, self.conv_tttf_2)[k]
+        fused = ops.conv3x3_ex(y, conv.weight, conv.bias, x2=side[k][:, i].contiguous())
+        mk2 = ops.upsample_bilinear(mkf[:, i].contiguous(), scale_factor=0.25)     # img_downsample_4x(mk.float()), :2501
+        return mk2 * fused + (1.0 - mk2) * y
 
 
 class MRCF_simple_v18(CRFP_DSV):

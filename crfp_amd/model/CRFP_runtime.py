@@ -150,10 +150,24 @@ class MRCF_simple_v18(nn.Module):
         lrs_2 = lrs[:, 1:].reshape(-1, c, h, w)
         return self.spynet(lrs_2.contiguous(), lrs_1.contiguous()).view(n, t - 1, 2, h, w), None
 
+    def _engine_takes(self, lrs, fvs, warp_size) -> bool:
+        """What crfp_rt_forward_clip is built for (csrc/engine_rt.hip, rt_check_dims): mid_channels = 32 with offset propagation
+        (test_runtime.py:41) and a warp window that is a multiple of 8, at least 64 and inside the 8x frame.  The reference clamps its
+        window by slicing (:8487,8548), so an oversized default ``warp_size=(1080, 1920)`` on a smaller frame or a ragged one is legal
+        there: those calls -- and ``offset_prop=False`` models, which have no conv_fuse / dcn_3.upsample to pack -- take the
+        per-operator composition, as they did before the one-call schedule existed."""
+        if self.mid_channels != 32 or not self.offset_prop or lrs.dim() != 5 or fvs.dim() != 5:
+            return False
+        h, w = lrs.shape[-2:]
+        wp_h, wp_w = int(warp_size[0]), int(warp_size[1])
+        fh, fw = fvs.shape[-2:]
+        return wp_h % 8 == 0 and wp_w % 8 == 0 and 64 <= wp_h <= 8 * h and 64 <= wp_w <= 8 * w and fh <= 8 * h and fw <= 8 * w
+
     @torch.no_grad()
     def forward(self, lrs, fvs, warp_size=(1080, 1920)):
-        if self.print_timings or self.mid_channels != 32:   # the one-call schedule is built for mid_channels = 32 (test_runtime.py:41)
+        if self.print_timings or not self._engine_takes(lrs, fvs, warp_size):
             return self.forward_staged(lrs, fvs, warp_size)
+        self.last_timings = {}   # per-stage timers exist on the staged path only (print_timings = True)
         return self.engine().forward(lrs, fvs, warp_size)
 
     @torch.no_grad()

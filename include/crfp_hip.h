@@ -209,8 +209,8 @@ int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const
  * out[n,t,3|1,8h,8w].  The n clips walk the recurrent chain in lock-step -- ONE launch per layer and frame step over all n clips --
  * so a 2x-resolution map that is a single round of workgroups for one clip becomes n rounds whose load / MFMA / store phases
  * overlap.  Per clip the arithmetic is that of crfp_dsv_forward_clip: outputs are bit-identical to n one-clip calls.  The workspace
- * holds n recurrent states (query crfp_dsv_batch_workspace_bytes); the status word is shared: an fp16-operand overflow in ANY clip
- * poisons every output frame of the call (rerun with CRFP_DSV_STRICT_F32, or clip by clip to find it).  The clip-level stages
+ * holds n recurrent states (query crfp_dsv_batch_workspace_bytes) and n status words at crfp_dsv_batch_status_offset, word b for clip
+ * b: an fp16-operand overflow poisons the frames of the clip it happened in and no other, as with one call per clip.  The clip-level stages
  * (FNet, encoder_lr) run once over all n * t frames when n * t <= 32 and in chunks of 8 frames per clip otherwise, so the
  * workspace does not grow with t. */
 size_t crfp_dsv_batch_workspace_bytes(int n, int t, int h, int w);

@@ -78,6 +78,26 @@ def main():
                         shapes=np.array([str(s) for s in shapes.values()]), lrs=lrs.numpy(), fvs=fvs.numpy(),
                         warp=np.array(warp), out=out.numpy())
     print(out.shape, float(out.mean()), float(out.abs().max()))
+    # round 4: the calls the one-call engine does not take and the module mirror routes through its per-operator composition --
+    # a model built with offset_prop=False (no conv_fuse / dcn_3.upsample parameters) and the default, oversized warp_size on a small
+    # frame (the reference clamps its window by slicing, :8487,8548)
+    extra = {}
+    net2 = ref.MRCF_simple_v18(mid_channels=32, y_only=False, hr_dcn=True, offset_prop=False, split_ratio=3,
+                               spynet_pretrained='pretrained_models/fnet.pth', device=torch.device("cpu"))
+    shapes2 = {k: tuple(v.shape) for k, v in net2.state_dict().items()}
+    sd2 = synth.make_state_dict_like(shapes2, SEED + 1)
+    net2.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd2.items()}, strict=True)
+    net2.eval()
+    lrs2 = torch.from_numpy(synth.make_clip(401, 1, 2, 16, 24, fv_size=32)[0])
+    fvs2 = torch.from_numpy(rs.uniform(0, 1, (1, 2, 3, 48, 48)).astype(np.float32))
+    extra["noprop.keys"] = np.array([f"{k}:{','.join(map(str, v))}" for k, v in shapes2.items()])
+    extra["noprop.weights_seed"] = np.int64(SEED + 1)
+    extra["noprop.lrs"], extra["noprop.fvs"], extra["noprop.warp"] = lrs2.numpy(), fvs2.numpy(), np.array((96, 128))
+    extra["noprop.out"] = net2(lrs2, fvs2, warp_size=(96, 128)).numpy()
+    extra["oversize.lrs"], extra["oversize.fvs"] = lrs2.numpy(), fvs2.numpy()
+    extra["oversize.out"] = net(lrs2, fvs2).numpy()          # warp_size = the signature's default (1080, 1920) on a 128 x 192 frame
+    np.savez_compressed(os.path.join(HERE, "runtime_flags.npz"), **extra)
+    print({k: (v.shape if hasattr(v, "shape") else v) for k, v in extra.items()})
 
 
 if __name__ == "__main__":

@@ -358,11 +358,15 @@ def test_runtime_engine_one_call_vs_reference_golden_and_oracle(orc):
     got = my(l.to(dev()), f.to(dev()), warp_size=(96, 128))
     ref = ro.runtime_forward(orc.load_numpy_state(sdy), l, f, (96, 128), y_only=True)
     assert tuple(got.shape) == (2, 2, 1, 128, 192) and _stats(got, ref)[0] < 2e-4
-    # geometry the schedule cannot run is refused by name, nothing is computed
-    with pytest.raises(ValueError, match="warp_size"):
-        m(lrs, fvs, warp_size=(100, 192))
-    with pytest.raises(ValueError, match="warp_size"):
-        m(lrs, fvs, warp_size=(256, 192))                   # taller than the 192-row frame
+    # geometry the one-call schedule cannot run: the ENGINE refuses it by name ...
+    with pytest.raises(ValueError, match="geometry"):
+        m.engine().forward(lrs, fvs, (256, 192))            # taller than the 192-row frame
+    # ... and the module routes such calls through the per-operator composition, as the reference clamps its window by slicing
+    # (model/CRFP_runtime.py:8487,8548): the default warp_size on a small frame == the clamped window
+    big = m(lrs, fvs, warp_size=(1080, 1920))
+    ref_big = ro.runtime_forward(P, lrs.cpu(), fvs.cpu(), (1080, 1920))
+    assert _stats(big, ref_big)[0] < 2e-4
+    assert _stats(big, m(lrs, fvs, warp_size=(8 * lrs.shape[-2], 8 * lrs.shape[-1])).cpu())[0] < 2e-4
     # `.data` writes + invalidate_packed, like CRFP_DSV
     m.conv_last.weight.data *= 0.5
     m.invalidate_packed()

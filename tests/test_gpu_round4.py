@@ -142,16 +142,23 @@ def test_fnet_forward_more_pairs_than_one_pass():
         assert torch.equal(one[0], all_[i]), i
 
 
-def test_batch_overflow_poisons_the_whole_call_and_is_reported():
-    """The status word is shared by the clips of a lock-step call: an fp16-operand overflow in one clip turns every frame of the
-    call into NaN (never a finite wrong frame) and overflowed() says why."""
+def test_batch_overflow_poisons_only_the_clip_it_happened_in():
+    """One status word per clip of a lock-step call: an fp16-operand overflow in clip 1 turns clip 1's frames into NaN (never a finite
+    wrong frame), leaves clips 0 and 2 bit-identical to their one-clip results, and overflowed() reports it."""
     eng, _ = _engine("f32")
-    lrs, fvs, mks = _batch((91, 92), 3, 24, 40, 64)
-    lrs = lrs.clone()
-    lrs[1] *= 1e6
-    out = eng.forward(lrs, fvs * 1.0, mks)
+    lrs, fvs, mks = _batch((91, 92, 93), 3, 24, 40, 64)
+    eng.batch_mode = "loop"
+    ref = eng.forward(lrs, fvs, mks).clone()
+    assert not eng.overflowed()
+    eng.batch_mode = "lockstep"
+    bad = lrs.clone()
+    bad[1] *= 1e6
+    out = eng.forward(bad, fvs, mks)
     assert eng.overflowed()
-    assert torch.isnan(out).all()
-    eng.on_overflow = "fallback"
-    out2 = eng.forward(lrs, fvs, mks)
-    assert torch.isfinite(out2[0]).all()
+    assert torch.isnan(out[1]).all()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2])
+    eng.on_overflow = "fallback"          # reruns the batch in strict fp32
+    out2 = eng.forward(bad, fvs, mks)
+    assert torch.isfinite(out2[0]).all() and torch.isfinite(out2[2]).all()
+    eng.on_overflow = "poison"
+    assert torch.equal(eng.forward(lrs, fvs, mks), ref) and not eng.overflowed()   # the words are cleared by the next call
