@@ -102,7 +102,12 @@ def pmc_traffic(family: str, storage: str, lr=(180, 320)):
             calls += r["calls"]
     if not calls:
         return None
-    return {"bytes_per_launch": tot / calls, "source": "profiles/" + fname, "measured_in_run": False}
+    # the summary names the kernel sources it was collected with (tools/summarize_pmc.py): another digest = other kernels than the ones timed here
+    from crfp_amd import _lib
+    meta = os.path.join(ROOT, "profiles", fname.replace(".json", ".meta.json"))
+    sha = json.load(open(meta)).get("kernels_src_sha") if os.path.exists(meta) else None
+    return {"bytes_per_launch": tot / calls, "source": "profiles/" + fname, "measured_in_run": False,
+            "kernels_src_sha": sha, "stale": None if sha is None else sha != _lib.kernel_source_digest()}
 
 
 def warp_dcn_8d(fam, steady_frames, storage, h, w):

@@ -113,6 +113,19 @@ def lib():
     return _lib
 
 
+def kernel_source_digest() -> str:
+    """sha256 (12 hex digits) over the kernel sources (csrc/*.hip, *.h, *.inc, Makefile): names the build a profile was taken with, so that
+    bench.py can tell when the committed PMC summary belongs to other kernels than the ones it is timing (`stale`)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def check(rc: int, what: str):
     if rc != 0:
         msg = lib().crfp_last_error_string().decode(errors="replace")

@@ -2644,7 +2644,11 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // 15.1 us, conv2(+x) 17.7 -> 17.0, conv_fuse 22.2 -> 21.6, identical values; block0 (5 chunks: a half-empty last stage) 25.4 -> 26.0,
         // so odd chunk counts keep the 4-wave kernel
         // (for layers with several cout tiles it loses: FNet dec2a 36 -> 43 us, enc3b 22 -> 26, the pixel-shuffle heads +0..1 us)
-        static const int x8_max_wgs = getenv("CRFP_BF16_X8_MAX_WGS") ? atoi(getenv("CRFP_BF16_X8_MAX_WGS")) : (1 << 30);   // A/B knob (round 4)
+        // ... and only while its 8-row tiles fill no more than one round of the chip's 512 slots (two 60 KB workgroups per CU): a lock-step
+        // batch of clips is several rounds, where tile granularity no longer matters and the 4-wave kernel's four workgroups per CU overlap
+        // more of each other's load / MFMA / store phases (round 4, same box, 4 clips: res.main0 15.1 -> 14.1 us per clip, conv_fuse 14.7 -> 14.0,
+        // conv1 9.9 -> 9.2; CRFP_BF16_X8_MAX_WGS overrides the threshold for A/B runs)
+        static const int x8_max_wgs = getenv("CRFP_BF16_X8_MAX_WGS") ? atoi(getenv("CRFP_BF16_X8_MAX_WGS")) : 512;
         if (a.ctiles == 1 && ((a.kq >> 2) & 1) == 0 && (long long)a.N * ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH) <= x8_max_wgs) {
             const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH);
             conv3x3_bf16x8_kernel<<<dim3(tiles8 * a.ctiles, 1, a.N), B8_NT, 0, s>>>(am);
@@ -2654,7 +2658,8 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // 8-wave single-accumulator kernel for the convs with one cout tile (the 32-cout layers: one round of 450 workgroups
         // instead of 1.17 rounds of 900; same-box: conv1 26.4 -> 24.6 us, conv2 28.7 -> 26.1, block0 46.0 -> 43.2, main0 40.0 ->
         // 38.0, clip -1.5 %); with several cout tiles the 4-wave kernel stays (offset/mask head 114.0 vs 117.7 us)
-        if (a.ctiles == 1 && !uses_s3_dst_only_4wave(a)) {
+        static const int s8_max_wgs = getenv("CRFP_F32_S8_MAX_WGS") ? atoi(getenv("CRFP_F32_S8_MAX_WGS")) : (1 << 30);   // A/B knob (round 4)
+        if (a.ctiles == 1 && !uses_s3_dst_only_4wave(a) && (long long)a.N * ((a.W + TW - 1) / TW) * ((a.H + S8_TH - 1) / S8_TH) <= s8_max_wgs) {
 #ifdef CRFP_S8_NW
             constexpr int s8nw = CRFP_S8_NW;
 #else

@@ -516,6 +516,126 @@ class CRFP_DSV_CRA(CRFP_DSV):
         return mk2 * fused + (1.0 - mk2) * y
 
 
+class CRFP_simple(nn.Module):
+    """The reference's CRFP_simple ("v13", model/CRFP.py:816-1099) and, with ``dense = True``, its sibling CRFP ("v15", :1101-1385): the
+    ablation wirings in front of CRFP_DSV -- no carried features (every level passes all mid_channels on), ``upsample`` keeps
+    mid_channels, the previous state is warped at 8x FIRST and then brought to 2x (:1023-1026), and both constructor flags are live:
+    ``hr_dcn=False`` runs dcn_3 / forward_resblocks_3 at 2x resolution in mid_channels and up-samples afterwards (:1066-1078),
+    ``offset_prop=False`` drops the offset hand-down (:1032-1033).  The dense variant feeds each residual block the warped previous
+    state as a third input (:1311,1316,1321).  Same constructor and state_dict table as the reference (tests/golden/dsv_flags.npz);
+    forward is a composition of per-operator HIP calls."""
+
+    dense = False
+
+    def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, spynet_pretrained=None):
+        super().__init__()
+        if mid_channels < 8 or mid_channels % 8:
+            raise ValueError(f"mid_channels = {mid_channels}: needs a multiple of 8 (last_channels = mid_channels // 8, 8 deformable groups)")
+        self.device = device
+        self.mid_channels, self.last_channels = mid_channels, mid_channels // 8
+        self.dg_num, self.dk, self.max_residue_magnitude = 8, 3, 10
+        self.y_only, self.hr_dcn, self.offset_prop = y_only, hr_dcn, offset_prop
+        m, l, k = mid_channels, mid_channels // 8, (3 if self.dense else 2)
+        self.spynet = FNet(in_nc=3)
+        if spynet_pretrained is not None:
+            self.spynet.load_state_dict(torch.load(spynet_pretrained, map_location="cpu"))
+        self.dcn_0 = DCN_module(m, 8, 3, 10)
+        self.dcn_1 = DCN_module(m, 8, 3, 10, pre_offset=offset_prop, interpolate='none')
+        self.dcn_2 = DCN_module(m, 8, 3, 10, pre_offset=offset_prop, interpolate='none')
+        self.dcn_3 = (DCN_module(l, 1, 3, 10, repeat=True, pre_offset=offset_prop, interpolate='pixelshuffle') if hr_dcn
+                      else DCN_module(m, 8, 3, 10, pre_offset=offset_prop, interpolate='none'))
+        self.encoder_lr = LTE.LTE_simple_lr(m)
+        self.encoder_hr = LTE.LTE_simple_hr_single(l)
+        self.conv_tttf = conv3x3(l * 2, l)
+        self.forward_resblocks_0 = ResidualBlocksWithInputConv(m * k, m, 1)
+        self.forward_resblocks_1 = ResidualBlocksWithInputConv(m * k, m, 1)
+        self.forward_resblocks_2 = ResidualBlocksWithInputConv(m * k, m, 1)
+        self.forward_resblocks_3 = ResidualBlocksWithInputConv(l * k, l, 1) if hr_dcn else ResidualBlocksWithInputConv(m * k, m, 1)
+        self.downsample = PixelUnShufflePack_v2(l, m, 4, downsample_kernel=3)
+        self.upsample = PixelShufflePack(m, m, 2, upsample_kernel=3)
+        self.upsample_post = PixelShufflePack(m, l, 4, upsample_kernel=3)
+        self.conv_last = nn.Conv2d(l, 1 if y_only else 3, 3, 1, 1)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+
+    def compute_flow(self, lrs):
+        n, t, c, h, w = lrs.shape
+        cur, prev = lrs[:, 1:].reshape(-1, c, h, w), lrs[:, :-1].reshape(-1, c, h, w)
+        return self.spynet(cur.contiguous(), prev.contiguous()).view(n, t - 1, 2, h, w), None
+
+    init_weights = CRFP_DSV.init_weights
+
+    @torch.no_grad()
+    def forward(self, lrs, fvs, mks):
+        if lrs.dim() != 5 or not lrs.is_cuda:
+            raise RuntimeError("crfp_amd: needs CUDA/HIP tensors lrs[n,t,3,h,w], fvs[n,t,3,8h,8w], mks[n,t,1,8h,8w]")
+        n, t, _, h, w = lrs.shape
+        m, l = self.mid_channels, self.last_channels
+        lrelu = lambda x: torch.nn.functional.leaky_relu(x, 0.1)   # noqa: E731
+        lrs = lrs.float().contiguous()
+        mkf = mks.to(torch.float32)
+        flows = self.compute_flow(lrs)[0] if t > 1 else None
+        flat = lrs.reshape(n * t, 3, h, w)
+        up8_all = ops.upsample_bilinear(flat, scale_factor=8)
+        x_lr = self.encoder_lr(flat, islr=True)[2].view(n, t, m, h, w)
+        fov = fvs.float() * mkf + up8_all.view(n, t, 3, 8 * h, 8 * w) * (1.0 - mkf)
+        x_hr = self.encoder_hr(torch.cat((fov.reshape(n * t, 3, 8 * h, 8 * w), up8_all), 1), islr=True)[2].view(n, t, l, 8 * h, 8 * w)
+        blocks = (self.forward_resblocks_0, self.forward_resblocks_1, self.forward_resblocks_2)
+        dcns = (self.dcn_0, self.dcn_1, self.dcn_2)
+        rep = 2 if self.dense else 1                 # the dense variant hands the (warped) previous state to every block once more
+        state = None                                 # [n, last, 8h, 8w] after the first frame
+        outs = []
+        for i in range(t):
+            cur = self.upsample(x_lr[:, i].contiguous())
+            if i == 0:
+                z2, z8 = lrs.new_zeros(n, m, 2 * h, 2 * w), lrs.new_zeros(n, l, 8 * h, 8 * w)
+                for block in blocks:
+                    cur = block(torch.cat([cur] + [z2] * rep, 1))
+                if self.hr_dcn:
+                    cur = lrelu(self.upsample_post(cur))
+                    state = self.forward_resblocks_3(torch.cat([cur] + [z8] * rep, 1))
+                else:
+                    state = self.forward_resblocks_3(torch.cat([cur] + [z2] * rep, 1))
+            else:
+                flow = flows[:, i - 1].contiguous()
+                f2c = ops.upsample_bilinear(flow, scale_factor=2, mul=2.0)
+                f2 = f2c.permute(0, 2, 3, 1).contiguous()
+                if self.hr_dcn:      # warp at 8x, then both versions of the state to 2x (:1021-1026)
+                    f8c = ops.upsample_bilinear(flow, scale_factor=8, mul=8.0)
+                    prev8, prev8_w = state, flow_warp(state, f8c.permute(0, 2, 3, 1).contiguous())
+                    prev2_w, prev2 = self.downsample(prev8_w), self.downsample(prev8)
+                else:
+                    prev2 = self.downsample(state)
+                    prev2_w = flow_warp(prev2, f2)
+                offset = None
+                for k in range(3):
+                    aligned, offset = dcns[k](cur, prev2, prev2_w, f2c) if k == 0 else dcns[k](cur, prev2, prev2_w, f2c, offset)
+                    if not self.offset_prop:
+                        offset = None
+                    cur = blocks[k](torch.cat([cur, aligned] + ([prev2_w] if self.dense else []), 1))
+                if self.hr_dcn:
+                    cur = lrelu(self.upsample_post(cur))
+                    aligned, _ = self.dcn_3(cur, prev8, prev8_w, f8c, offset)
+                    state = self.forward_resblocks_3(torch.cat([cur, aligned] + ([prev8_w] if self.dense else []), 1))
+                else:
+                    aligned, _ = self.dcn_3(cur, prev2, prev2_w, f2c, offset)
+                    state = self.forward_resblocks_3(torch.cat([cur, aligned] + ([prev2_w] if self.dense else []), 1))
+            if not self.hr_dcn:
+                state = lrelu(self.upsample_post(state))
+            fused = ops.conv3x3_ex(state, self.conv_tttf.weight, self.conv_tttf.bias, x2=x_hr[:, i].contiguous())
+            mk = mkf[:, i]
+            state = lrelu(mk * fused + (1.0 - mk) * state)
+            lr = lrs[:, i]
+            base = (0.299 * lr[:, 0] + 0.587 * lr[:, 1] + 0.114 * lr[:, 2]).unsqueeze(1) if self.y_only else lr
+            outs.append(_run(self.conv_last, state) + ops.upsample_bilinear(base.contiguous(), scale_factor=8))
+        return torch.stack(outs, dim=1)
+
+
+class CRFP(CRFP_simple):
+    """The reference's CRFP ("v15", model/CRFP.py:1101-1385): see CRFP_simple."""
+
+    dense = True
+
+
 class MRCF_simple_v18(CRFP_DSV):
     """The reference's one-frame-per-call model (model/CRFP_test.py:2114-2478; built by test_video.py and
     test_runtime.py through ``from model import MRCF_test / MRCF_runtime``): same parameters as CRFP_DSV,

@@ -45,3 +45,8 @@ for r in rows[:30]:
     h = "-" if r["hbm_MB_per_launch_corrected"] is None else f"{r['hbm_MB_per_launch_corrected']:.1f}"
     print(f"{r['kernel']:60s} {r['calls']:6d} {r['avg_us']:9.1f} {r['pct']:6.2f} {f:>11s} {w:>11s} {h:>22s}")
 json.dump(rows, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+# which kernels these counters belong to: bench.py compares it with the library it is timing and tags the traffic figure `stale` otherwise
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from crfp_amd import _lib  # noqa: E402
+json.dump({"kernels_src_sha": _lib.kernel_source_digest(), "bench_args": os.environ.get("BENCH_ARGS", "")},
+          open(os.path.join(out, "pmc_summary.meta.json"), "w"))
