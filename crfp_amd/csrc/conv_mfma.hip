@@ -2528,6 +2528,17 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         set_error("conv_mfma %s: pixel-shuffle store supports r in {2, 4} with none/relu/lrelu (r=%d act=%d)", name, a.ps_r, a.act);
         return CRFP_E_UNSUPPORTED;
     }
+    if (a.ksplit > 0) {
+        // K split over blockIdx.z exists in ONE launch branch (the fp32-MFMA kernel over SRC_NCHW_SHIFT views, two K-quads per step) and
+        // writes raw partial sums: anything else would drop trailing chunks, apply bias / activation once per slice, or keep grid.z = N
+        bool shift_only = true;
+        for (int i = 0; i < a.nsrc; ++i) shift_only = shift_only && a.src[i].kind == SRC_NCHW_SHIFT;
+        if (!shift_only || ((a.kq >> 1) % a.ksplit) != 0 || a.act != CRFP_ACT_NONE || a.post_scale != 1.0f || a.resid || a.store != ST_NCHW) {
+            set_error("conv_mfma %s: ksplit = %d needs SRC_NCHW_SHIFT sources only, (kq / 2) %% ksplit == 0 (kq = %d), no activation / scale / residual "
+                      "and an NCHW store of the partial sums", name, a.ksplit, a.kq);
+            return CRFP_E_UNSUPPORTED;
+        }
+    }
     static const bool env_strict = precision_env_strict("CRFP_CONV_MODE");
     const bool use_split = !(env_strict || a.strict);
     bool ct2 = a.ctiles % 2 == 0;

@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -452,13 +453,32 @@ struct SideStream {
     }
 };
 constexpr int kMaxDevices = 64;
-static thread_local SideStream g_side[kMaxDevices];
+// One table per host thread, allocated on first use and kept in a process-wide registry: crfp_shutdown() walks ALL tables, so the
+// streams and events of worker threads that have exited are released as well (a thread_local destructor would have to call
+// into the HIP runtime while the process may already be tearing it down).
+struct SideTable { SideStream dev[kMaxDevices]; };
+static std::mutex g_side_mu;
+static std::vector<SideTable*> g_side_tables;
+static thread_local SideTable* g_side_tl = nullptr;
+static SideStream* side_table() {
+    if (!g_side_tl) {
+        g_side_tl = new SideTable();
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        g_side_tables.push_back(g_side_tl);
+    }
+    return g_side_tl->dev;
+}
+static void destroy_all_side_streams() {   // caller: no crfp_dsv_* call in flight on any thread
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    for (SideTable* t : g_side_tables)
+        for (int d = 0; d < kMaxDevices; ++d) t->dev[d].destroy();
+}
 // streams and events belong to the device that was current when they were created; a device index outside the table
 // gets no side stream (the caller then runs the single-stream schedule) instead of aliasing another device's slot
 static SideStream* side_slot() {   // the calling thread's table entry for the current device; creates nothing
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    return &g_side[dev];
+    return &side_table()[dev];
 }
 static SideStream* side_stream() {
     SideStream* ss = side_slot();
@@ -916,7 +936,7 @@ __global__ void round_bf16_copy_kernel(const float* __restrict__ src, float* __r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (float)(__bf16)src[i];
 }
-namespace crfp_bf16 { void shutdown_side_streams() { for (int d = 0; d < kMaxDevices; ++d) g_side[d].destroy(); } }
+namespace crfp_bf16 { void shutdown_side_streams() { destroy_all_side_streams(); } }
 #else
 namespace crfp_bf16 { void shutdown_side_streams(); }
 namespace crfp { void rt_shutdown_streams(); }   // engine_rt.hip
@@ -1234,7 +1254,7 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
 
 #ifndef CRFP_ACT_BF16
 int crfp_shutdown(void) {
-    for (int d = 0; d < kMaxDevices; ++d) g_side[d].destroy();
+    destroy_all_side_streams();
     crfp_bf16::shutdown_side_streams();
     crfp::rt_shutdown_streams();
     return 0;

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 namespace crfp {
@@ -342,12 +343,24 @@ struct Lanes {
     }
 };
 constexpr int kRtMaxDevices = 64;
-static thread_local Lanes g_lanes[kRtMaxDevices];
+// per-thread tables in a process-wide registry, as the CRFP_DSV side streams (engine.hip): crfp_shutdown() releases every thread's lanes
+struct LaneTable { Lanes dev[kRtMaxDevices]; };
+static std::mutex g_lanes_mu;
+static std::vector<LaneTable*> g_lane_tables;
+static thread_local LaneTable* g_lanes_tl = nullptr;
+static Lanes* lane_table() {
+    if (!g_lanes_tl) {
+        g_lanes_tl = new LaneTable();
+        std::lock_guard<std::mutex> lk(g_lanes_mu);
+        g_lane_tables.push_back(g_lanes_tl);
+    }
+    return g_lanes_tl->dev;
+}
 static Lanes* lanes_for_current_device() {
     static const bool on = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);   // read once
     int dev = 0;
     if (!on || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kRtMaxDevices) return nullptr;
-    Lanes& l = g_lanes[dev];
+    Lanes& l = lane_table()[dev];
     if (!l.create()) return nullptr;
     l.used = 0;
     return &l;
@@ -599,7 +612,11 @@ struct Runner {
 };
 
 }  // namespace rt
-void rt_shutdown_streams() { for (int d = 0; d < rt::kRtMaxDevices; ++d) rt::g_lanes[d].destroy(); }
+void rt_shutdown_streams() {
+    std::lock_guard<std::mutex> lk(rt::g_lanes_mu);
+    for (rt::LaneTable* t : rt::g_lane_tables)
+        for (int d = 0; d < rt::kRtMaxDevices; ++d) t->dev[d].destroy();
+}
 }  // namespace crfp
 
 using namespace crfp;

@@ -102,7 +102,7 @@ static int launch_spy_conv(const SpyConvArgs& a, int K, hipStream_t s) {
 // i.e. ONE 3x3 convolution over 9 cin "virtual" channels.  The nine shifted views are nine SRC_NCHW_SHIFT sources of the same
 // tensor (conv_mfma.hip: shifted read, own zero-padding test, ReLU on the way in), so the library's implicit-GEMM kernel
 // (v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, exact fp32 products) runs it unchanged; 81 / 49 of the taps are structural
-// zeros.  Weights are rearranged (spy_w9_kernel) and packed per call into the workspace.  Needs cin % 4 == 0.
+// zeros.  Weights are rearranged (spy_w9_kernel) and packed per call into the workspace.  Needs cin % 8 == 0 (two K-quads per step of the fp32-MFMA kernel).
 __global__ void spy_w9_kernel(const float* __restrict__ w7, float* __restrict__ w9, int cout, int cin) {
     const int total = cout * 9 * cin * 9;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {

@@ -12,6 +12,11 @@ python tools/site_table.py > gpurun_out/${TAG}_site_f32.txt 2>&1
 python tools/site_table.py --storage bf16 > gpurun_out/${TAG}_site_bf16.txt 2>&1
 bash tools/collect_profiles.sh ${TAG}_f32 > gpurun_out/${TAG}_collect_f32.log 2>&1
 BENCH_ARGS="--storage bf16" bash tools/collect_profiles.sh ${TAG}_bf16 > gpurun_out/${TAG}_collect_bf16.log 2>&1
+# BASELINE config 4 as round 4 runs it: 4 clips per rank in ONE crfp_dsv_forward_batch call (lock-step launches over all clips)
+BENCH_ARGS="--config 4" bash tools/collect_profiles.sh ${TAG}_c4 > gpurun_out/${TAG}_collect_c4.log 2>&1
+python tools/prof_batch.py f32 4 > gpurun_out/${TAG}_lockstep_vs_loop_f32.txt 2>&1
+python tools/prof_batch.py bf16 4 > gpurun_out/${TAG}_lockstep_vs_loop_bf16.txt 2>&1
+python tools/bench_batch.py both > gpurun_out/${TAG}_batch_scaling.txt 2>&1
 bash tools/collect_util.sh ${TAG}_f32_util > gpurun_out/${TAG}_util_f32.log 2>&1
 BENCH_ARGS="--storage bf16" bash tools/collect_util.sh ${TAG}_bf16_util > gpurun_out/${TAG}_util_bf16.log 2>&1
 for c in 2 3 4 5; do python - <<P

@@ -15,7 +15,7 @@ LABDEF="-DCRFP_LAB"; OBJDIR=build_lab
 if [ "${LAB:-1}" = 0 ]; then LABDEF=""; OBJDIR=build; fi   # LAB=0: a variant of the PRODUCT build (no lab switches compiled in)
 /opt/rocm/bin/hipcc $FLAGS $LABDEF $SCHED $extra -c $C/$base.hip -o $ROOT/_ab/obj/$base.$name.o 2>&1 | grep -v "not a recognized feature" | grep -E "error|warning: fail" || true
 objs=""
-for f in runtime conv_mfma conv_narrow gather resample metrics engine api spynet; do
+for f in runtime conv_mfma conv_narrow gather resample metrics engine engine_rt api spynet; do   # = SRCS of csrc/Makefile
   if [ $f = $base ]; then objs="$objs $ROOT/_ab/obj/$base.$name.o"; else objs="$objs $C/$OBJDIR/$f.o"; fi
 done
 if [[ "$extra" == *CRFP_ACT_BF16_VARIANT* ]]; then echo "bf16 variants: build by hand"; fi
