@@ -1757,6 +1757,202 @@ __global__ __launch_bounds__(P2_NT, 2) void conv3x3_bf16_pair_kernel(const ConvA
     ec.xend = min(W, tx0 + P2_OW);
     conv_epilogue<1, 2, 1, 2>(ec, acc, 0, tx0, ty0, wave, j, h);
 }
+
+// ---------------------------------------------------------------- LDS-DMA ring form (round 4): an experiment that LOST its A/B -- compiled only with
+// -DCRFP_BF16_RING (make EXTRA=-DCRFP_BF16_RING), then enabled per process with CRFP_BF16_RING=<min workgroups>.  Bit-identical to the shipped
+// kernels, but 16.3 us per clip against 9.3 for a 32 -> 32 conv in a 4-clip lock-step batch (profiles/r04_bf16_ring_ab.txt): with
+// every phase removed (no DMA, no MFMA, no stores) the barrier-per-13-KB-unit skeleton alone costs 8 us per clip.
+#ifdef CRFP_BF16_RING
+// What bounds the bf16 convs in throughput mode (a lock-step batch: several rounds of workgroups per launch) is memory-level
+// parallelism: a one-tile workgroup holds its halo tile in flight during its prologue and nothing afterwards, and its weights are
+// re-staged for every tile.  This form is persistent and role-split: a workgroup = 4 consumer waves + 1 loader wave walks the tiles of its
+// band; the unit of work is (tile, 16-channel chunk) = 4 K-quads x 6 halo rows x 68 pixels = 13 KB, which the loader wave brings into a
+// D-deep LDS ring with `global_load_lds_dwordx4` (no VGPR round trip, no conversion: the bf16 quads go to LDS as they lie in HBM) up to
+// D - 1 units ahead; ALL chunks' A fragments stay in LDS for the life of the workgroup.  One s_barrier per unit: the loader passes it
+// after `s_waitcnt vmcnt(16 (D - 2))` (its own counter holds nothing but the DMAs: the consumers' epilogue stores cannot disturb the
+// count), the consumers after their MFMAs of the previous unit -- which is also what frees that unit's slot for the next DMA.
+// LDS image of a unit: [halo row][quad of the chunk][34 pieces of 16 B = pixels tx0 - 2 .. tx0 + 65]; a piece = two adjacent pixels of
+// one quad plane = 16 contiguous bytes in HBM.  Pieces outside the image (the 3x3 zero padding) are loaded from a clamped address and
+// zeroed by the loader before it releases the unit.  Same K order, same accumulation order, same epilogue as conv3x3_bf16_kernel<1>:
+// identical values.
+constexpr int RG_PC = 34, RG_ROWS = 6;
+constexpr int RG_PIECES = RG_ROWS * 4 * RG_PC;        // 816 pieces per unit
+constexpr int RG_UNIT = RG_PIECES * 16;               // 13 056 bytes
+constexpr int RG_PPI = 51, RG_NDMA = 16;              // 16 wave-instructions of 51 pieces = 1.5 lines of 34: a window never touches a third line
+constexpr int RG_WCH = 9 * 64 * 16;                   // bytes of one chunk's A fragments
+constexpr int RG_NT = 320;
+
+template <int D>
+__global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvArgs a, int wgs_per_item, int probe) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
+    unsigned char* const ring = rg_lds;                        // D units
+    bf16x8* const wl = reinterpret_cast<bf16x8*>(rg_lds + D * RG_UNIT);   // [chunk][tap][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int H = a.H, W = a.W, n = blockIdx.z;
+    const int tiles_x = (W + TW - 1) / TW, ntiles = tiles_x * ((H + 3) / 4);
+    const int nch = a.kq >> 2;
+    if (probe & 8) return;   // timing probe: launch + dispatch only
+    // this workgroup's tiles: XCD x walks one contiguous band of the tile list (xcd_band_tile), split evenly among the XCD's workgroups
+    const int G = wgs_per_item;                                 // a multiple of 8
+    const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, wpx = G >> 3;
+    const int bq = ntiles >> 3, br = ntiles & 7;
+    const int band0 = xcd * bq + min(xcd, br), blen = bq + (xcd < br ? 1 : 0);
+    const int t_first = band0 + (int)((long long)blen * wi / wpx), t_end = band0 + (int)((long long)blen * (wi + 1) / wpx);
+    const int ntl = t_end - t_first, total = ntl * nch;
+    {   // A fragments of every chunk: once per workgroup, all loads in flight together (nch <= 4: at most 2 304 vectors / 320 threads = 8 each)
+        const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit16);
+        const int nw = nch * 9 * 64;
+        bf16x8 wr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[k] = wp[min(tid + RG_NT * k, nw - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (tid + RG_NT * k < nw) wl[tid + RG_NT * k] = wr[k];
+    }
+    __syncthreads();
+    if (total <= 0) return;
+
+    if (wave == 4) {
+        // ------------------------------------------------------------ loader
+        // DMA instruction k of a unit covers pieces 51 k .. 51 k + 50 of the slot = a (row, quad) line of 34 and half of the next one, or the
+        // second half of a line and the whole next one: which quad a lane loads from is a select between two SCALAR-held plane pointers (a
+        // per-lane index into a.qd[] would become vector loads from the kernarg segment, which count on the same vmcnt as the DMAs).
+        // Per lane and k, once per workgroup: halo row (-1 .. 4), first pixel of the piece (-2 .. 64) and their offset inside a plane.
+        typedef __attribute__((address_space(3))) void* lds_vp;
+        typedef const __attribute__((address_space(1))) void* glb_vp;
+        constexpr int QF = kQuadBytes / 4;              // floats per pixel quad
+        const int rs = a.qd[0].rs;                      // floats per plane row: the same for every K quad (conv_ring_eligible)
+        int prow[RG_NDMA], pcol[RG_NDMA], rel[RG_NDMA];
+#pragma unroll
+        for (int k = 0; k < RG_NDMA; ++k) {
+            const int P0 = k * RG_PPI, lineA = P0 / RG_PC, offA = P0 - lineA * RG_PC, nA = RG_PC - offA;   // compile-time
+            const int lineB = lineA + 1 < RG_ROWS * 4 ? lineA + 1 : lineA;
+            const bool inB = lane >= nA;
+            prow[k] = (inB ? lineB / 4 : lineA / 4) - 1;
+            pcol[k] = 2 * (inB ? lane - nA : offA + lane) - 2;
+            rel[k] = prow[k] * rs + pcol[k] * QF;
+        }
+        // (tile, chunk) cursors of the unit being issued and of the unit being released: incremented, never divided
+        struct Cur { int tx0, ty0, ch; };
+        const int wtiles = tiles_x * TW;
+        auto first = [&]() { Cur c; c.tx0 = (t_first % tiles_x) * TW; c.ty0 = (t_first / tiles_x) * 4; c.ch = 0; return c; };
+        auto next = [&](Cur& c) {
+            if (++c.ch == nch) { c.ch = 0; c.tx0 += TW; if (c.tx0 >= wtiles) { c.tx0 = 0; c.ty0 += 4; } }
+        };
+        auto interior = [&](const Cur& c) { return c.ty0 > 0 && c.ty0 + 5 <= H && c.tx0 > 0 && c.tx0 + 66 <= W; };
+        auto issue = [&](int u, const Cur& c) {
+            unsigned char* slot = ring + (u % D) * RG_UNIT;
+            const QuadDesc* qd = a.qd + 4 * c.ch;
+            const float* qb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qb[q] = qd[q].base + (long long)n * qd[q].bstride;
+            if (interior(c)) {          // wave-uniform: plane pointer of the tile origin + the lane's constant offset
+                const long long torg = (long long)c.ty0 * rs + c.tx0 * QF;
+#pragma unroll
+                for (int k = 0; k < RG_NDMA; ++k) {
+                    const int P0 = k * RG_PPI, lineA = P0 / RG_PC, offA = P0 - lineA * RG_PC, nA = RG_PC - offA;
+                    const int lineB = lineA + 1 < RG_ROWS * 4 ? lineA + 1 : lineA;
+                    const float* g = (lane >= nA ? qb[lineB & 3] : qb[lineA & 3]) + torg + rel[k];
+                    if (!(probe & 1) && lane < RG_PPI && P0 + lane < RG_PIECES) __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)(slot + P0 * 16), 16, 0, 0);
+                }
+            } else {                    // a tile at the image border: clamped addresses, fix() zeroes what lies outside
+#pragma unroll
+                for (int k = 0; k < RG_NDMA; ++k) {
+                    const int P0 = k * RG_PPI, lineA = P0 / RG_PC, offA = P0 - lineA * RG_PC, nA = RG_PC - offA;
+                    const int lineB = lineA + 1 < RG_ROWS * 4 ? lineA + 1 : lineA;
+                    const int gy = min(max(c.ty0 + prow[k], 0), H - 1), gx = min(max(c.tx0 + pcol[k], 0), W - 1);
+                    const float* g = (lane >= nA ? qb[lineB & 3] : qb[lineA & 3]) + (long long)gy * rs + gx * QF;
+                    if (!(probe & 1) && lane < RG_PPI && P0 + lane < RG_PIECES) __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)(slot + P0 * 16), 16, 0, 0);
+                }
+            }
+        };
+        // the zero padding: pieces (or halves of pieces) outside the image, zeroed after the unit's DMAs have landed
+        auto fix = [&](int u, const Cur& c) {
+            if (interior(c)) return;
+            unsigned char* slot = ring + (u % D) * RG_UNIT;
+#pragma unroll
+            for (int k = 0; k < RG_NDMA; ++k) {
+                const int P0 = k * RG_PPI;
+                const int gy = c.ty0 + prow[k], gx = c.tx0 + pcol[k];
+                const bool on = lane < RG_PPI && P0 + lane < RG_PIECES, vy = gy >= 0 && gy < H;
+                const bool v0 = vy && gx >= 0 && gx < W, v1 = vy && gx + 1 >= 0 && gx + 1 < W;
+                cu32x2* dst = reinterpret_cast<cu32x2*>(slot + (P0 + lane) * 16);
+                if (on && !v0) dst[0] = cu32x2{0u, 0u};
+                if (on && !v1) dst[1] = cu32x2{0u, 0u};
+            }
+        };
+        Cur ci = first(), cw = ci;
+        for (int u = 0; u < D - 1 && u < total; ++u) { issue(u, ci); next(ci); }
+        for (int u = 0; u < total; ++u) {
+            // DMAs younger than unit u's: those of units u + 1 .. min(u + D - 2, total - 1)
+            const int ahead = min(D - 2, total - 1 - u);
+            static_assert(RG_NDMA == 16 && D <= 4, "the counted waits below");
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fix(u, cw);
+            next(cw);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // unit u released; every consumer is done with unit u - 1
+            if (u + D - 1 < total) { issue(u + D - 1, ci); next(ci); }          // ... whose slot the next DMA takes
+        }
+        asm volatile("s_barrier" ::: "memory");                                  // the consumers' closing barrier
+        return;
+    }
+
+    // ---------------------------------------------------------------- consumers (waves 0-3: one output row of 64 pixels each)
+    const EpiCtx ec = epi_ctx(a, n);
+    const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
+    float4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = bp[2 * g + h];
+    f32x16 acc[1][2];
+    int tx0 = (t_first % tiles_x) * TW, ty0 = (t_first / tiles_x) * 4;
+    for (int tl = 0; tl < ntl; ++tl, tx0 += TW) {
+        if (tx0 >= tiles_x * TW) { tx0 = 0; ty0 += 4; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // accumulators start at the bias
+            const float4 bq4 = bias4[g];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                acc[0][pt][4 * g + 0] = bq4.x; acc[0][pt][4 * g + 1] = bq4.y;
+                acc[0][pt][4 * g + 2] = bq4.z; acc[0][pt][4 * g + 3] = bq4.w;
+            }
+        }
+        for (int ch = 0; ch < nch; ++ch) {
+            const int u = tl * nch + ch;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // unit u has landed (the loader waited for it)
+            const unsigned char* slot = ring + (u % D) * RG_UNIT;
+            const bf16x8* wc = wl + ch * 9 * 64;
+            if (probe & 2) continue;   // timing probe: no operand reads, no MFMAs
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const bf16x8 wa = wc[tap * 64 + lane];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    // lane half h: quads 2h, 2h + 1 of the chunk at pixel tx0 + 32 pt + j + kx - 1 = image column + 2 in the slot
+                    const unsigned char* e = slot + (((wave + ky) * 4 + 2 * h) * RG_PC) * 16 + (pt * 32 + j + kx + 1) * 8;
+                    const cu32x2 lo = *reinterpret_cast<const cu32x2*>(e), hi = *reinterpret_cast<const cu32x2*>(e + RG_PC * 16);
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    const bf16x8 bq8 = __builtin_bit_cast(bf16x8, u32x4_t{lo.x, lo.y, hi.x, hi.y});
+                    acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bq8, acc[0][pt], 0, 0, 0);
+                }
+            }
+        }
+        if (!(probe & 4)) conv_epilogue<1, 2, 1, 2>(ec, acc, 0, tx0, ty0, wave, j, h);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // pairs with the loader's closing barrier
+}
+
+// all K quads are whole bf16 quads with unit pixel stride (SRC_Q4), in whole 16-channel chunks, one cout tile
+static bool conv_ring_eligible(const ConvArgs& a) {
+    if (a.ctiles != 1 || (a.kq & 3) || a.kq < 4 || a.kq > 16 || a.W < 2) return false;
+    for (int q = 0; q < a.kq; ++q)
+        if (a.qd[q].mask != 15 || a.qd[q].cs != kQuadBytes / 4 || a.qd[q].rs != a.qd[0].rs) return false;
+    return true;
+}
+#endif  // CRFP_BF16_RING
 #endif  // CRFP_ACT_BF16
 
 #ifdef CRFP_LAB   // experiments that lose to conv3x3_split_kernel<1,1,2>: built only into the lab library (make lab)
@@ -2659,6 +2855,33 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // batch of clips is several rounds, where tile granularity no longer matters and the 4-wave kernel's four workgroups per CU overlap
         // more of each other's load / MFMA / store phases (round 4, same box, 4 clips: res.main0 15.1 -> 14.1 us per clip, conv_fuse 14.7 -> 14.0,
         // conv1 9.9 -> 9.2; CRFP_BF16_X8_MAX_WGS overrides the threshold for A/B runs)
+#ifdef CRFP_BF16_RING
+        // LDS-DMA ring form (see the kernel): CRFP_BF16_RING=<min workgroups of the one-tile form> enables it for launches at least that large
+        static const int ring_min = getenv("CRFP_BF16_RING") ? atoi(getenv("CRFP_BF16_RING")) : (1 << 30);
+        if ((long long)a.N * tiles >= ring_min && conv_ring_eligible(am)) {
+            const int nch = a.kq >> 2;
+            const int D = nch <= 2 ? 4 : 3;
+            const size_t lds = (size_t)D * RG_UNIT + (size_t)nch * RG_WCH;
+            static const int ring_wgs = getenv("CRFP_BF16_RING_WGS") ? atoi(getenv("CRFP_BF16_RING_WGS")) : 0;
+            static const int ring_probe = getenv("CRFP_BF16_RING_PROBE") ? atoi(getenv("CRFP_BF16_RING_PROBE")) : 0;   // timing probes: results wrong by design
+            int G = ring_wgs > 0 ? ring_wgs : (int)((512 + a.N - 1) / a.N);   // ~2 workgroups per CU over the whole launch
+            G = (G + 7) / 8 * 8;
+            if (G > tiles) G = tiles / 8 * 8;
+            if (G >= 8) {
+                if (D == 4) {
+                    static const int once4 = hipFuncSetAttribute((const void*)conv3x3_bf16_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)once4;
+                    conv3x3_bf16_ring_kernel<4><<<dim3(G, 1, a.N), RG_NT, lds, s>>>(am, G, ring_probe);
+                } else {
+                    static const int once3 = hipFuncSetAttribute((const void*)conv3x3_bf16_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)once3;
+                    conv3x3_bf16_ring_kernel<3><<<dim3(G, 1, a.N), RG_NT, lds, s>>>(am, G, ring_probe);
+                }
+                CRFP_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+#endif
         static const int x8_max_wgs = getenv("CRFP_BF16_X8_MAX_WGS") ? atoi(getenv("CRFP_BF16_X8_MAX_WGS")) : 512;
         if (a.ctiles == 1 && ((a.kq >> 2) & 1) == 0 && (long long)a.N * ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH) <= x8_max_wgs) {
             const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH);
