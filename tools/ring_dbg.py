@@ -1,3 +1,5 @@
+"""Bit-for-bit check of the LDS-DMA ring conv build (make -C crfp_amd/csrc EXTRA=-DCRFP_BF16_RING; CRFP_BF16_RING=1) against the shipped
+kernels: runs a 2-frame bf16 clip in child processes with and without the switch and compares workspace intermediates."""
 import sys, os, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
