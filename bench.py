@@ -80,17 +80,22 @@ def kernel_family(name: str) -> str:
 ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_split8_kernel", "conv3x3_pair_kernel", "conv3x3_mfma_kernel",
                                   "conv3x3_bf16_kernel", "conv3x3_bf16x8_kernel", "conv3x3_q16_kernel"),
                  "conv3x3_narrow": ("conv3x3_narrow_kernel", "conv3x3_narrow_pair_kernel"),
-                 "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel<false>", "dcn3_kernel"), "dcnv2_shared_c4_fused": ("dcn3_kernel<true>",),
+                 "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel<false",), "dcnv2_shared_c4_fused": ("dcn3_kernel<true",),
                  "flow_warp_q4_c4": ("flow_warp_p4_kernel",), "flow_warp_q4_c32": ("flow_warp_p4_kernel",),
                  "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "flow_warp_q4_c32+c24": ("flow_warp_p4_dual_kernel",),
                  "hr_prep_up8_blend": ("hr_prep_kernel",), "offset_mask_conv+dcnv2_g8_fused": ("dcn_fused_kernel",)}
 
 
-def pmc_traffic(family: str, storage: str, lr=(180, 320)):
+def pmc_traffic(family: str, storage: str, lr=(180, 320), clips_per_call: int = 1):
     """{"bytes_per_launch", "source", "measured_in_run": False} from the committed rocprofv3 PMC summary (2 x FETCH_SIZE +
     WRITE_SIZE per MI355X_MICROARCH.md, separate --pmc passes, tools/collect_profiles.sh) of the same workload; None when
     no summary exists for this storage mode.  It is a constant as far as this run is concerned -- hence the tag."""
-    fname = "pmc_summary_latest.json" if storage == "f32" else "pmc_summary_latest_bf16.json"
+    # one committed summary per launch shape: fp32 / bf16 one-clip calls, and BASELINE config 4's lock-step call of 4 bf16 clips (its
+    # launches carry 4 clips each, so bytes per launch are those of 4 clips)
+    fname = ("pmc_summary_latest_c4.json" if (storage == "bf16" and clips_per_call == 4) else
+             "pmc_summary_latest.json" if storage == "f32" else "pmc_summary_latest_bf16.json")
+    if clips_per_call not in (1, 4) or (clips_per_call == 4 and storage != "bf16"):
+        return None
     path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path) or family not in ROCPROF_NAMES or tuple(lr) != (180, 320):
         return None   # the committed counter passes ran the 180x320 geometry; bytes per launch do not transfer to another one
@@ -344,7 +349,7 @@ def main():
                                   "frac_of_per_layer_roof": t_roof / t_act,
                                   "frac_mfma": dom["TFLOPs"] / peak, "frac_hbm": dom["GBps"] / HBM_PEAK_GBS,
                                   "achieved_TFLOPs": dom["TFLOPs"], "mfma_peak_TFLOPs": peak, "achieved_GBps": dom["GBps"],
-                                  "traffic": pmc_traffic(dom["kernel"], storage, (h, w)), "avg_launch_us": dom["avg_us"],
+                                  "traffic": pmc_traffic(dom["kernel"], storage, (h, w), bclips), "avg_launch_us": dom["avg_us"],
                                   "algorithmic_flops_per_launch": domf["flops"] / domf["launches"],
                                   "algorithmic_bytes_per_launch": domf["bytes"] / domf["launches"],
                                   "frac_of_fp32_mfma_peak": dom["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
@@ -354,7 +359,7 @@ def main():
                                           "max(MFMA time, HBM time) / measured time"}
         else:
             result["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"], storage, (h, w)),
+                                  "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"], storage, (h, w), bclips),
                                   "avg_launch_us": dom["avg_us"],
                                   "algorithmic_bytes_per_launch": domf["bytes"] / domf["launches"]}
         fz = fam.get("offset_mask_conv+dcnv2_g8_fused")
@@ -368,7 +373,7 @@ def main():
                                    "avg_us": 1e3 * fz["ms"] / fz["launches"], "achieved": fz["flops"] / fs / 1e12, "peak": peak,
                                    "unit": "TFLOP/s", "frac": fz["flops"] / fs / 1e12 / peak,
                                    "algorithmic_GBps": fz["bytes"] / fs / 1e9,
-                                   "traffic": pmc_traffic("offset_mask_conv+dcnv2_g8_fused", storage, (h, w)),
+                                   "traffic": pmc_traffic("offset_mask_conv+dcnv2_g8_fused", storage, (h, w), bclips),
                                    "hbm_bytes_not_moved_per_launch": 2.0 * px2 * 216 * 4,
                                    "note": "offset / mask head + dcn_g8 in one launch, bit-identical to the two-kernel path "
                                            "(CRFP_DCN_FUSED=0 restores it: conv_mfma:dcn.offset_mask + dcnv2_g8_c32); flops = conv + DCN GEMM + "
@@ -387,7 +392,7 @@ def main():
                                   "ms_per_step": 1e3 * gs / psteps,
                                   "per_kernel": {n: {"avg_us": 1e3 * f["ms"] / f["launches"], "GBps": f["bytes"] / (f["ms"] * 1e-3) / 1e9,
                                                      "frac": f["bytes"] / (f["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                     "traffic": pmc_traffic(n, storage, (h, w))} for n, f in gat.items()},
+                                                     "traffic": pmc_traffic(n, storage, (h, w), bclips)} for n, f in gat.items()},
                                   "note": "dcn_3 priced at its compact 2+1 offset/mask channels, not the 9x-replicated API tensors; "
                                           "bf16 storage: feature bytes halve, offsets / masks / flow stay fp32"
                                           + ("; dcn_g8 (dcn_0/1/2) runs inside the fused kernel reported under dcn_fused and is not "
