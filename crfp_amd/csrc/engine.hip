@@ -573,10 +573,13 @@ struct Runner {
     // which 2x-resolution conv pairs run as one launch: bf16 storage only (the fp32 build's intermediate does not fit LDS, conv_mfma.hip),
     // and one clip per call only: the pair kernel (two 77 KB workgroups per CU, 1.25x the MFMAs for conv A's halo) wins where a launch is a
     // single round of workgroups (39.5 -> 34.5 and 31.9 -> 25.3 us per clip, round 3); in a lock-step batch the two single convs on the
-    // 4-wave kernel take 26.0 and 19.9 us per clip against the pairs' 29.0 and 19.9 (round 4, 4 clips, same box).  CRFP_CONV_PAIR=0 / 2: never / always
+    // 4-wave kernel take 26.0 and 19.9 us per clip against the pairs' 29.0 and 19.9 (round 4, 4 clips, same box), and so do the 540 x 960 maps of
+    // one 4K clip (1 088 pair tiles: 572 vs 562 frames/s).  So: pairs while the launch is at most one round of the 512 slots.
+    // CRFP_CONV_PAIR=0 / 2: never / always
     bool pair_convs() const {
         static const int mode = !kActBf16 ? 0 : (getenv("CRFP_CONV_PAIR") ? atoi(getenv("CRFP_CONV_PAIR")) : 1);   // read once
-        return mode == 2 || (mode == 1 && L.B == 1);
+        const long long pair_tiles = (long long)L.B * ((2 * L.w + 61) / 62) * ((2 * L.h + 7) / 8);   // 8 x 62 output tiles of the pair kernel
+        return mode == 2 || (mode == 1 && pair_tiles <= 512);
     }
     // plain Q4 -> Q4 conv on whole tensors
     void mfma_q(int id, int N, const Q4& in, const Q4& out) {
