@@ -1318,8 +1318,10 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     const double px = (double)a.N * a.H * a.W;
     ProfScope prof("offset_mask_conv+dcnv2_g8_fused", s, px * (8.0 + (32 + 32 + 32) * sizeof(act_t)),
                    2.0 * px * 32 * 216 * 9 + 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
-    // 8-wave workgroups: 91.9 vs 97.0 us per launch same-box against <4>
-    dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
+    // 8-wave workgroups: 91.9 vs 97.0 us per launch same-box against <4> (one clip); CRFP_DCN_FUSE_NW=4: A/B knob for multi-round launches
+    static const int nw4 = getenv("CRFP_DCN_FUSE_NW") && atoi(getenv("CRFP_DCN_FUSE_NW")) == 4;
+    if (nw4) dcn_fused_kernel<4><<<dim3((a.W + 31) / 32, (a.H + 3) / 4, a.N), 256, 0, s>>>(a);
+    else dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
     CRFP_CHECK_LAUNCH();
     return 0;
 }

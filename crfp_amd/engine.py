@@ -185,7 +185,12 @@ class DSVEngine:
 
     def stream_frame(self, lr, fv, mk, fg=None):
         """lr[3,h,w], fv[3,8h,8w], mk[1,8h,8w], optional regional mask fg[1,8h,8w] -> [3|1,8h,8w]; the first
-        call after clear_states() starts a sequence."""
+        call after clear_states() starts a sequence.
+        With ``inputs_resident = True`` the library reads lr / fv / mk on its own side stream WITHOUT waiting for the caller's stream
+        (that is the point: frame i's flow network runs beside frame i - 1).  The tensors must therefore be complete when this
+        method is called: nothing still queued on the current torch stream may be writing them (a non_blocking host-to-device copy, a
+        decode or crop kernel, an in-place op) -- synchronise such producers first, or leave the flag off.  Only dtype and contiguity
+        can be checked here."""
         if self.inputs_resident:
             # a conversion here would be a kernel on this stream that is still writing the input when the library starts reading it
             for name, t_, dt in (("lr", lr, (torch.float32,)), ("fv", fv, (torch.float32,)), ("mk", mk, (torch.bool, torch.uint8))):
