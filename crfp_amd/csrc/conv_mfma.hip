@@ -30,6 +30,13 @@
 namespace CRFP_NS {
 
 constexpr int TW = 64, LW = TW + 2;
+// activation loads of the implicit-GEMM kernels.  -DCRFP_CONV_NT (A/B builds): non-temporal, so that a layer's INPUT does not displace its
+// OUTPUT from the XCD's 4 MB L2 -- with the XCD-banded tile order the next layer's workgroups run on the XCD that wrote their input.
+#ifdef CRFP_CONV_NT
+#define CRFP_LDACT(T, p) __builtin_nontemporal_load(reinterpret_cast<const T*>(p))
+#else
+#define CRFP_LDACT(T, p) (*reinterpret_cast<const T*>(p))
+#endif
 #ifndef CRFP_TAP_UNROLL
 #define CRFP_TAP_UNROLL 3
 #endif
@@ -747,10 +754,10 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
         CRFP_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) CRFP_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                   \
         CRFP_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) CRFP_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                   \
         _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                                 \
-            rq0[t] = *reinterpret_cast<const f32x4*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
-            rq1[t] = *reinterpret_cast<const f32x4*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
-            rq2[t] = *reinterpret_cast<const f32x4*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
-            rq3[t] = *reinterpret_cast<const f32x4*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
+            rq0[t] = CRFP_LDACT(f32x4, qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
+            rq1[t] = CRFP_LDACT(f32x4, qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
+            rq2[t] = CRFP_LDACT(f32x4, qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
+            rq3[t] = CRFP_LDACT(f32x4, qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
         }                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < NWS; ++k) {                                                 \
             const int idx = min(tid + 256 * k, CT * WPC - 1);                                             \
@@ -977,10 +984,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         CRFP_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) CRFP_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                   \
         CRFP_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) CRFP_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                   \
         _Pragma("unroll") for (int t = 0; t < S8_NIN; ++t) {                                              \
-            rq0[t] = *reinterpret_cast<const f32x4*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
-            rq1[t] = *reinterpret_cast<const f32x4*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
-            rq2[t] = *reinterpret_cast<const f32x4*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
-            rq3[t] = *reinterpret_cast<const f32x4*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
+            rq0[t] = CRFP_LDACT(f32x4, qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
+            rq1[t] = CRFP_LDACT(f32x4, qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
+            rq2[t] = CRFP_LDACT(f32x4, qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
+            rq3[t] = CRFP_LDACT(f32x4, qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
         }                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < S8_NWS; ++k) {                                              \
             const int idx = min(tid + S8_NT * k, S8_WPC - 1);                                             \
@@ -1151,10 +1158,10 @@ __global__ __launch_bounds__(S8P_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         S8P_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) S8P_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                     \
         S8P_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) S8P_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                     \
         _Pragma("unroll") for (int t = 0; t < S8P_NIN; ++t) {                                             \
-            rq0[t] = *reinterpret_cast<const f32x4*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
-            rq1[t] = *reinterpret_cast<const f32x4*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
-            rq2[t] = *reinterpret_cast<const f32x4*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
-            rq3[t] = *reinterpret_cast<const f32x4*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
+            rq0[t] = CRFP_LDACT(f32x4, qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);                \
+            rq1[t] = CRFP_LDACT(f32x4, qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);                \
+            rq2[t] = CRFP_LDACT(f32x4, qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);                \
+            rq3[t] = CRFP_LDACT(f32x4, qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);                \
         }                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < S8P_NWS; ++k) {                                             \
             const int idx = min(tid + S8P_NT * k, S8_WPC - 1);                                            \
@@ -1343,10 +1350,10 @@ __global__ __launch_bounds__(256, RPW == 1 ? 4 : 3) void conv3x3_bf16_kernel(con
         CRFP_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) CRFP_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                   \
         CRFP_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) CRFP_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                   \
         _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                                 \
-            rq0[t] = *reinterpret_cast<const cu32x2*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);               \
-            rq1[t] = *reinterpret_cast<const cu32x2*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);               \
-            rq2[t] = *reinterpret_cast<const cu32x2*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);               \
-            rq3[t] = *reinterpret_cast<const cu32x2*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);               \
+            rq0[t] = CRFP_LDACT(cu32x2, qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);               \
+            rq1[t] = CRFP_LDACT(cu32x2, qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);               \
+            rq2[t] = CRFP_LDACT(cu32x2, qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);               \
+            rq3[t] = CRFP_LDACT(cu32x2, qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);               \
         }                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < NWS; ++k) {                                                 \
             const int idx = min(tid + 256 * k, WPC - 1);                                                  \
@@ -1469,7 +1476,7 @@ __global__ __launch_bounds__(B8_NT, 2) void conv3x3_bf16x8_kernel(const ConvArgs
                 const float* qb_ = d_.base + (long long)n * d_.bstride;                                   \
                 qm[c2][q] = d_.mask;                                                                      \
                 _Pragma("unroll") for (int t = 0; t < B8_NIN; ++t)                                        \
-                    rq[c2][q][t] = *reinterpret_cast<const cu32x2*>(qb_ + cgy[t] * d_.rs + cgx[t] * d_.cs); \
+                    rq[c2][q][t] = CRFP_LDACT(cu32x2, qb_ + cgy[t] * d_.rs + cgx[t] * d_.cs); \
             }                                                                                             \
         }                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < B8_NWS; ++k) {                                              \
@@ -1624,10 +1631,10 @@ __global__ __launch_bounds__(P2_NT, 2) void conv3x3_bf16_pair_kernel(const ConvA
         CRFP_QDESC(qb0, qrs0, qcs0, qm0, 0, CH) CRFP_QDESC(qb1, qrs1, qcs1, qm1, 1, CH)                   \
         CRFP_QDESC(qb2, qrs2, qcs2, qm2, 2, CH) CRFP_QDESC(qb3, qrs3, qcs3, qm3, 3, CH)                   \
         _Pragma("unroll") for (int t = 0; t < P2_NIN; ++t) {                                              \
-            rq0[t] = *reinterpret_cast<const cu32x2*>(qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);               \
-            rq1[t] = *reinterpret_cast<const cu32x2*>(qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);               \
-            rq2[t] = *reinterpret_cast<const cu32x2*>(qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);               \
-            rq3[t] = *reinterpret_cast<const cu32x2*>(qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);               \
+            rq0[t] = CRFP_LDACT(cu32x2, qb0 + cgy[t] * qrs0 + cgx[t] * qcs0);               \
+            rq1[t] = CRFP_LDACT(cu32x2, qb1 + cgy[t] * qrs1 + cgx[t] * qcs1);               \
+            rq2[t] = CRFP_LDACT(cu32x2, qb2 + cgy[t] * qrs2 + cgx[t] * qcs2);               \
+            rq3[t] = CRFP_LDACT(cu32x2, qb3 + cgy[t] * qrs3 + cgx[t] * qcs3);               \
         }                                                                                                 \
         _Pragma("unroll") for (int k = 0; k < P2_NWS; ++k) {                                              \
             const int idx = min(tid + P2_NT * k, P2_WPC - 1);                                             \

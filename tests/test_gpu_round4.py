@@ -162,3 +162,49 @@ def test_batch_overflow_poisons_only_the_clip_it_happened_in():
     assert torch.isfinite(out2[0]).all() and torch.isfinite(out2[2]).all()
     eng.on_overflow = "poison"
     assert torch.equal(eng.forward(lrs, fvs, mks), ref) and not eng.overflowed()   # the words are cleared by the next call
+
+
+def test_batch_forward_is_graph_capturable_and_replays_bit_exact():
+    """crfp_dsv_forward_batch (two-stream schedule over a 3-clip lock-step batch) captured into a HIP graph once and replayed on new
+    inputs equals the eager call bit for bit -- the batch entry point keeps the clip entry point's stream contract."""
+    eng, _ = _engine("f32")
+    a = _batch((101, 102, 103), 3, 24, 40, 64)
+    b = _batch((104, 105, 106), 3, 24, 40, 64)
+    eager = [eng.forward(*x).clone() for x in (a, b)]      # also warms up the side stream and its events
+    L, Fv, M = (x.clone() for x in a)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = eng.forward(L, Fv, M)
+    for i in (1, 0, 1):
+        src = (a, b)[i]
+        L.copy_(src[0]); Fv.copy_(src[1]); M.copy_(src[2])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager[i])
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_two_batches_in_flight_on_two_streams_are_bit_exact(storage):
+    """Two lock-step calls in flight on two caller streams (two engines = two workspaces, one shared side stream per host thread):
+    every clip equals its sequential result bit for bit (concurrent dispatches must not disturb each other)."""
+    from crfp_amd import synth
+    from crfp_amd.engine import DSVEngine
+    sd = {k: T(v.copy()) for k, v in synth.make_state_dict(7).items()}
+    engs = [DSVEngine(sd, dev(), storage=storage) for _ in range(2)]
+    data = [_batch(range(110 + 3 * g, 113 + 3 * g), 3, 36, 64, 64) for g in range(2)]
+    seq = [engs[0].forward(*d).clone() for d in data]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev()) for _ in range(2)]
+    for _ in range(4):
+        outs = [None, None]
+        cur = torch.cuda.current_stream()
+        for s in streams:
+            s.wait_stream(cur)
+        for g in range(2):
+            with torch.cuda.stream(streams[g]):
+                outs[g] = engs[g].forward(*data[g])
+        for s in streams:
+            cur.wait_stream(s)
+        torch.cuda.synchronize()
+        assert all(torch.equal(outs[g], seq[g]) for g in range(2))
