@@ -718,7 +718,7 @@ struct Runner {
             if (parts & 1) encode_lr(B * t, lq, lr_f, 0);
             ovf_add = 1;
             ovf_skip0 = 1;         // the pair whose current frame opens a clip straddles two clips: never read, raises nothing
-            if ((parts & 2) && B * t > 1) fnet(B * t - 1, lq + lqf, lr_f, lq, lr_f, F(L.flow_lr) + fq);
+            if ((parts & 2) && t > 1) fnet(B * t - 1, lq + lqf, lr_f, lq, lr_f, F(L.flow_lr) + fq);   // one-frame clips need no flow
             return;
         }
         ovf_div = 0;               // per-clip passes: every item of a launch belongs to clip b

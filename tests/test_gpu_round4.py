@@ -65,6 +65,18 @@ def test_lockstep_batch_is_bit_identical_to_one_clip_calls(storage, n, t, h, w):
     assert not eng.overflowed()
 
 
+def test_lockstep_batch_of_one_frame_clips_and_small_maps():
+    """t = 1 (no flow network, first-frame branch only) and the smallest legal map (8 x 8 LR) in a batch of 5."""
+    for storage in ("f32", "bf16"):
+        eng, _ = _engine(storage)
+        for (n, t, h, w) in ((5, 1, 24, 40), (5, 2, 8, 8)):
+            lrs, fvs, mks = _batch(range(200, 200 + n), t, h, w, 32)
+            eng.batch_mode = "loop"
+            ref = eng.forward(lrs, fvs, mks).clone()
+            eng.batch_mode = "lockstep"
+            assert torch.equal(eng.forward(lrs, fvs, mks), ref), (storage, n, t, h, w)
+
+
 def test_lockstep_batch_matches_the_oracle(orc):
     """The batch path against the oracle itself (not only against our own one-clip path): 2 clips x 3 frames, fp32."""
     eng, sd = _engine("f32")
