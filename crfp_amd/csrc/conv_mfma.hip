@@ -1818,7 +1818,7 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
             if (tid + RG_NT * k < nw) wl[tid + RG_NT * k] = wr[k];
     }
     __syncthreads();
-    if (total <= 0) return;
+    if (total <= 0 || (probe & 16)) return;   // probe 16: preamble only (A fragments into LDS)
 
     if (wave == 4) {
         // ------------------------------------------------------------ loader
