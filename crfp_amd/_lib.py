@@ -68,6 +68,8 @@ SIGNATURES = {
                                [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_dsv_stream_frame": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 3 +
                               [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "crfp_dsv_stream_batch": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 4 +
+                              [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_fnet_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_rt_param_name": (C.c_char_p, [C.c_int]),
     "crfp_rt_param_numel": (C.c_int, [C.c_int, C.c_int]),
@@ -84,7 +86,7 @@ SIGNATURES = {
 # bf16-storage twins of the engine entry points (same argument lists)
 for _n in ("crfp_dsv_packed_weight_bytes", "crfp_dsv_pack_weights", "crfp_dsv_workspace_bytes", "crfp_dsv_status_offset",
            "crfp_dsv_forward_clip", "crfp_dsv_stream_frame", "crfp_fnet_forward", "crfp_dsv_debug_fetch",
-           "crfp_dsv_batch_workspace_bytes", "crfp_dsv_batch_status_offset", "crfp_dsv_forward_batch"):
+           "crfp_dsv_batch_workspace_bytes", "crfp_dsv_batch_status_offset", "crfp_dsv_forward_batch", "crfp_dsv_stream_batch"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 
 _lib = None

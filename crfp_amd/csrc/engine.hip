@@ -337,7 +337,8 @@ struct Layout {
     Layout(int B_, int t_, int h_, int w_) : B(B_), t(t_), h(h_), w(w_) {
         flat = (long long)B * t <= kFlatFrames;
         TC = flat ? t : kChunkFrames;
-        const int nb = flat ? (B * t > 1 ? B * t - 1 : 1) : TC;
+        // pairs one FNet pass holds: all of a flat job's (the B - 1 straddling ones included); one per sequence for the one-frame-per-call layout
+        const int nb = t == 1 ? B : (flat ? B * t - 1 : TC);
         fnet_cap = nb;
         const int H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w;
         h1 = h / 2; w1 = w / 2; h2 = h1 / 2; w2 = w1 / 2; h3 = h2 / 2; w3 = w2 / 2;
@@ -348,7 +349,7 @@ struct Layout {
         // (CRFP_DSV_INPUTS_RESIDENT: the flow network of call i runs while frame i - 1 still reads the other slot)
         flow_lr = A.take("flow_lr", t == 1 ? 2 * B : B * TC, 1, h, w, 0, 0, true);
         if (kActBf16 && t == 1)
-            for (int p = 0; p < 2; ++p) lr_keep[p] = A.take(p ? "lr_keep.1" : "lr_keep", 3, 0, h, (w + 1) / 2, 1);   // >= 3 * h * w floats
+            for (int p = 0; p < 2; ++p) lr_keep[p] = A.take(p ? "lr_keep.1" : "lr_keep", 3 * B, 0, h, (w + 1) / 2, 1);   // >= B * 3 * h * w floats
         lr_q4 = A.take("lr_q4", 2 * B * t, 1, h, w);   // the LR frames as quads: [0, B t) current frames, [B t, 2 B t) previous frames when they are not the same tensor
         e_lr0 = A.take("enc_lr0", B * TC, 8, h, w);
         x_lr = A.take("x_lr", B * TC, 8, h, w);
@@ -501,7 +502,7 @@ struct Runner {
     int strict = 0;     // CRFP_DSV_STRICT_F32: fp32 MFMA for every conv and for dcn_g8's GEMM
     bool down_done = false;   // one-frame-per-call path: downsample(state) already ran on the side stream, beside FNet
     int flow_slot = 0;        // one-frame-per-call path: which of the two flow_lr slots FNet writes
-    float* flow_lr_slot() const { return F(L.flow_lr) + (long long)flow_slot * L.h * L.w * 4; }
+    float* flow_lr_slot() const { return F(L.flow_lr) + (long long)flow_slot * L.B * L.h * L.w * 4; }   // B flows per call parity
 
     // Status words: one per clip of the call.  Batch item n of a launch raises word ovf_off + (n + ovf_add) / ovf_div (ovf_word(),
     // crfp_common.h): the per-frame launches carry one item per clip (div 1); the clip-level stages set their own mapping (clip_stage).
@@ -1114,21 +1115,31 @@ int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* 
     return CRFP_API(crfp_dsv_forward_batch)(packed, flags, lrs, fvs, mks, out, 1, t, h, w, workspace, workspace_bytes, stream);
 }
 
-int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
-                          const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
+// One frame of n independent sequences in lock-step (the reference's streaming forward carries the batch axis too, model/CRFP_test.py:2250-2451):
+// lr / lr_prev [n,3,h,w], fv [n,3,8h,8w], mk [n,1,8h,8w], out [n,3|1,8h,8w]; the workspace holds the n recurrent states.
+int CRFP_API(crfp_dsv_stream_batch)(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
+                          const uint8_t* mk, const uint8_t* fg, float* out, int first, int n, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream) {
     const int y_only = flags & CRFP_DSV_Y_ONLY;
+    if (n < 1) { set_error("dsv_stream_batch: n = %d", n); return CRFP_E_BADARG; }
+    if (fg && n > 1) { set_error("dsv_stream_batch: the regional mask `fg` is supported for one sequence per call (n = 1)"); return CRFP_E_UNSUPPORTED; }
+    if (n > kFlatFrames) { set_error("dsv_stream_batch: at most %d sequences per call (got %d)", kFlatFrames, n); return CRFP_E_UNSUPPORTED; }
+    const int B = n;
+    const long long lr_f = 3LL * h * w, fq = (long long)h * w * 4;
     if (kActBf16 && (flags & CRFP_DSV_STRICT_F32)) { set_error("dsv (bf16 storage): CRFP_DSV_STRICT_F32 belongs to the fp32 entry points"); return CRFP_E_UNSUPPORTED; }
-    Layout L(1, 1, h, w);
-    int rc = check_common(packed, 1, 1, h, w, workspace, workspace_bytes, L);
+    Layout L(B, 1, h, w);
+    int rc = check_common(packed, B, 1, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     const bool resident = (flags & CRFP_DSV_INPUTS_RESIDENT) != 0;
     if (!lr || !fv || !mk || !out || (!first && !resident && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
-    // one frame of one sequence: the frame's tensors ARE the call's arguments; its flow and encoder_lr features sit in slot 0 / the parity slot
+    // one frame of every sequence: the call's arguments ARE the frames (batch stride = one frame); flows and encoder_lr features sit in the
+    // first B slots / the parity's B slots of their stores
     Runner::FrameIO io;
     io.lr = lr; io.fv = fv; io.mk = mk; io.out = out; io.x_lr = R.F(L.x_lr);
+    io.lr_b = lr_f; io.fv_b = 3LL * 64 * h * w; io.mk_b = 64LL * h * w; io.out_b = (long long)(y_only ? 1 : 3) * 64 * h * w;
+    io.x_b = 8LL * h * w * 4; io.flow_b = fq;
     SideStream* ssp = (!first && side_stream_enabled() && !prof_enabled() && !(flags & CRFP_DSV_SINGLE_STREAM)) ? side_stream() : nullptr;
     hipStream_t main_s = (hipStream_t)stream;
     // per-sequence host note, kept next to the side stream (also when this call runs on one stream)
@@ -1153,7 +1164,7 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
             return CRFP_E_BADARG;
         }
         const int par = first ? 0 : (int)(++ctx->n & 1u);
-        const size_t lr_bytes = 3 * (size_t)h * w * sizeof(float);
+        const size_t lr_bytes = (size_t)B * 3 * (size_t)h * w * sizeof(float);
         // the kept copy: fp32 build = the Q4 quads FNet reads anyway (slot par of lr_q4); bf16 build = an fp32 NCHW copy (a Q4 copy would be bf16)
         auto keep_and_get = [&](const float** cur, const float** prev) {
             if (kActBf16) {
@@ -1161,8 +1172,8 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
                 *cur = lr;
                 *prev = R.F(L.lr_keep[par ^ 1]);
             } else {
-                *cur = R.lr_to_q4(lr, 1, par, 0);
-                *prev = R.adv(R.F(L.lr_q4), (long long)(par ^ 1) * h * w * 4);
+                *cur = R.lr_to_q4(lr, B, par * B, 1);
+                *prev = R.adv(R.F(L.lr_q4), (long long)(par ^ 1) * B * h * w * 4);
             }
         };
         R.flow_slot = par;
@@ -1170,8 +1181,8 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
         if (!ssp) {   // one stream (first frame, profiling, CRFP_DSV_SINGLE_STREAM, CRFP_SIDE_STREAM=0): same order, same bits
             if (first) R.reset_state();
             keep_and_get(&cur, &prev);
-            if (!first) R.fnet(1, cur, 0, prev, 0, R.flow_lr_slot());
-            R.encode_lr(1, cur, 0);
+            if (!first) R.fnet(B, cur, lr_f, prev, lr_f, R.flow_lr_slot());
+            R.encode_lr(B, cur, lr_f);
             io.flow_lr = first ? nullptr : R.flow_lr_slot();
             R.frame_pre(par, first != 0, io);
             R.frame(par, first != 0, io, fg);
@@ -1196,8 +1207,8 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
         forked = true;
         if (!early && hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
         keep_and_get(&cur, &prev);
-        R.fnet(1, cur, 0, prev, 0, R.flow_lr_slot());
-        R.encode_lr(1, cur, 0);
+        R.fnet(B, cur, lr_f, prev, lr_f, R.flow_lr_slot());
+        R.encode_lr(B, cur, lr_f);
         io.flow_lr = R.flow_lr_slot();
         R.frame_pre(par, false, io, nullptr, 3);   // incl. the two flow up-samplings (set par as well)
         if (early && hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
@@ -1213,9 +1224,9 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     if (ctx) ctx->kept = ctx->chained = false;   // a call without the flag keeps no frame and orders nothing for a later resident call
     if (!ssp) {
         if (first) R.reset_state();
-        const float* lq = R.lr_to_q4(lr, 1, 0, 0);
-        if (!first) R.fnet(1, lq, 0, R.lr_to_q4(lr_prev, 1, 1, 0), 0, R.F(L.flow_lr));
-        R.encode_lr(1, lq, 0);
+        const float* lq = R.lr_to_q4(lr, B, 0, 1);
+        if (!first) R.fnet(B, lq, lr_f, R.lr_to_q4(lr_prev, B, B, 1), lr_f, R.F(L.flow_lr));
+        R.encode_lr(B, lq, lr_f);
         io.flow_lr = first ? nullptr : R.F(L.flow_lr);
         R.frame_pre(0, first != 0, io);
         R.frame(0, first != 0, io, fg);
@@ -1233,16 +1244,16 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     auto fail = [&](const char* what) { join(); set_error("dsv_stream_frame: %s failed", what); return 1; };
     hipEvent_t ev_start = ss.event(0), ev_side = ss.event(1);
     if (!ss.ok) return fail("hipEventCreate");
-    const float* lq = R.lr_to_q4(lr, 1, 0, 0);   // before the fork: read on both streams
-    const float* lqp = R.lr_to_q4(lr_prev, 1, 1, 0);
+    const float* lq = R.lr_to_q4(lr, B, 0, 1);   // before the fork: read on both streams
+    const float* lqp = R.lr_to_q4(lr_prev, B, B, 1);
     if (hipEventRecord(ev_start, main_s) != hipSuccess) return fail("record");
-    R.fnet(1, lq, 0, lqp, 0, R.F(L.flow_lr));
+    R.fnet(B, lq, lr_f, lqp, lr_f, R.F(L.flow_lr));
     io.flow_lr = R.F(L.flow_lr);
     R.frame_pre(0, false, io, nullptr, 2);
     R.s = ss.s;
     if (hipStreamWaitEvent(ss.s, ev_start, 0) != hipSuccess) return fail("fork");
     forked = true;
-    R.encode_lr(1, lq, 0);
+    R.encode_lr(B, lq, lr_f);
     R.frame_pre(0, false, io, nullptr, 1);
     // downsample(state) needs nothing of this call: it runs here, beside FNet's small kernels, instead of in front of the recurrent chain
     // (same box, 24 calls: bf16 27.74 -> 27.40 ms, fp32 45.81 -> 45.23 ms, same bits; profiles/r03_stream_down_side_ab.txt)
@@ -1253,6 +1264,12 @@ int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* 
     if (hipStreamWaitEvent(main_s, ev_side, 0) != hipSuccess) return fail("join");
     R.frame(0, false, io, fg);
     return R.rc;
+}
+
+int CRFP_API(crfp_dsv_stream_frame)(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
+                          const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    return CRFP_API(crfp_dsv_stream_batch)(packed, flags, lr, lr_prev, fv, mk, fg, out, first, 1, h, w, workspace, workspace_bytes, stream);
 }
 
 #ifndef CRFP_ACT_BF16

@@ -127,7 +127,7 @@ class DSVEngine:
         """True when the split-fp16 range guard fired in the last clip forward (or, stream=True, in the running
         streamed sequence).  Synchronises the device."""
         if stream:
-            return self._stream_ws is not None and bool(self._status(self._stream_ws, 1, *self._stream_hw) & 1)
+            return self._stream_ws is not None and bool(self._status(self._stream_ws, 1, *self._stream_hw[1:], self._stream_hw[0]) & 1)
         return self._ovf is not None and bool(int(self._ovf.item()) & 1)   # OR over every clip of the last forward()
 
     def _after(self, ws, key, rerun):
@@ -185,7 +185,8 @@ class DSVEngine:
 
     def stream_frame(self, lr, fv, mk, fg=None):
         """lr[3,h,w], fv[3,8h,8w], mk[1,8h,8w], optional regional mask fg[1,8h,8w] -> [3|1,8h,8w]; the first
-        call after clear_states() starts a sequence.
+        call after clear_states() starts a sequence.  With a leading batch axis -- lr[n,3,h,w], fv[n,3,8h,8w], mk[n,1,8h,8w] -> [n,3|1,8h,8w] --
+        the n sequences advance in lock-step in ONE call (crfp_dsv_stream_batch: n <= 32, no fg), per sequence bit-identical to n engines.
         With ``inputs_resident = True`` the library reads lr / fv / mk on its own side stream WITHOUT waiting for the caller's stream
         (that is the point: frame i's flow network runs beside frame i - 1).  The tensors must therefore be complete when this
         method is called: nothing still queued on the current torch stream may be writing them (a non_blocking host-to-device copy, a
@@ -199,14 +200,20 @@ class DSVEngine:
         lr, fv = _dev(lr, "lr"), _dev(fv, "fv")
         mk8 = mk.view(torch.uint8) if (self.inputs_resident and mk.dtype == torch.bool) else (mk if self.inputs_resident else self._mask_u8(mk))
         fg8 = None if fg is None else self._mask_u8(fg)
-        _, h, w = lr.shape
-        if self._stream_ws is None or self._stream_hw != (h, w):
-            nb = self._fn("crfp_dsv_workspace_bytes")(1, h, w)
+        batched = lr.dim() == 4
+        n = lr.shape[0] if batched else 1
+        h, w = lr.shape[-2:]
+        if batched and (tuple(fv.shape) != (n, 3, 8 * h, 8 * w) or mk8.numel() != n * 64 * h * w):
+            raise ValueError(f"stream_frame: lr {tuple(lr.shape)} / fv {tuple(fv.shape)} / mk {tuple(mk.shape)}: expected [n,3,h,w], [n,3,8h,8w], [n,1,8h,8w]")
+        if self._stream_ws is None or self._stream_hw != (n, h, w):
+            nb = self._fn("crfp_dsv_batch_workspace_bytes")(n, 1, h, w)
+            if nb == 0:
+                raise ValueError(f"unsupported streaming shape n={n} h={h} w={w}")
             self._stream_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
-            self._stream_hw = (h, w)
+            self._stream_hw = (n, h, w)
             self._stream_prev = None
         first = self._stream_prev is None
-        out = torch.empty((1 if self.y_only else 3, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
+        out = torch.empty(((n,) if batched else ()) + (1 if self.y_only else 3, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
         if self.on_overflow == "fallback" and self.precision != "f32":
             raise NotImplementedError("on_overflow='fallback' cannot rewind a streamed sequence: use 'poison' or 'raise'")
         resident = bool(self.inputs_resident)
@@ -214,13 +221,13 @@ class DSVEngine:
             raise RuntimeError("crfp_amd: inputs_resident changed in the middle of a streamed sequence; call clear_states() first")
         self._stream_resident = resident
         with torch.cuda.device(self.device):
-            _lib.check(self._fn("crfp_dsv_stream_frame")(
+            _lib.check(self._fn("crfp_dsv_stream_batch")(
                 self.packed.data_ptr(), self._flags() | (_lib.DSV_INPUTS_RESIDENT if resident else 0), lr.data_ptr(),
                 None if (first or resident) else self._stream_prev.data_ptr(), fv.data_ptr(), mk8.data_ptr(),
                 None if fg8 is None else fg8.data_ptr(), out.data_ptr(),
-                1 if first else 0, h, w, self._stream_ws.data_ptr(), self._stream_ws.numel(), _stream()),
-                "crfp_dsv_stream_frame")
-        self._after(self._stream_ws, (1, h, w, 1), None)
+                1 if first else 0, n, h, w, self._stream_ws.data_ptr(), self._stream_ws.numel(), _stream()),
+                "crfp_dsv_stream_batch")
+        self._after(self._stream_ws, (1, h, w, n), None)
         # the reference keeps a COPY of the frame (model/CRFP_test.py:2234-2238, ``.clone()``): a caller that refills one
         # input buffer in place must not change what the next call sees as the previous frame
         if resident:            # the library kept the frame inside the workspace

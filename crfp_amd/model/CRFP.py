@@ -458,14 +458,19 @@ class CRFP_DSV(nn.Module):
     def forward_stream(self, lrs, fvs, mks, fgs=None):
         """lrs[1,t,3,h,w], fvs[1,t,3,8h,8w], mks / fgs[1,t,1,8h,8w] -> [1,t,3|1,8h,8w]; recurrent state and
         the previous LR frame persist between calls (reference model/CRFP_test.py:2234-2239,2438-2441)."""
-        assert lrs.shape[0] == 1, "streaming runs one sequence at a time"
         if not self.has_engine():
             raise NotImplementedError("crfp_amd: the one-frame-per-call interface exists for mid_channels=32, hr_dcn=True, offset_prop=True "
                                       "(the configuration test_video.py / test_runtime.py build)")
         eng = self.engine()
-        outs = [eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i], None if fgs is None else fgs[0, i])
-                for i in range(lrs.shape[1])]
-        return torch.stack(outs, dim=0)[None]
+        if lrs.shape[0] == 1:
+            outs = [eng.stream_frame(lrs[0, i], fvs[0, i], mks[0, i], None if fgs is None else fgs[0, i])
+                    for i in range(lrs.shape[1])]
+            return torch.stack(outs, dim=0)[None]
+        # n > 1 sequences advance in lock-step, one crfp_dsv_stream_batch call per frame (the reference's forward carries n through every op)
+        if fgs is not None:
+            raise NotImplementedError("crfp_amd: the regional mask `fgs` is supported for one sequence per call (n = 1)")
+        outs = [eng.stream_frame(lrs[:, i].contiguous(), fvs[:, i].contiguous(), mks[:, i].contiguous()) for i in range(lrs.shape[1])]
+        return torch.stack(outs, dim=1)
 
     def init_weights(self, pretrained=None, strict=True):
         if isinstance(pretrained, str):

@@ -227,6 +227,14 @@ int crfp_dsv_stream_frame(const void* packed, int flags, const float* lr, const 
                           const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* The same for n independent sequences in lock-step, one frame of each per call (the reference's streaming forward carries the batch axis too,
+ * model/CRFP_test.py:2250-2451): lr / lr_prev [n,3,h,w], fv [n,3,8h,8w], mk [n,1,8h,8w], out [n,3|1,8h,8w]; the workspace
+ * (crfp_dsv_batch_workspace_bytes(n, 1, h, w)) holds the n recurrent states and n status words.  n <= 32; `fg` needs n = 1.  Per sequence the
+ * results are bit-identical to n one-sequence call chains.  crfp_dsv_stream_frame = this with n = 1. */
+int crfp_dsv_stream_batch(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
+                          const uint8_t* mk, const uint8_t* fg, float* out, int first, int n, int h, int w, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* ---- bf16 storage (BASELINE configs 3-5): the same engine with every activation tensor and the recurrent state held
  * as bf16 in HBM (half the traffic of the HBM-bound kernels, one bf16 MFMA per product instead of three fp16 ones).
  * What stays fp32: the API tensors (lrs, fvs, out), all accumulators and interpolation arithmetic, biases, and everything
@@ -246,6 +254,9 @@ int crfp_dsv_forward_batch_bf16(const void* packed, int flags, const float* lrs,
                                 float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 int crfp_dsv_stream_frame_bf16(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
                                const uint8_t* mk, const uint8_t* fg, float* out, int first, int h, int w, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int crfp_dsv_stream_batch_bf16(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
+                               const uint8_t* mk, const uint8_t* fg, float* out, int first, int n, int h, int w, void* workspace,
                                size_t workspace_bytes, void* stream);
 int crfp_fnet_forward_bf16(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
                            void* workspace, size_t workspace_bytes, void* stream);

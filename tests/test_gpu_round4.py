@@ -220,3 +220,51 @@ def test_two_batches_in_flight_on_two_streams_are_bit_exact(storage):
             cur.wait_stream(s)
         torch.cuda.synchronize()
         assert all(torch.equal(outs[g], seq[g]) for g in range(2))
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_streaming_batch_of_sequences_is_bit_identical_to_single_sequences(storage):
+    """crfp_dsv_stream_batch: n sequences, one frame of each per call (the reference's streaming forward carries the batch axis,
+    model/CRFP_test.py:2250-2451), against n engines streaming one sequence each -- same bits per sequence, with and without the
+    resident-inputs promise, across a clear_states() in the middle."""
+    from crfp_amd import synth
+    from crfp_amd.engine import DSVEngine
+    sd = {k: T(v.copy()) for k, v in synth.make_state_dict(7).items()}
+    n, t, h, w = 3, 6, 27, 45
+    lrs, fvs, mks = _batch(range(300, 300 + n), t, h, w, 64)
+    mk8 = mks.view(torch.uint8)
+    singles = [DSVEngine(sd, dev(), storage=storage) for _ in range(n)]
+    ref = []
+    for b, e in enumerate(singles):
+        outs = []
+        for i in range(t):
+            if i == 4:
+                e.clear_states()
+            outs.append(e.stream_frame(lrs[b, i], fvs[b, i], mk8[b, i]).clone())
+        ref.append(torch.stack(outs))
+    ref = torch.stack(ref)                                   # [n, t, c, H, W]
+    # frame-major copies made up front: the resident-inputs promise is that nothing on the stream is still writing a frame when its call is made
+    fr = [(lrs[:, i].contiguous(), fvs[:, i].contiguous(), mk8[:, i].contiguous()) for i in range(t)]
+    torch.cuda.synchronize()
+    for resident in (False, True):
+        eng = DSVEngine(sd, dev(), storage=storage)
+        eng.inputs_resident = resident
+        got = []
+        for i in range(t):
+            if i == 4:
+                eng.clear_states()
+            got.append(eng.stream_frame(*fr[i]).clone())
+        got = torch.stack(got, dim=1)
+        torch.cuda.synchronize()
+        assert got.shape == ref.shape and torch.equal(got, ref), f"resident={resident}: max diff {float((got - ref).abs().max()):.3e}"
+        assert not eng.overflowed(stream=True)
+    # the module mirror: MRCF_simple_v18.forward(lrs[n, t, ...]) == its n = 1 calls
+    from crfp_amd.model import CRFP
+    m = CRFP.MRCF_simple_v18(device=dev(), mid_channels=32)
+    m.load_state_dict(sd, strict=True)
+    m.storage = storage
+    m = m.to(dev()).eval()
+    both = m(lrs[:, :4], fvs[:, :4], mks[:, :4])
+    assert torch.equal(both, ref[:, :4])
+    with pytest.raises(RuntimeError, match="fg"):
+        eng.stream_frame(*fr[0], fg=mks[:, 0])
