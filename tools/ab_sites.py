@@ -24,7 +24,7 @@ def child(a):
     from crfp_amd import _lib, synth
     from crfp_amd.model import CRFP
     dev = torch.device("cuda:0")
-    sd = synth.make_state_dict(7)
+    sd = synth.make_state_dict(7, offset_std=(a.offset_std if a.offset_std > 0 else None))
     m = CRFP.CRFP_DSV(device=dev, mid_channels=32, y_only=False, hr_dcn=True, offset_prop=True)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
     m.storage = a.storage
@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--t", type=int, default=7); ap.add_argument("--fv", type=int, default=96)
     ap.add_argument("--mode", default="clip", choices=("clip", "stream"))
     ap.add_argument("--all-sites", action="store_true", help="print every launch site (sorted by time) for the first variant")
+    ap.add_argument("--offset-std", type=float, default=0.0, help="0.02 = SURVEY 8(d)'s N(0, 0.02) dcn_offset / dcn_mask heads (default: the stress weights)")
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
     if a.child:
@@ -97,7 +98,7 @@ def main():
     for r in range(a.rounds):
         for name, env in variants:
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--storage", a.storage, "--steps", str(a.steps), "--h", str(a.h),
-                   "--w", str(a.w), "--t", str(a.t), "--fv", str(a.fv), "--mode", a.mode]
+                   "--w", str(a.w), "--t", str(a.t), "--fv", str(a.fv), "--mode", a.mode, "--offset-std", str(a.offset_std)]
             p = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("ABRESULT ")]
             if not line:
