@@ -112,10 +112,12 @@ def counted_frames(i_batch: int, n_frames: int) -> Iterable[int]:
     return (i for i in range(n_frames) if not (i == 0 and i_batch % 50 == 0))
 
 
-def eval_clip(model, batch: dict, i_batch: int, with_ssim: bool = True):
-    """One eval batch through the model (trainer.py:307-369): batch has LR, HR, Ref, Ref_sp on device."""
-    with torch.no_grad():
-        sr = model(lrs=batch["LR"], fvs=batch["Ref"], mks=batch["Ref_sp"])
+def eval_clip(model, batch: dict, i_batch: int, with_ssim: bool = True, sr: Optional[torch.Tensor] = None):
+    """One eval batch through the model (trainer.py:307-369): batch has LR, HR, Ref, Ref_sp on device.  sr: the model's output for
+    this batch when the caller already ran it (eval_reds with clips_per_call > 1)."""
+    if sr is None:
+        with torch.no_grad():
+            sr = model(lrs=batch["LR"], fvs=batch["Ref"], mks=batch["Ref_sp"])
     B, N, C, H, W = sr.shape
     sr = sr.view(B * N, C, H, W)
     hr = batch["HR"].view(B * N, -1, H, W)
@@ -137,12 +139,40 @@ def load_checkpoint(model, model_path: str):
     return sorted(saved)
 
 
-def eval_reds(model, args, rank: int = 0, world: int = 1, dist=None, device=None, with_ssim: bool = True, log=None):
+def eval_reds(model, args, rank: int = 0, world: int = 1, dist=None, device=None, with_ssim: bool = True, log=None,
+              clips_per_call: int = 1):
     """Trainer.eval_basicvsr over dataset.reds.EvalSet (trainer.py:295-413): batch size 1, items sharded round-robin over
-    ranks (each item is an independent clip window), per-frame metrics, one final all-reduce."""
+    ranks (each item is an independent clip window), per-frame metrics, one final all-reduce.
+    clips_per_call > 1 (not in the reference, whose eval DataLoader is batch_size=1, dataset/dataloader.py:14): that many of a rank's
+    windows go through ONE model call (crfp_dsv_forward_batch: lock-step launches over the windows, per window bit-identical to its
+    own call), every window keeping its own `i_batch` for the frame-0 rule -- the same metrics, more frames per second."""
     from .dataset import reds
     ds = reds.EvalSet(args)
     dev = device if device is not None else next(model.parameters()).device
+    if clips_per_call > 1:
+        mine = shard_clips(len(ds), rank, world)
+        cache = {}
+
+        def batched(i_batch):
+            if i_batch not in cache:
+                cache.clear()                      # the shard is walked in order: one group alive at a time
+                g0 = mine.index(i_batch)
+                group = mine[g0:g0 + clips_per_call]
+                items = [ds[i] for i in group]
+                if any(it["LR"].shape != items[0]["LR"].shape for it in items):
+                    group, items = group[:1], items[:1]
+                batch = {k: (torch.stack([it[k] for it in items]).to(dev) if torch.is_tensor(items[0][k]) else items[0][k]) for k in items[0]}
+                with torch.no_grad():
+                    sr_all = model(lrs=batch["LR"], fvs=batch["Ref"], mks=batch["Ref_sp"])
+                for b, i in enumerate(group):
+                    one = {k: (v[b:b + 1] if torch.is_tensor(v) else v) for k, v in batch.items()}
+                    cache[i] = eval_clip(model, one, i, with_ssim, sr=sr_all[b:b + 1])
+            m = cache[i_batch]
+            if log is not None:
+                log(i_batch, m)
+            return m
+
+        return evaluate(batched, len(ds), rank, world, dist, dev)
 
     def clip_fn(i_batch):
         item = ds[i_batch]
@@ -171,6 +201,7 @@ def main(argv=None):
     ap.add_argument("--GT_size", type=int, default=256)
     ap.add_argument("--FV_size", type=int, default=96)
     ap.add_argument("--y_only", type=int, default=0)
+    ap.add_argument("--clips_per_call", type=int, default=1, help="windows per model call (lock-step batch; same metrics)")
     a = ap.parse_args(argv)
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     dist = None
@@ -183,7 +214,7 @@ def main(argv=None):
     model = CRFP.CRFP_DSV(device=dev, mid_channels=32, y_only=bool(a.y_only), hr_dcn=True, offset_prop=True).to(dev).eval()
     if a.model_path:
         load_checkpoint(model, a.model_path)
-    res = eval_reds(model, a, rank, world, dist, dev)
+    res = eval_reds(model, a, rank, world, dist, dev, clips_per_call=a.clips_per_call)
     if rank == 0:
         print(json.dumps(res))
 

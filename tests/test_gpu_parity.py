@@ -615,6 +615,9 @@ def test_eval_reds_end_to_end_vs_oracle(orc, tmp_path, y_only):
             out.append((p, s, py, sy))
         return out
 
+    # several windows per model call (lock-step batch inside the library): the very same numbers
+    res3 = evalrig.eval_reds(m, args, device=dev(), clips_per_call=3)
+    assert res3 == res
     ref = evalrig.evaluate(oracle_frames, len(reds.EvalSet(args)))
     assert res["frames"] == ref["frames"] == 8 * 3 - 1      # frame 0 of batch 0 is skipped (trainer.py:350-351)
     for k in ("psnr", "psnr_y"):
