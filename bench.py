@@ -34,6 +34,8 @@ Extra objects on that line:
                 per 5-frame clip) and of the whole-frame CRFP_DSV engine on the same rig.
   warp_dcn_8d   SURVEY 8(d)'s figure un-re-scoped: API-tensor bytes of flow_warp x3 + DCNv2 x4 per steady-state frame divided by
                 the time of ALL warp / DCN kernels of such a frame, the fused offset-head + DCN kernel included.
+  lockstep_batch_frames_per_sec  (clip configs) n = 2 / 4 clips per crfp_dsv_forward_batch call (lock-step launches over the clips), bit-exactness against
+                one-clip calls; warp_dcn_8d_spec_weights: the 8(d) figure, frames/s and parity with SURVEY 8(d)'s own N(0, 0.02) DCN heads.
   collectives   which backend ran the barrier / MAX / SUM reductions (CRFP_FORCE_DIST=1 initialises RCCL even with one rank).
 """
 import argparse
@@ -528,6 +530,33 @@ def main():
             del es, os_
         ms["bit_exact_vs_sequential"] = exact
         result["multi_stream_frames_per_sec"] = ms
+
+    if extras and mode == "clip":
+        # the batch axis inside the library (crfp_dsv_forward_batch): n clips per call in lock-step, one launch per layer over all of them
+        lb = {}
+        exact_lb = True
+        with torch.no_grad():
+            for nclips in (2, 4):
+                seeds = benchutil.rank_clip_seeds(rank, nclips, base=4321)
+                cl = [synth.make_clip(sd_, 1, t, h, w, fv_size=fv, sigma_t=cfg["sigma"]) for sd_ in seeds]
+                stack = tuple(torch.from_numpy(np.concatenate([c[k] for c in cl], 0)).to(dev) for k in range(3))
+                eng.batch_mode = "loop"
+                ref_b = eng.forward(*stack).clone()
+                eng.batch_mode = "lockstep"
+                got_b = eng.forward(*stack)
+                exact_lb = exact_lb and bool(torch.equal(got_b, ref_b))
+                torch.cuda.synchronize()
+                n_s = max(2, min(args.steps, 4))
+                t0 = time.perf_counter()
+                for _ in range(n_s):
+                    eng.forward(*stack)
+                torch.cuda.synchronize()
+                lb[str(nclips)] = nclips * t * n_s / (time.perf_counter() - t0)
+                del stack, ref_b, got_b
+        lb["bit_exact_vs_one_clip_calls"] = exact_lb
+        lb["note"] = "frames/s with n clips per crfp_dsv_forward_batch call (the reference's own [n, t, ...] batch axis); one clip per call is the headline"
+        result["lockstep_batch_frames_per_sec"] = lb
+        torch.cuda.empty_cache()
 
     if extras and storage == "f32":
         # the per-operator C-ABI entry points (NCHW API tensors in and out: each call includes its layout conversions)
