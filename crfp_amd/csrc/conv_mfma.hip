@@ -1287,8 +1287,12 @@ __device__ __forceinline__ cu32x2 quad_words(cu32x2 r, int m, bool valid) {
     return cu32x2{r.x & k0, r.y & k1};
 }
 
+#ifndef CRFP_BF16_LB
+#define CRFP_BF16_LB 5   // workgroups per CU the register allocation aims at.  Round 4, same box, 4-clip lock-step batch: 4 -> 5 takes the kernel
+                         // sum per clip 5.67 -> 5.60 ms (32 -> 32 convs 9.4 -> 8.9 us), one-clip calls unchanged; 6 spills (40 B) and loses 6 %
+#endif
 template <int RPW>
-__global__ __launch_bounds__(256, RPW == 1 ? 4 : 3) void conv3x3_bf16_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, RPW == 1 ? CRFP_BF16_LB : 3) void conv3x3_bf16_kernel(const ConvArgs a) {
     constexpr int CT = 1, TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
     constexpr int NEL = LH * LW;                 // halo pixels
     constexpr int NIN = (NEL + 255) / 256;       // halo pixels per thread; each carries the chunk's 4 quads
