@@ -298,3 +298,37 @@ def test_plain_c_host_runs_on_the_gpu(tmp_path):
     """examples/c_host_smoke.c: hipMalloc'ed buffers, crfp_flow_warp_f32 / crfp_upsample_bilinear_f32 / an argument error, from C."""
     r = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "c_host_smoke: OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_pmc_traffic_is_tagged_with_the_kernel_source_digest(tmp_path, monkeypatch):
+    """bench.py joins the committed PMC summary by kernel-name prefix and tags it stale when the summary's kernel-source digest is not
+    the one of the library being timed."""
+    import json
+    import bench
+    from crfp_amd import _lib
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    rows = [{"kernel": "crfp::dcn3_kernel<true, 3>", "calls": 24, "hbm_MB_per_launch_corrected": 231.5},
+            {"kernel": "conv3x3_split8_kernel<8>", "calls": 492, "hbm_MB_per_launch_corrected": 81.2},
+            {"kernel": "conv3x3_split_kernel<1, 1, 2>", "calls": 120, "hbm_MB_per_launch_corrected": 58.8}]
+    (prof / "pmc_summary_latest.json").write_text(json.dumps(rows))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    tr = bench.pmc_traffic("dcnv2_shared_c4_fused", "f32")
+    assert tr and abs(tr["bytes_per_launch"] - 231.5e6) < 1 and tr["stale"] is None          # no digest file: unknown
+    (prof / "pmc_summary_latest.meta.json").write_text(json.dumps({"kernels_src_sha": _lib.kernel_source_digest()}))
+    assert bench.pmc_traffic("dcnv2_shared_c4_fused", "f32")["stale"] is False
+    conv = bench.pmc_traffic("conv3x3_mfma", "f32")
+    assert abs(conv["bytes_per_launch"] - (81.2e6 * 492 + 58.8e6 * 120) / 612) < 1       # call-weighted over the family's kernels
+    (prof / "pmc_summary_latest.meta.json").write_text(json.dumps({"kernels_src_sha": "0" * 12}))
+    assert bench.pmc_traffic("conv3x3_mfma", "f32")["stale"] is True
+    assert bench.pmc_traffic("conv3x3_mfma", "f32", (270, 480)) is None                   # another geometry: bytes do not transfer
+    assert bench.pmc_traffic("conv3x3_mfma", "f32", (180, 320), 4) is None                # no fp32 lock-step summary
+
+
+def test_committed_pmc_summaries_belong_to_the_shipped_kernels():
+    """The summaries bench.py reads must have been collected with the kernel sources in the tree (else the driver's line says stale)."""
+    import json
+    from crfp_amd import _lib
+    for name in ("pmc_summary_latest", "pmc_summary_latest_bf16", "pmc_summary_latest_c4"):
+        meta = json.load(open(os.path.join(ROOT, "profiles", name + ".meta.json")))
+        assert meta["kernels_src_sha"] == _lib.kernel_source_digest(), f"profiles/{name}.json is stale: re-run tools/measure_round.sh and copy the summaries"
