@@ -83,6 +83,12 @@ SIGNATURES = {
     "crfp_dsv_debug_fetch": (C.c_int, [C.c_char_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p] +
                              [C.POINTER(C.c_int)] * 3 + [C.c_void_p]),
 }
+# the CRFP_DSV_CRA wiring: its own parameter table / packed weights / workspace, the forward call of crfp_dsv_forward_batch
+CRA_NUM_PARAMS = 144
+for _n in ("param_name", "param_numel", "packed_weight_bytes", "pack_weights", "batch_workspace_bytes", "batch_status_offset", "forward_batch"):
+    SIGNATURES["crfp_cra_" + _n] = SIGNATURES["crfp_dsv_" + _n]
+for _n in ("packed_weight_bytes", "pack_weights", "batch_workspace_bytes", "batch_status_offset", "forward_batch"):
+    SIGNATURES["crfp_cra_" + _n + "_bf16"] = SIGNATURES["crfp_dsv_" + _n]
 # bf16-storage twins of the engine entry points (same argument lists)
 for _n in ("crfp_dsv_packed_weight_bytes", "crfp_dsv_pack_weights", "crfp_dsv_workspace_bytes", "crfp_dsv_status_offset",
            "crfp_dsv_forward_clip", "crfp_dsv_stream_frame", "crfp_fnet_forward", "crfp_dsv_debug_fetch",

@@ -405,6 +405,9 @@ int launch_fg_prep(const uint8_t* fg, float* fg2, int H8, int W8, hipStream_t s)
 // dst = src * scale(y,x); scale is float [H][W] (scale_f) or u8 [H][W] (scale_u8)
 int launch_scale_q4(const float* src, int src_pad, float* dst, int nq, int H, int W, const float* scale_f,
                     const uint8_t* scale_u8, hipStream_t s);
+// CRFP_DSV_CRA level fusion: [prop | carry] = mk2 * fused + (1 - mk2) * y, mk2 = the x0.25 bilinear resample of the u8 mask [4H][4W]
+int launch_cra_blend(const float* y, long long y_b, const float* fused, long long f_b, const uint8_t* mk, long long mk_b, float* prop,
+                     long long prop_b, float* carry, long long carry_b, int N, int H, int W, hipStream_t s);
 int launch_psnr_ssim_partial(const float* a, const float* b, const uint8_t* mask, double* acc, int N, int C, int H, int W,
                              float mul, float add, hipStream_t s);
 int launch_psnr_partial(const float* a, const float* b, double* acc, int N, int C, int H, int W, hipStream_t s);

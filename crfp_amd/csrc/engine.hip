@@ -27,7 +27,8 @@ namespace CRFP_NS {
 struct ConvDef { const char* stem; int cout, cin; };
 // order == reference state_dict order (weight, bias per entry); checked against the imported
 // reference by tests/golden/make_golden.py through crfp_amd/synth.py
-static const ConvDef kConvs[59] = {
+constexpr int kNumDsvConvs = 59, kNumCraConvs = 72;
+static const ConvDef kConvs[kNumCraConvs] = {
     {"spynet.encoder1.0", 32, 6}, {"spynet.encoder1.2", 32, 32}, {"spynet.encoder2.0", 64, 32},
     {"spynet.encoder2.2", 64, 64}, {"spynet.encoder3.0", 128, 64}, {"spynet.encoder3.2", 128, 128},
     {"spynet.decoder1.0", 256, 128}, {"spynet.decoder1.2", 256, 256}, {"spynet.decoder2.0", 128, 256},
@@ -52,11 +53,23 @@ static const ConvDef kConvs[59] = {
     {"forward_resblocks_3.main.0", 4, 8}, {"forward_resblocks_3.main.2.0.conv1", 4, 4},
     {"forward_resblocks_3.main.2.0.conv2", 4, 4},
     {"downsample.downsample_conv", 32, 64}, {"upsample.upsample_conv", 96, 32},
-    {"upsample_post.upsample_conv", 64, 24}, {"conv_last", 3, 4}};
+    {"upsample_post.upsample_conv", 64, 24}, {"conv_last", 3, 4},
+    // CRFP_DSV_CRA only (reference model/CRFP.py:2314-2664): the deeper levels of its LTE_simple_hr_ps fovea encoder (:156-166) and the
+    // three per-level fusion convs
+    {"encoder_hr.slice2.1", 16, 64}, {"encoder_hr.slice2.3", 16, 16}, {"encoder_hr.slice3.0", 16, 16}, {"encoder_hr.slice3.2", 16, 16},
+    {"encoder_hr.slice4.0", 16, 16}, {"encoder_hr.slice4.2", 16, 16}, {"encoder_hr.conv_lv0", 16, 16}, {"encoder_hr.conv_lv1", 16, 16},
+    {"encoder_hr.conv_lv2", 16, 16}, {"encoder_hr.conv_lv3", 4, 4}, {"conv_tttf_0", 32, 48}, {"conv_tttf_1", 32, 48},
+    {"conv_tttf_2", 32, 48}};
+// CRFP_DSV_CRA's state_dict order (the reference registers encoder_hr's levels and the fusion convs between encoder_lr and the
+// propagation branches, :2347-2353), as indices into kConvs
+static const int kCraOrder[kNumCraConvs] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37,
+    38, 39, 40, 41, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 42, 69, 70, 71, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58};
 
 enum { CI_D3_UPS = 31, CI_D3_FUSE = 32, CI_D3_B0 = 33, CI_D3_B2 = 34, CI_D3_OFF = 35, CI_D3_MASK = 36, CI_D3_DCN = 37,
        CI_ENC_LR0 = 38, CI_ENC_LR1 = 39, CI_ENC_HR0 = 40, CI_ENC_HR1 = 41, CI_TTTF = 42, CI_RB3 = 52, CI_DOWN = 55,
-       CI_UPS = 56, CI_UPP = 57, CI_LAST = 58 };
+       CI_UPS = 56, CI_UPP = 57, CI_LAST = 58,
+       CI_C_S2A = 59, CI_C_S2B, CI_C_S3A, CI_C_S3B, CI_C_S4A, CI_C_S4B, CI_C_LV0, CI_C_LV1, CI_C_LV2, CI_C_LV3, CI_C_T0 };
 static inline int ci_dcn(int lvl, int which) {  // which: 0 fuse, 1 block.0, 2 block.2, 3 offset, 4 mask, 5 dcn
     static const int base[3] = {13, 19, 25};     // lvl 0 has no conv_fuse: block.0 is 14
     return base[lvl] + which;
@@ -83,7 +96,10 @@ enum ItemId {
     IT_LVL0,  // per level 10 items: FUSE, DB0, DB1, OM, DCNW, RB0, RB0F, RB1, RB2, OMF
     IT_UPP = IT_LVL0 + 30, IT_POFF,
     IT_EH0, IT_EH1, IT_D3B0, IT_D3B1, IT_D3FUSE, IT_D3OM, IT_D3W, IT_R3_0, IT_R3_0F, IT_R3_1, IT_R3_2, IT_TTTF,
-    IT_LAST, IT_COUNT
+    IT_LAST,
+    // CRFP_DSV_CRA only
+    IT_C_LV3, IT_C_S2A, IT_C_S2B, IT_C_LV2, IT_C_S3A, IT_C_S3B, IT_C_LV1, IT_C_S4A, IT_C_S4B, IT_C_LV0, IT_C_T0, IT_C_T1, IT_C_T2,
+    IT_COUNT
 };
 enum { L_FUSE = 0, L_DB0, L_DB1, L_OM, L_DCNW, L_RB0, L_RB0F, L_RB1, L_RB2, L_OMF };
 static inline int it_lvl(int lvl, int which) { return IT_LVL0 + 10 * lvl + which; }
@@ -153,6 +169,7 @@ struct Model {
     size_t total_floats = 0;
     int y_only = 0;
     bool use_s3 = false;   // producer-split SRC_S3 edges (default precision only); packed weights are identical either way
+    bool cra = false;      // the CRFP_DSV_CRA wiring: 13 more convs behind the CRFP_DSV ones
 
     void add_mfma(int id, const char* name, int ci, int ci2, std::vector<SrcSpec> srcs, int store, int ps_r, int act,
                   float post_scale = 1.0f) {
@@ -177,7 +194,7 @@ struct Model {
         it.n_b = 4;
     }
 
-    Model(int y_only_, bool use_s3_) : y_only(y_only_), use_s3(use_s3_) {
+    Model(int y_only_, bool use_s3_, bool cra_ = false) : y_only(y_only_), use_s3(use_s3_), cra(cra_) {
         const int Q = SRC_Q4;
         static const char* fn[14] = {"conv_mfma:fnet.enc1a", "conv_mfma:fnet.enc1b", "conv_mfma:fnet.enc2a",
                                      "conv_mfma:fnet.enc2b", "conv_mfma:fnet.enc3a", "conv_mfma:fnet.enc3b",
@@ -248,6 +265,19 @@ struct Model {
         add_narrow(IT_R3_2, "conv_narrow:res3.conv2_add", CI_RB3 + 2, -1, {{Q, 4}}, CRFP_ACT_NONE, NE_PLAIN);
         add_narrow(IT_TTTF, "conv_narrow:tttf_blend", CI_TTTF, -1, {{Q, 4}, {Q, 4}}, CRFP_ACT_NONE, NE_BLEND);
         add_narrow(IT_LAST, "conv_narrow:last_plus_base", CI_LAST, -1, {{Q, 4}}, CRFP_ACT_NONE, NE_LAST);
+        if (cra) {
+            // LTE_simple_hr_ps (:156-166): slice1 is CRFP_DSV's encoder_hr pair; conv_lv3 (8x) gives the map conv_tttf blends in; slice2
+            // opens with PixelUnshuffle(4) (rides in the conv's load, like `downsample`), slice2-4 and conv_lv0-2 are 16-channel convs at 2x
+            add_narrow(IT_C_LV3, "conv_narrow:cra.lv3", CI_C_LV3, -1, {{Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
+            add_mfma(IT_C_S2A, "conv_mfma:cra.slice2a_unshuf4", CI_C_S2A, -1, {{SRC_UNSHUF4, 64}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+            static const struct { int id, ci; const char* name; } c16[] = {
+                {IT_C_S2B, CI_C_S2B, "conv_mfma:cra.slice2b"}, {IT_C_LV2, CI_C_LV2, "conv_mfma:cra.lv2"}, {IT_C_S3A, CI_C_S3A, "conv_mfma:cra.slice3a"},
+                {IT_C_S3B, CI_C_S3B, "conv_mfma:cra.slice3b"}, {IT_C_LV1, CI_C_LV1, "conv_mfma:cra.lv1"}, {IT_C_S4A, CI_C_S4A, "conv_mfma:cra.slice4a"},
+                {IT_C_S4B, CI_C_S4B, "conv_mfma:cra.slice4b"}, {IT_C_LV0, CI_C_LV0, "conv_mfma:cra.lv0"}};
+            for (auto& c : c16) add_mfma(c.id, c.name, c.ci, -1, {{Q, 16}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+            // conv_tttf_k(cat(level features (32), fovea level (16))) (:2533): the blend with the resampled mask is its own small pass
+            for (int k = 0; k < 3; ++k) add_mfma(IT_C_T0 + k, "conv_mfma:cra.tttf_level", CI_C_T0 + k, -1, {{Q, 32}, {Q, 16}}, ST_Q4, 0, CRFP_ACT_NONE);
+        }
         size_t cur = 0;
         for (int i = 0; i < IT_COUNT; ++i) {
             Item& it = items[i];
@@ -264,7 +294,12 @@ struct Model {
 };
 
 // strict: the fp32-MFMA wiring (no SRC_S3 edges); same packed-weight layout as the default wiring
-static const Model& model_for(int y_only, bool strict = false) {
+static const Model& model_for(int y_only, bool strict = false, bool cra = false) {
+    if (cra) {
+        static const Model m0(0, false, true), m1(1, false, true), s0(0, true, true), s1(1, true, true);
+        if (strict || !conv_s3_supported()) return y_only ? m1 : m0;
+        return y_only ? s1 : s0;
+    }
     static const Model m0(0, false), m1(1, false), s0(0, true), s1(1, true);
     if (strict || !conv_s3_supported()) return y_only ? m1 : m0;
     return y_only ? s1 : s0;
@@ -331,10 +366,13 @@ struct Layout {
     // frame-level
     Ten xin8[2], eh[2], x_hr[2], prop0[2], prop_a, prop_b, flow2[2], flow8[2], prev2, prev2w, prevhrw, carryw, fa, fb, offfeat[3], offmask,
         aligned, y0, y1, up, poff, g0, g1, g2, om3, al3, z0, z1, feat, fg2, sc_prop, sc_cw, sc_al, sc_up, sc_al3;
+    // CRFP_DSV_CRA: slice1's output, the 2x chain's two temporaries, the three fovea levels per buffer set, a level's features and their fused twin
+    Ten c_s1, c_a, c_b, c_lv[2][3], c_y, c_f;
+    bool cra;
     int h1, w1, h2, w2, h3, w3;
     int fnet_cap;   // pairs one FNet pass can hold
 
-    Layout(int B_, int t_, int h_, int w_) : B(B_), t(t_), h(h_), w(w_) {
+    Layout(int B_, int t_, int h_, int w_, bool cra_ = false) : B(B_), t(t_), h(h_), w(w_), cra(cra_) {
         flat = (long long)B * t <= kFlatFrames;
         TC = flat ? t : kChunkFrames;
         // pairs one FNet pass holds: all of a flat job's (the B - 1 straddling ones included); one per sequence for the one-frame-per-call layout
@@ -406,6 +444,16 @@ struct Layout {
         z0 = A.take("res3.z0", B, 1, H8, W8);
         z1 = A.take("res3.z1", B, 1, H8, W8);
         feat = A.take("feat", B, 1, H8, W8);
+        if (cra) {
+            static const char* lvn[2][3] = {{"cra.lv0", "cra.lv1", "cra.lv2"}, {"cra.lv0.1", "cra.lv1.1", "cra.lv2.1"}};
+            c_s1 = A.take("cra.s1", B, 1, H8, W8);
+            c_a = A.take("cra.a", B, 4, H2, W2);
+            c_b = A.take("cra.b", B, 4, H2, W2);
+            for (int p = 0; p < 2; ++p)
+                for (int k = 0; k < 3; ++k) c_lv[p][k] = A.take(lvn[p][k], B, 4, H2, W2);
+            c_y = A.take("cra.y", B, 8, H2, W2);
+            c_f = A.take("cra.fused", B, 8, H2, W2);
+        }
         // regional-mask (fgs) copies of the streaming variant (one frame per call, one sequence per workspace)
         if (t == 1 && B == 1) {
             fg2 = A.take("fg2", 1, 0, H2 / 2, W2, 1);   // H2*W2 floats (kind 1 stores 2 floats per element)
@@ -735,18 +783,26 @@ struct Runner {
 
     // ResidualBlockNoBN of level l (model/CRFP.py:449-481): y0 + conv2(relu(conv1(y0))), the 32 output channels going to the
     // propagated features (24) and the carried ones (8).  bf16 build: one launch, conv1's output stays in LDS.
-    void res_block(int l, float* prop_next, float* carry_l, int H2, int W2) {
+    // CRFP_DSV_CRA (M.cra): the block's 32 channels stay together (cra.y); the level's fusion conv and the masked blend then write the
+    // same two destinations (model/CRFP.py:2533-2535): [prop | carry] = mk2 * conv_tttf_l(cat(y, fovea level l)) + (1 - mk2) * y
+    void res_block(int l, float* prop_next, float* carry_l, int H2, int W2, int par = 0, const uint8_t* mk = nullptr, long long mk_b = 0) {
         const int B = L.B;
         const long long P2q = (long long)H2 * W2 * 4, P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;
+        std::vector<DstBind> dsts = {{prop_next, 6 * P2q, 0, 6}, {carry_l, 6 * P2qp, 6, 8, 1}};
+        if (M.cra) dsts = {{F(L.c_y), L.c_y.bs, 0, 8}};
 #ifdef CRFP_ACT_BF16
-        if (pair_convs()) {
-            mfma_pair(it_lvl(l, L_RB1), it_lvl(l, L_RB2), "conv_mfma_pair:res.conv1_conv2_add", B, H2, W2, {{F(L.y0), L.y0.bs}},
-                      {{prop_next, 6 * P2q, 0, 6}, {carry_l, 6 * P2qp, 6, 8, 1}}, F(L.y0), L.y0.bs);
-            return;
-        }
+        if (pair_convs())
+            mfma_pair(it_lvl(l, L_RB1), it_lvl(l, L_RB2), "conv_mfma_pair:res.conv1_conv2_add", B, H2, W2, {{F(L.y0), L.y0.bs}}, dsts, F(L.y0), L.y0.bs);
+        else
 #endif
-        mfma(it_lvl(l, L_RB1), B, H2, W2, {{F(L.y0), L.y0.bs}}, {{F(L.y1), L.y1.bs, 0, 8}});
-        mfma(it_lvl(l, L_RB2), B, H2, W2, {{F(L.y1), L.y1.bs}}, {{prop_next, 6 * P2q, 0, 6}, {carry_l, 6 * P2qp, 6, 8, 1}}, 0, 0, F(L.y0), L.y0.bs);
+        {
+            mfma(it_lvl(l, L_RB1), B, H2, W2, {{F(L.y0), L.y0.bs}}, {{F(L.y1), L.y1.bs, 0, 8}});
+            mfma(it_lvl(l, L_RB2), B, H2, W2, {{F(L.y1), L.y1.bs}}, dsts, 0, 0, F(L.y0), L.y0.bs);
+        }
+        if (!M.cra) return;
+        const Ten& lv = L.c_lv[par][l];
+        mfma(IT_C_T0 + l, B, H2, W2, {{F(L.c_y), L.c_y.bs}, {F(lv), lv.bs}}, {{F(L.c_f), L.c_f.bs, 0, 8}});
+        RUN(launch_cra_blend(F(L.c_y), L.c_y.bs, F(L.c_f), L.c_f.bs, mk, mk_b, prop_next, 6 * P2q, carry_l, 6 * P2qp, B, H2, W2, s));
     }
 
     // What one frame step reads and writes outside the workspace: frame i of each of the B clips, so every batch stride is
@@ -782,11 +838,27 @@ struct Runner {
         if (parts & 1) {
             const Ten& xin = L.xin8[par];
             RUN(launch_hr_prep(io.lr, io.fv, io.mk, F(xin), h, w, s, B, io.lr_b, io.fv_b, io.mk_b, xin.bs));
+            // CRFP_DSV_CRA: slice1's output feeds conv_lv3 (-> x_hr, what conv_tttf blends in) and the three 2x levels
+            const Ten& s1 = M.cra ? L.c_s1 : L.x_hr[par];
             if (pair_mask() & 1)
-                narrow_pair(IT_EH0, IT_EH1, "conv_narrow_pair:enc_hr", H8, W8, {{F(xin), xin.bs}, {adv(F(xin), P8q), xin.bs}}, {F(L.x_hr[par]), L.x_hr[par].bs});
+                narrow_pair(IT_EH0, IT_EH1, "conv_narrow_pair:enc_hr", H8, W8, {{F(xin), xin.bs}, {adv(F(xin), P8q), xin.bs}}, {F(s1), s1.bs});
             else {
                 narrow(IT_EH0, H8, W8, {{F(xin), xin.bs}, {adv(F(xin), P8q), xin.bs}}, {F(L.eh[par]), L.eh[par].bs});
-                narrow(IT_EH1, H8, W8, {{F(L.eh[par]), L.eh[par].bs}}, {F(L.x_hr[par]), L.x_hr[par].bs});
+                narrow(IT_EH1, H8, W8, {{F(L.eh[par]), L.eh[par].bs}}, {F(s1), s1.bs});
+            }
+            if (M.cra) {
+                narrow(IT_C_LV3, H8, W8, {{F(s1), s1.bs}}, {F(L.x_hr[par]), L.x_hr[par].bs});
+                const Q4 a = q(L.c_a, 4, H2, W2), b = q(L.c_b, 4, H2, W2);
+                auto lv = [&](int k) { return q(L.c_lv[par][k], 4, H2, W2); };
+                mfma(IT_C_S2A, B, H2, W2, {{F(s1), s1.bs, 0}}, {{a.p, a.bs(), 0, 4}});
+                mfma_q(IT_C_S2B, B, a, b);
+                mfma_q(IT_C_LV2, B, b, lv(2));
+                mfma_q(IT_C_S3A, B, b, a);
+                mfma_q(IT_C_S3B, B, a, b);
+                mfma_q(IT_C_LV1, B, b, lv(1));
+                mfma_q(IT_C_S4A, B, b, a);
+                mfma_q(IT_C_S4B, B, a, b);
+                mfma_q(IT_C_LV0, B, b, lv(0));
             }
             if (before_ups && !rc && hipStreamWaitEvent(s, before_ups, 0) != hipSuccess) { set_error("dsv: hipStreamWaitEvent failed"); rc = 1; }
             mfma(IT_UPS, B, h, w, {{io.x_lr, io.x_b}}, {{F(L.prop0[par]), L.prop0[par].bs, 0, 6}}, H2, W2);
@@ -871,7 +943,7 @@ struct Runner {
                     mfma(it_lvl(l, L_RB0), 1, H2, W2, {{F(L.sc_prop), 0}, {F(L.sc_cw), 0}, {F(L.sc_al), 0}}, {{F(L.y0), 0, 0, 8}});
                 } else
                     mfma(it_lvl(l, L_RB0), B, H2, W2, {{prop, bs6}, {cw, bs6}, {F(L.aligned), bs8}}, {{F(L.y0), bs8, 0, 8}});
-                res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2);
+                res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2, par, io.mk, io.mk_b);
                 prop = prop_next;
                 std::swap(prop_next, prop_other);
                 offprev = f;
@@ -909,7 +981,7 @@ struct Runner {
         } else {
             for (int l = 0; l < 3; ++l) {
                 mfma(it_lvl(l, L_RB0F), B, H2, W2, {{prop, bs6}, {nullptr, 0}}, {{F(L.y0), bs8, 0, 8}});
-                res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2);
+                res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2, par, io.mk, io.mk_b);
                 prop = prop_next;
                 std::swap(prop_next, prop_other);
             }
@@ -962,16 +1034,26 @@ int crfp_dsv_param_numel(int index, int y_only) {
     return index % 2 ? co : co * kConvs[ci].cin * 9;
 }
 
-#endif  // parameter table: exported once
+const char* crfp_cra_param_name(int index) {
+    static thread_local std::string s;
+    if (index < 0 || index >= CRFP_CRA_NUM_PARAMS) return nullptr;
+    s = std::string(kConvs[kCraOrder[index / 2]].stem) + (index % 2 ? ".bias" : ".weight");
+    return s.c_str();
+}
 
-size_t CRFP_API(crfp_dsv_packed_weight_bytes)(int y_only) { return model_for(y_only).total_floats * sizeof(float); }
+int crfp_cra_param_numel(int index, int y_only) {
+    if (index < 0 || index >= CRFP_CRA_NUM_PARAMS) return CRFP_E_BADARG;
+    const int ci = kCraOrder[index / 2], co = conv_cout(ci, y_only);
+    return index % 2 ? co : co * kConvs[ci].cin * 9;
+}
 
-int CRFP_API(crfp_dsv_pack_weights)(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
-    const Model& M = model_for(y_only);
-    if (!params || !packed) { set_error("pack_weights: null argument"); return CRFP_E_BADARG; }
+#endif  // parameter tables: exported once
+
+}  // extern "C"
+
+// params: 2 * kNumCraConvs pointers in kConvs order (the CRFP_DSV wiring reads the first 2 * kNumDsvConvs)
+static int pack_weights_impl(const Model& M, const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
     if (packed_bytes < M.total_floats * sizeof(float)) { set_error("pack_weights: packed buffer too small"); return CRFP_E_WORKSPACE; }
-    for (int i = 0; i < CRFP_DSV_NUM_PARAMS; ++i)
-        if (!params[i]) { set_error("pack_weights: parameter %d (%s) is null", i, crfp_dsv_param_name(i)); return CRFP_E_BADARG; }
     hipStream_t s = (hipStream_t)stream;
     float* pk = (float*)packed;
     for (int i = 0; i < IT_COUNT; ++i) {
@@ -1008,6 +1090,30 @@ int CRFP_API(crfp_dsv_pack_weights)(const float* const* params, int y_only, void
     return 0;
 }
 
+extern "C" {
+
+size_t CRFP_API(crfp_dsv_packed_weight_bytes)(int y_only) { return model_for(y_only).total_floats * sizeof(float); }
+size_t CRFP_API(crfp_cra_packed_weight_bytes)(int y_only) { return model_for(y_only, false, true).total_floats * sizeof(float); }
+
+int CRFP_API(crfp_dsv_pack_weights)(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
+    if (!params || !packed) { set_error("pack_weights: null argument"); return CRFP_E_BADARG; }
+    for (int i = 0; i < CRFP_DSV_NUM_PARAMS; ++i)
+        if (!params[i]) { set_error("pack_weights: parameter %d (%s) is null", i, crfp_dsv_param_name(i)); return CRFP_E_BADARG; }
+    return pack_weights_impl(model_for(y_only), params, y_only, packed, packed_bytes, stream);
+}
+
+// params: CRFP_CRA_NUM_PARAMS device pointers in the order of the reference's CRFP_DSV_CRA state_dict (crfp_cra_param_name)
+int CRFP_API(crfp_cra_pack_weights)(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
+    if (!params || !packed) { set_error("pack_weights: null argument"); return CRFP_E_BADARG; }
+    const float* eng[2 * kNumCraConvs];
+    for (int j = 0; j < kNumCraConvs; ++j)
+        for (int k = 0; k < 2; ++k) {
+            if (!params[2 * j + k]) { set_error("pack_weights: parameter %d (%s) is null", 2 * j + k, crfp_cra_param_name(2 * j + k)); return CRFP_E_BADARG; }
+            eng[2 * kCraOrder[j] + k] = params[2 * j + k];
+        }
+    return pack_weights_impl(model_for(y_only, false, true), eng, y_only, packed, packed_bytes, stream);
+}
+
 static bool dims_ok(int n, int t, int h, int w) { return n >= 1 && t >= 1 && h >= 8 && w >= 8 && (long long)n * t <= (1 << 20); }
 
 size_t CRFP_API(crfp_dsv_batch_workspace_bytes)(int n, int t, int h, int w) {
@@ -1015,6 +1121,10 @@ size_t CRFP_API(crfp_dsv_batch_workspace_bytes)(int n, int t, int h, int w) {
     return Layout(n, t, h, w).bytes();
 }
 size_t CRFP_API(crfp_dsv_workspace_bytes)(int t, int h, int w) { return CRFP_API(crfp_dsv_batch_workspace_bytes)(1, t, h, w); }
+size_t CRFP_API(crfp_cra_batch_workspace_bytes)(int n, int t, int h, int w) {
+    if (!dims_ok(n, t, h, w)) return 0;
+    return Layout(n, t, h, w, true).bytes();
+}
 
 static int check_common(const void* packed, int n, int t, int h, int w, void* ws, size_t ws_bytes, const Layout& L) {
     if (!packed || !ws) { set_error("dsv: null packed weights or workspace"); return CRFP_E_BADARG; }
@@ -1028,20 +1138,26 @@ size_t CRFP_API(crfp_dsv_batch_status_offset)(int n, int t, int h, int w) {
     return Layout(n, t, h, w).status;
 }
 size_t CRFP_API(crfp_dsv_status_offset)(int t, int h, int w) { return CRFP_API(crfp_dsv_batch_status_offset)(1, t, h, w); }
+size_t CRFP_API(crfp_cra_batch_status_offset)(int n, int t, int h, int w) {
+    if (!dims_ok(n, t, h, w)) return 0;
+    return Layout(n, t, h, w, true).status;
+}
+
+}  // extern "C"
 
 // n clips in lock-step through the recurrent chain (reference model/CRFP.py:1510-1535: every op of forward() carries the batch
 // axis n): ONE launch per layer and frame step over all n clips, so a 360 x 640 map that is a single round of workgroups for one
 // clip becomes n rounds whose load / MFMA / store phases overlap.  Per clip the arithmetic is that of a one-clip call, bit for bit.
-int CRFP_API(crfp_dsv_forward_batch)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
-                           float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+static int forward_batch_impl(bool cra, const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                              float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
     const int y_only = flags & CRFP_DSV_Y_ONLY;
     if (kActBf16 && (flags & CRFP_DSV_STRICT_F32)) { set_error("dsv (bf16 storage): CRFP_DSV_STRICT_F32 belongs to the fp32 entry points"); return CRFP_E_UNSUPPORTED; }
     if (!dims_ok(n, t, h, w)) { set_error("dsv: need n,t>=1, h,w>=8 (got %d,%d,%d,%d)", n, t, h, w); return CRFP_E_BADARG; }
-    Layout L(n, t, h, w);
+    Layout L(n, t, h, w, cra);
     int rc = check_common(packed, n, t, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     if (!lrs || !fvs || !mks || !out) { set_error("dsv_forward_clip: null tensor"); return CRFP_E_BADARG; }
-    Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32, cra), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
     const int TC = L.TC;
     SideStream* ssp = side_stream_enabled() && !prof_enabled() && !(flags & CRFP_DSV_SINGLE_STREAM) ? side_stream() : nullptr;
@@ -1108,6 +1224,21 @@ int CRFP_API(crfp_dsv_forward_batch)(const void* packed, int flags, const float*
     }
     if (R.rc) join();   // a launch failed mid-clip: the last pre_done wait may not have been enqueued
     return R.rc;
+}
+
+extern "C" {
+
+int CRFP_API(crfp_dsv_forward_batch)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                           float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_batch_impl(false, packed, flags, lrs, fvs, mks, out, n, t, h, w, workspace, workspace_bytes, stream);
+}
+
+// The same call for the reference's CRFP_DSV_CRA wiring (model/CRFP.py:2314-2664): packed = crfp_cra_pack_weights' buffer, workspace sized by
+// crfp_cra_batch_workspace_bytes.  Schedule, status words and flags as crfp_dsv_forward_batch; the four-level fovea encoder is
+// state-independent and runs with the rest of a frame's pre-work on the side stream.
+int CRFP_API(crfp_cra_forward_batch)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                           float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_batch_impl(true, packed, flags, lrs, fvs, mks, out, n, t, h, w, workspace, workspace_bytes, stream);
 }
 
 int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,

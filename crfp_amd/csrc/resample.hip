@@ -315,6 +315,36 @@ int launch_scale_q4(const float* src, int src_pad, float* dst, int nq, int H, in
     return 0;
 }
 
+// CRFP_DSV_CRA's cross-resolution fusion at one 2x level (reference model/CRFP.py:2533-2535 and twins): out = mk2 * fused + (1 - mk2) * y with
+// mk2 = F.interpolate(mk.float(), scale_factor=0.25, bilinear) -- at that ratio the mean of the centre 2 x 2 pixels of every 4 x 4 block
+// (source coordinate 4 d + 1.5, weights 1/2, 1/2) -- and the 32 output channels split into the propagated 24 (plain Q4) and the
+// carried 8 (P4 planes), exactly where the residual block's second conv puts them in the plain CRFP_DSV wiring
+__global__ void cra_blend_kernel(const act_t* __restrict__ y, long long y_b, const act_t* __restrict__ f, long long f_b,
+                                 const uint8_t* __restrict__ mk, long long mk_b, act_t* __restrict__ prop, long long prop_b,
+                                 act_t* __restrict__ carry, long long carry_b, int H, int W) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
+    if (x >= W || yy >= H) return;
+    const uint8_t* m = mk + n * mk_b + (long long)(4 * yy + 1) * (4 * W) + 4 * x + 1;
+    const float a = m[0] ? 1.0f : 0.0f, b = m[1] ? 1.0f : 0.0f, c = m[4 * W] ? 1.0f : 0.0f, d = m[4 * W + 1] ? 1.0f : 0.0f;
+    const float mk2 = (a * 0.5f + b * 0.5f) * 0.5f + (c * 0.5f + d * 0.5f) * 0.5f, inv = 1.0f - mk2;
+    const long long pix = (long long)yy * W + x, plane = (long long)H * W;
+    for (int q = 0; q < 8; ++q) {
+        const cf32x4 vy = ldq(y + n * y_b + (q * plane + pix) * 4), vf = ldq(f + n * f_b + (q * plane + pix) * 4);
+        const cf32x4 o = vf * mk2 + vy * inv;
+        if (q < 6) stq(prop + n * prop_b + (q * plane + pix) * 4, o);
+        else stq(carry + n * carry_b + (((long long)(q - 6) * (H + 1) + yy) * (W + 1) + x) * 4, o);
+    }
+}
+
+int launch_cra_blend(const float* y, long long y_b, const float* fused, long long f_b, const uint8_t* mk, long long mk_b, float* prop,
+                     long long prop_b, float* carry, long long carry_b, int N, int H, int W, hipStream_t s) {
+    ProfScope prof("cra_blend", s, (double)N * H * W * (3.0 * 32 * sizeof(act_t) + 4.0), 0);
+    cra_blend_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(as_act(y), y_b, as_act(fused), f_b, mk, mk_b, as_act(prop), prop_b,
+                                                                      as_act(carry), carry_b, H, W);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
 #ifndef CRFP_ACT_BF16
 // nn.AvgPool2d(2, 2) on NCHW planes (floor mode: a trailing odd row / column is dropped) -- FNet's pooling (model/CRFP.py:755)
 __global__ void avgpool2_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int OH, int OW) {

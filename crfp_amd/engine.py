@@ -10,8 +10,11 @@ from . import _lib
 from .ops import _dev, _stream
 
 
-def param_names():
+def param_names(wiring: str = "dsv"):
+    """The reference's state_dict keys in the order the pack call takes them: ``dsv`` = CRFP_DSV, ``cra`` = CRFP_DSV_CRA."""
     L = _lib.lib()
+    if wiring == "cra":
+        return [L.crfp_cra_param_name(i).decode() for i in range(_lib.CRA_NUM_PARAMS)]
     return [L.crfp_dsv_param_name(i).decode() for i in range(_lib.NUM_PARAMS)]
 
 
@@ -54,20 +57,23 @@ class DSVEngine:
         self._stream_hw = None
         self.pack(state_dict)
 
+    WIRING = "dsv"   # which parameter table / entry-point family this handle drives (CRAEngine: "cra")
+
     def _fn(self, name):
         return getattr(_lib.lib(), name + self._sfx)
 
     def pack(self, state_dict):
         L = _lib.lib()
-        names = param_names()
+        names = param_names(self.WIRING)
         missing = [k for k in names if k not in state_dict]
         if missing:
-            raise KeyError(f"state_dict lacks CRFP_DSV parameters: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+            raise KeyError(f"state_dict lacks {'CRFP_DSV_CRA' if self.WIRING == 'cra' else 'CRFP_DSV'} parameters: {missing[:4]}{'...' if len(missing) > 4 else ''}")
         keep = []
-        ptrs = (C.c_void_p * _lib.NUM_PARAMS)()
+        ptrs = (C.c_void_p * len(names))()
+        numel = L.crfp_cra_param_numel if self.WIRING == "cra" else L.crfp_dsv_param_numel
         for i, k in enumerate(names):
             t = state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
-            want = L.crfp_dsv_param_numel(i, self.y_only)
+            want = numel(i, self.y_only)
             if t.numel() != want:
                 raise ValueError(f"parameter {k}: {t.numel()} elements, expected {want}")
             keep.append(t)
@@ -352,3 +358,31 @@ class RuntimeEngine:
                     ovf |= ws[:4].view(torch.int32)
         self._ovf = ovf if ovf is not None else ws[:4].view(torch.int32)
         return out
+
+
+class CRAEngine(DSVEngine):
+    """Handle on the one-call schedule of the reference's CRFP_DSV_CRA wiring (crfp_cra_* entry points, include/crfp_hip.h): the same
+    clip / lock-step batch forward, flags, status words and overflow policies as DSVEngine, over this wiring's own packed weights and
+    workspace.  Clip forward only: the reference's one-frame-per-call model (model/CRFP_test.py) is the plain CRFP_DSV."""
+
+    WIRING = "cra"
+    _MAP = {"crfp_dsv_packed_weight_bytes": "crfp_cra_packed_weight_bytes", "crfp_dsv_pack_weights": "crfp_cra_pack_weights",
+            "crfp_dsv_batch_workspace_bytes": "crfp_cra_batch_workspace_bytes", "crfp_dsv_batch_status_offset": "crfp_cra_batch_status_offset",
+            "crfp_dsv_forward_batch": "crfp_cra_forward_batch"}
+
+    def _fn(self, name):
+        if name == "crfp_dsv_forward_clip":   # batch_mode "loop": the n = 1 form of the batch call
+            f = getattr(_lib.lib(), "crfp_cra_forward_batch" + self._sfx)
+            return lambda packed, flags, lrs, fvs, mks, out, t, h, w, ws, nb, stream: f(packed, flags, lrs, fvs, mks, out, 1, t, h, w, ws, nb, stream)
+        if name not in self._MAP:
+            raise NotImplementedError(f"crfp_amd: {name} has no CRFP_DSV_CRA counterpart (clip forward only)")
+        return getattr(_lib.lib(), self._MAP[name] + self._sfx)
+
+    def stream_frame(self, *a, **k):
+        raise NotImplementedError("crfp_amd: the one-frame-per-call schedule exists for the plain CRFP_DSV wiring only")
+
+    def compute_flow(self, cur, prev):
+        raise NotImplementedError("crfp_amd: use the model's flow network modules (CRFP_DSV_CRA.compute_flow)")
+
+    def debug_fetch(self, name, t, h, w):
+        raise NotImplementedError("crfp_amd: debug_fetch reads the CRFP_DSV workspace layout")

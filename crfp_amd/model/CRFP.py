@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from crfp_amd import ops
 from crfp_amd.dcn_v2 import DCNv2
-from crfp_amd.engine import DSVEngine
+from crfp_amd.engine import CRAEngine, DSVEngine
 from . import LTE
 
 
@@ -339,6 +339,8 @@ class CRFP_DSV(nn.Module):
         writing parameters through ``.data`` (see ``_signature``)."""
         self._engine_sig = None
 
+    _engine_class = DSVEngine
+
     def has_engine(self) -> bool:
         """The one-call C++ schedule (csrc/engine.hip) exists for the configuration the reference ships and evaluates (main.py:34 with
         eval.sh's flags: mid_channels=32, hr_dcn, offset_prop); every other flag combination runs ``forward_composed``."""
@@ -353,7 +355,7 @@ class CRFP_DSV(nn.Module):
         check = os.environ.get("CRFP_CHECK_PACKED") == "1"
         if (self._engine is None or self._engine_sig != sig or self._engine.device != dev
                 or self._engine.storage != self.storage):
-            self._engine = DSVEngine(self.state_dict(), dev, self.y_only, storage=self.storage)
+            self._engine = self._engine_class(self.state_dict(), dev, self.y_only, storage=self.storage)
             self._engine_sig = sig
             self._engine_sum = self._checksum() if check else None
         elif check and self._engine_sum is not None and not torch.equal(self._engine_sum, self._checksum()):
@@ -487,8 +489,11 @@ class CRFP_DSV_CRA(CRFP_DSV):
     factory line): CRFP_DSV plus a cross-resolution fusion of the fovea into every 2x level.  ``encoder_hr`` is the four-level
     ``LTE_simple_hr_ps``; after each level's residual block the 32 features are replaced, under the x0.25-resampled fovea mask, by
     ``conv_tttf_k(cat(features, fovea level k))`` (:2533-2535,2549-2551,2565-2567 and the first-frame twins).  Same constructor,
-    same state_dict table as the reference (tests/golden/dsv_flags.npz).  Runs as a composition of per-operator HIP calls
-    (``forward_composed``): there is no one-call engine schedule for this ablation wiring."""
+    same state_dict table as the reference (tests/golden/dsv_flags.npz).  mid_channels = 32 with both flags on runs the one-call engine
+    schedule of this wiring (``crfp_cra_forward_batch``, crfp_amd.engine.CRAEngine: clip forward, lock-step batches, both storage
+    types); every other constructor combination runs ``forward_composed`` (per-operator HIP calls), as in CRFP_DSV."""
+
+    _engine_class = CRAEngine
 
     def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, spynet_pretrained=None):
         super().__init__(device, mid_channels, y_only, hr_dcn, offset_prop, spynet_pretrained)
@@ -506,8 +511,12 @@ class CRFP_DSV_CRA(CRFP_DSV):
                 for j in range(3):
                     self._modules[f"conv_tttf_{j}"] = conv3x3(m + l * 4, m)
 
-    def has_engine(self) -> bool:
-        return False
+    def compute_flow(self, lrs):
+        n, t, c, h, w = lrs.shape   # the flow network as per-operator calls (the engine computes its flows inside the clip call)
+        return self.spynet(lrs[:, 1:].reshape(-1, c, h, w).contiguous(), lrs[:, :-1].reshape(-1, c, h, w).contiguous()).view(n, t - 1, 2, h, w), None
+
+    def forward_stream(self, lrs, fvs, mks, fgs=None):
+        raise NotImplementedError("crfp_amd: the one-frame-per-call interface belongs to the plain CRFP_DSV wiring (model/CRFP_test.py)")
 
     def _encode_hr(self, x6, n, t):
         lv0, lv1, lv2, lv3 = self.encoder_hr(x6)

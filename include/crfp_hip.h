@@ -235,6 +235,23 @@ int crfp_dsv_stream_batch(const void* packed, int flags, const float* lr, const 
                           const uint8_t* mk, const uint8_t* fg, float* out, int first, int n, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* ---- CRFP_DSV_CRA engine: the reference's cross-resolution-fusion wiring of the same model (model/CRFP.py:2314-2664; the `_cra` run of
+ * eval.sh, factory line main.py:35): CRFP_DSV with the four-level fovea encoder LTE_simple_hr_ps (:156-166) and, after each 2x level's
+ * residual block, features <- mk2 * conv_tttf_k(cat(features, fovea level k)) + (1 - mk2) * features with mk2 the x0.25 bilinear resample
+ * of the fovea mask (:2501,2533-2535).  mid_channels = 32, hr_dcn = offset_prop = True.  Parameters: CRFP_CRA_NUM_PARAMS device pointers in
+ * the order of the reference's CRFP_DSV_CRA state_dict (crfp_cra_param_name).  The forward call takes the tensors, flags, status words and
+ * workspace rules of crfp_dsv_forward_batch (n clips in lock-step, bit-identical per clip to n one-clip calls); packed weights and
+ * workspaces are this wiring's own (query the crfp_cra_* sizes). */
+#define CRFP_CRA_NUM_PARAMS 144
+const char* crfp_cra_param_name(int index);
+int crfp_cra_param_numel(int index, int y_only);
+size_t crfp_cra_packed_weight_bytes(int y_only);
+int crfp_cra_pack_weights(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+size_t crfp_cra_batch_workspace_bytes(int n, int t, int h, int w);
+size_t crfp_cra_batch_status_offset(int n, int t, int h, int w);
+int crfp_cra_forward_batch(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                           float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- bf16 storage (BASELINE configs 3-5): the same engine with every activation tensor and the recurrent state held
  * as bf16 in HBM (half the traffic of the HBM-bound kernels, one bf16 MFMA per product instead of three fp16 ones).
  * What stays fp32: the API tensors (lrs, fvs, out), all accumulators and interpolation arithmetic, biases, and everything
@@ -258,6 +275,12 @@ int crfp_dsv_stream_frame_bf16(const void* packed, int flags, const float* lr, c
 int crfp_dsv_stream_batch_bf16(const void* packed, int flags, const float* lr, const float* lr_prev, const float* fv,
                                const uint8_t* mk, const uint8_t* fg, float* out, int first, int n, int h, int w, void* workspace,
                                size_t workspace_bytes, void* stream);
+size_t crfp_cra_packed_weight_bytes_bf16(int y_only);
+int crfp_cra_pack_weights_bf16(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+size_t crfp_cra_batch_workspace_bytes_bf16(int n, int t, int h, int w);
+size_t crfp_cra_batch_status_offset_bf16(int n, int t, int h, int w);
+int crfp_cra_forward_batch_bf16(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                                float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 int crfp_fnet_forward_bf16(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
                            void* workspace, size_t workspace_bytes, void* stream);
 int crfp_dsv_debug_fetch_bf16(const char* name, int t, int h, int w, const void* workspace, float* out_nchw,
