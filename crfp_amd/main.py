@@ -53,8 +53,13 @@ def build_model(args, device, spynet_pretrained='pretrained_models/fnet.pth'):
     from .model import CRFP
     if spynet_pretrained is not None and not os.path.exists(spynet_pretrained):
         spynet_pretrained = None
-    return CRFP.CRFP_DSV(mid_channels=32, y_only=args.y_only, hr_dcn=args.hr_dcn, offset_prop=args.offset_prop,
-                         spynet_pretrained=spynet_pretrained, device=device).to(device)
+    # The reference switches wirings by (un)commenting a factory line (main.py:34-35: CRFP_DSV is live, CRFP_DSV_CRA commented out);
+    # here the class name comes from the environment, default the live line
+    name = os.environ.get("CRFP_MODEL", "CRFP_DSV")
+    if name not in ("CRFP_DSV", "CRFP_DSV_CRA", "CRFP", "CRFP_simple"):
+        raise SystemExit(f"crfp_amd: CRFP_MODEL={name!r}: expected CRFP_DSV, CRFP_DSV_CRA, CRFP or CRFP_simple (classes of model/CRFP.py)")
+    return getattr(CRFP, name)(mid_channels=32, y_only=args.y_only, hr_dcn=args.hr_dcn, offset_prop=args.offset_prop,
+                               spynet_pretrained=spynet_pretrained, device=device).to(device)
 
 
 def main(argv=None):

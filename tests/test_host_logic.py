@@ -332,3 +332,18 @@ def test_committed_pmc_summaries_belong_to_the_shipped_kernels():
     for name in ("pmc_summary_latest", "pmc_summary_latest_bf16", "pmc_summary_latest_c4"):
         meta = json.load(open(os.path.join(ROOT, "profiles", name + ".meta.json")))
         assert meta["kernels_src_sha"] == _lib.kernel_source_digest(), f"profiles/{name}.json is stale: re-run tools/measure_round.sh and copy the summaries"
+
+
+def test_main_builds_the_wiring_the_environment_names(monkeypatch):
+    """main.py:34-35: the reference switches between CRFP_DSV and CRFP_DSV_CRA by (un)commenting a factory line; here CRFP_MODEL names it."""
+    import types
+    from crfp_amd import main
+    args = types.SimpleNamespace(y_only=False, hr_dcn=True, offset_prop=True)
+    monkeypatch.delenv("CRFP_MODEL", raising=False)
+    assert type(main.build_model(args, torch.device("cpu"), None)).__name__ == "CRFP_DSV"
+    monkeypatch.setenv("CRFP_MODEL", "CRFP_DSV_CRA")
+    m = main.build_model(args, torch.device("cpu"), None)
+    assert type(m).__name__ == "CRFP_DSV_CRA" and m.has_engine() and "conv_tttf_2.weight" in m.state_dict()
+    monkeypatch.setenv("CRFP_MODEL", "BasicVSR")
+    with pytest.raises(SystemExit):
+        main.build_model(args, torch.device("cpu"), None)
