@@ -36,6 +36,8 @@ Extra objects on that line:
                 the time of ALL warp / DCN kernels of such a frame, the fused offset-head + DCN kernel included.
   lockstep_batch_frames_per_sec  (clip configs) n = 2 / 4 clips per crfp_dsv_forward_batch call (lock-step launches over the clips), bit-exactness against
                 one-clip calls; warp_dcn_8d_spec_weights: the 8(d) figure, frames/s and parity with SURVEY 8(d)'s own N(0, 0.02) DCN heads.
+  cra_engine    (config 2) CRFP_DSV_CRA, the reference's cross-resolution-fusion wiring, on its own one-call schedule: frames/s and the
+                difference to the per-operator composition of the same model.
   collectives   which backend ran the barrier / MAX / SUM reductions (CRFP_FORCE_DIST=1 initialises RCCL even with one rank).
 """
 import argparse
@@ -558,6 +560,31 @@ def main():
         result["lockstep_batch_frames_per_sec"] = lb
         torch.cuda.empty_cache()
 
+    if extras and mode == "clip" and args.config == 2:
+        # the reference's other shipped-size wiring, CRFP_DSV_CRA (model/CRFP.py:2314; eval.sh's `_cra` run), on its own one-call schedule
+        # (crfp_cra_forward_batch): frames/s on this config's clip, checked against the per-operator composition of the same model
+        with torch.no_grad():
+            cra = CRFP.CRFP_DSV_CRA(device=dev, mid_channels=32)
+            cra_sd = synth.make_state_dict_like({k: tuple(v.shape) for k, v in cra.state_dict().items()}, 1)
+            cra.load_state_dict({k: torch.from_numpy(v) for k, v in cra_sd.items()})
+            cra = cra.to(dev).eval()
+            cra.storage = storage
+            d0 = data1[0]
+            got_c = cra(*d0)
+            ref_c = cra.forward_composed(*d0)
+            torch.cuda.synchronize()
+            n_s = max(2, min(args.steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(n_s):
+                cra(*d0)
+            torch.cuda.synchronize()
+            result["cra_engine"] = {"frames_per_sec": t * n_s / (time.perf_counter() - t0), "entry_point": "crfp_cra_forward_batch",
+                                    "max_abs_diff_vs_per_operator_composition": float((got_c - ref_c).abs().max()), "tolerance": 2e-4,
+                                    "note": "CRFP_DSV_CRA(mid_channels=32) on this config's clip, one clip per call"}
+            assert result["cra_engine"]["max_abs_diff_vs_per_operator_composition"] < 2e-4, result["cra_engine"]
+            del cra, got_c, ref_c
+        torch.cuda.empty_cache()
+
     if extras and storage == "f32":
         # the per-operator C-ABI entry points (NCHW API tensors in and out: each call includes its layout conversions)
         H2, W2, H8, W8 = 2 * h, 2 * w, 8 * h, 8 * w
@@ -667,7 +694,8 @@ def main():
 
     if rank == 0:
         for key, src, field in (("strict_f32_frames_per_sec", "strict_f32", "frames_per_sec"), ("warp_dcn_8d_frac", "warp_dcn_8d", "frac"),
-                                ("warp_dcn_frac", "warp_dcn", "frac"), ("dcn_fused_avg_us", "dcn_fused", "avg_us")):
+                                ("warp_dcn_frac", "warp_dcn", "frac"), ("dcn_fused_avg_us", "dcn_fused", "avg_us"),
+                                ("cra_engine_frames_per_sec", "cra_engine", "frames_per_sec")):
             if src in result:
                 result[key] = result[src][field]
         result["psnr_reduce"] = benchutil.psnr_reduce_record(vec, world)
