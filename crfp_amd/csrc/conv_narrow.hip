@@ -89,7 +89,11 @@ __device__ __forceinline__ void narrow_src_index(int dst, float scale, int in_si
     l0 = 1.0f - l1;
 }
 
-template <int KQ, int EPI>
+// GATE: NarrowArgs::gate holds, per 64 x 16 tile of this launch's map, whether the fovea mask has a set pixel within `gate_h` tiles of the
+// tile (mask_gate_kernel, resample.hip).  NE_PLAIN: tiles without one are not computed at all -- their outputs only ever feed pixels the
+// fovea blend deselects (encoder_hr, model/CRFP.py:1545-1547 -> conv_tttf's select, :1672-1675).  NE_BLEND: such tiles skip the second
+// source's loads and the MFMAs; the epilogue's `mask ? conv : centre` select picks the centre there anyway.
+template <int KQ, int EPI, bool GATE = false>
 __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_NARROW_OCC2 : CRFP_NARROW_OCC3)) void conv3x3_narrow_kernel(const NarrowArgs a) {
 #ifdef CRFP_ACT_BF16
     __shared__ cu32x2 tile[KQ][NLH][NLW];   // bf16 quads as they sit in HBM (8 bytes)
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     // load (`if (inside) r = load`) makes hipcc wait for each load right behind its issue (the select that merges the
     // zero needs the data) -- the first version's ISA read `G V(0) G V(0) ...`, five full memory latencies per quad.
     // Outside-image elements are zeroed when the registers are written to LDS.
-#define CRFP_NARROW_LOAD(T)                                                                               \
+#define CRFP_NARROW_LOAD(T, ACT)                                                                          \
     {                                                                                                     \
         const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * NTW, y0_ = ty_ * NTH;                \
         int cgy[NST], cgx[NST];                                                                           \
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         }                                                                                                 \
         if (!(NPROBE & 4))                                                                                \
         _Pragma("unroll") for (int k = 0; k < KQ; ++k) {                                                  \
+            if (GATE && EPI == NE_BLEND && k > 0 && !(ACT)) continue;   /* workgroup-uniform */               \
             if (qflow[k]) {   /* wave-uniform */                                                          \
                 _Pragma("unroll") for (int t = 0; t < NST; ++t)                                           \
                     r[k][t] = raw_flow(qbase[k] + ((long long)cgy[t] * W + cgx[t]) * 8);                  \
@@ -234,8 +239,13 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     const int band1 = BAND ? band0 + xq + (xcd < xr ? 1 : 0) : ntiles;
     const int t_step = BAND ? ((int)gridDim.x - xcd + 7) >> 3 : (int)gridDim.x;   // workgroups on this XCD
     int t_cur = BAND ? band0 + (blockIdx.x >> 3) : (int)blockIdx.x;
+    // gate flags of this batch item: 4 bytes per tile (halo 0 .. 3), this launch reads byte gate_h
+    const uint8_t* const gate = GATE ? a.gate + (long long)n * a.gate_bstride + a.gate_h : nullptr;
+    if (GATE && EPI != NE_BLEND)
+        while (t_cur < band1 && !gate[4 * t_cur]) t_cur += t_step;
     if (t_cur >= band1) return;
-    CRFP_NARROW_LOAD(t_cur)
+    bool act_cur = !GATE || gate[4 * t_cur] != 0;
+    CRFP_NARROW_LOAD(t_cur, act_cur)
     for (;;) {
 #pragma unroll
         for (int k = 0; k < KQ; ++k)
@@ -249,13 +259,17 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
 #endif
             }
         __syncthreads();
-        const int t_next = t_cur + t_step;
-        if (t_next < band1) CRFP_NARROW_LOAD(t_next)     // flies during the FMAs and stores below
+        int t_next = t_cur + t_step;
+        if (GATE && EPI != NE_BLEND)
+            while (t_next < band1 && !gate[4 * t_next]) t_next += t_step;
+        const bool act_next = !GATE || (t_next < band1 && gate[4 * t_next] != 0);
+        if (t_next < band1) CRFP_NARROW_LOAD(t_next, act_next)     // flies during the FMAs and stores below
 
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{bias.x, bias.y, bias.z, bias.w};
 #ifdef CRFP_ACT_BF16
+        if (!(GATE && EPI == NE_BLEND) || act_cur)
 #pragma unroll
         for (int k = 0; k < KQ; ++k)
 #pragma unroll
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         // a quad needs 18 halo + 9 weight ds_read_b128 (27 instead of 45 when the rows shared by the ky are re-read) and
         // stays at 108 / 128 / 149 VGPRs for KQ = 1 / 2 / 3 (+0.7 % clip); the FMA form spilled when ky was unrolled.
 #pragma unroll 1
-        for (int k = 0; k < ((NPROBE & 1) ? 0 : KQ); ++k) {
+        for (int k = 0; k < (((NPROBE & 1) || (GATE && EPI == NE_BLEND && !act_cur)) ? 0 : KQ); ++k) {
 #pragma unroll (CRFP_NARROW_KY_UNROLL)
             for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -388,6 +402,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         if (EPI == NE_BLEND && ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
         if (t_next >= band1) break;
         t_cur = t_next;
+        act_cur = act_next;
         // every wave is done reading the tile before it is overwritten.  LDS-only barrier: __syncthreads() would also
         // wait (vmcnt(0)) for the write acknowledgement of the stores above, which nobody in the workgroup reads
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -795,6 +810,14 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? CRFP_NARROW_OCC1 : (a.kq == 2 ? CRFP_NARROW_OCC2 : CRFP_NARROW_OCC3));
     const int share = (ntl + 256 * per_cu - 1) / (256 * per_cu);
     dim3 grid((ntl + share - 1) / share, 1, a.N);
+    if (a.gate) {   // mask-gated forms (engine.hip: encoder_hr and the fovea blend)
+        if (a.epi == NE_PLAIN && a.kq == 1) conv3x3_narrow_kernel<1, NE_PLAIN, true><<<grid, 256, 0, s>>>(a);
+        else if (a.epi == NE_PLAIN && a.kq == 2) conv3x3_narrow_kernel<2, NE_PLAIN, true><<<grid, 256, 0, s>>>(a);
+        else if (a.epi == NE_BLEND && a.kq == 2) conv3x3_narrow_kernel<2, NE_BLEND, true><<<grid, 256, 0, s>>>(a);
+        else { set_error("conv_narrow %s: no mask-gated form for kq=%d epi=%d", name, a.kq, a.epi); return CRFP_E_UNSUPPORTED; }
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
 #define CRFP_NARROW_LAUNCH(KQ_)                                                                    \
     switch (a.epi) {                                                                               \
         case NE_PLAIN: conv3x3_narrow_kernel<KQ_, NE_PLAIN><<<grid, 256, 0, s>>>(a); break;        \

@@ -276,6 +276,9 @@ struct NarrowArgs {
     long long* stamps;  // diagnostic builds (-DCRFP_NARROW_STAMPS) only
     unsigned* ovf;      // fp16-operand range guard (see ConvArgs::ovf): NE_BLEND raises it, NE_LAST poisons the frame when set
     int ovf_div, ovf_add;   // see ConvArgs
+    const uint8_t* gate;    // mask gate (launch_mask_gate): 4 flag bytes per 64 x 16 tile of the map, null = dense launch
+    long long gate_bstride; // bytes between batch items
+    int gate_h;             // which flag this launch reads: "a mask pixel within gate_h tiles of the tile" (0 .. 3)
 };
 
 // Activations of the offset/mask heads (DCN modules, model/CRFP.py:338-340): hardware exp2/rcp, ~1 ulp each.
@@ -397,14 +400,19 @@ int launch_avgpool2_nchw(const float* x, float* out, int N, int C, int H, int W,
 int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W,
                        hipStream_t s);
 // N > 1: lr_b / fv_b / mk_b = elements between the batch items of the three API tensors (frames of different clips), out_b likewise
+// gate (optional, launch_mask_gate): only tiles with a mask pixel within 3 tiles are produced (what encoder_hr's two convs then read)
 int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s, int N = 1,
-                   long long lr_b = 0, long long fv_b = 0, long long mk_b = 0, long long out_b = 0);
+                   long long lr_b = 0, long long fv_b = 0, long long mk_b = 0, long long out_b = 0, const uint8_t* gate = nullptr,
+                   long long gate_b = 0);
 int launch_offmask_nchw_to_q4(const float* offset, const float* mask, float* out, int N, int noff, int nmask, int H,
                               int W, hipStream_t s);
 int launch_fg_prep(const uint8_t* fg, float* fg2, int H8, int W8, hipStream_t s);
 // dst = src * scale(y,x); scale is float [H][W] (scale_f) or u8 [H][W] (scale_u8)
 int launch_scale_q4(const float* src, int src_pad, float* dst, int nq, int H, int W, const float* scale_f,
                     const uint8_t* scale_u8, hipStream_t s);
+// Per 64 x 16 tile of the [H8][W8] u8 mask (W8 a multiple of 4), 4 flag bytes: byte k != 0 iff a tile at most k tiles away (Chebyshev) holds
+// a set mask pixel (k = 0 .. 3).  gate: [N] items of gate_b bytes each (>= 4 * tiles).  The tile grid is conv3x3_narrow_kernel's.
+int launch_mask_gate(const uint8_t* mk, long long mk_b, uint8_t* gate, long long gate_b, int N, int H8, int W8, hipStream_t s);
 // CRFP_DSV_CRA level fusion: [prop | carry] = mk2 * fused + (1 - mk2) * y, mk2 = the x0.25 bilinear resample of the u8 mask [4H][4W]
 int launch_cra_blend(const float* y, long long y_b, const float* fused, long long f_b, const uint8_t* mk, long long mk_b, float* prop,
                      long long prop_b, float* carry, long long carry_b, int N, int H, int W, hipStream_t s);

@@ -369,6 +369,9 @@ struct Layout {
     // CRFP_DSV_CRA: slice1's output, the 2x chain's two temporaries, the three fovea levels per buffer set, a level's features and their fused twin
     Ten c_s1, c_a, c_b, c_lv[2][3], c_y, c_f;
     bool cra;
+    // mask gate of each buffer set: 4 flag bytes per 64 x 16 tile of the 8x map and clip (launch_mask_gate); gate_b = bytes per clip
+    Ten gate[2];
+    long long gate_b;
     int h1, w1, h2, w2, h3, w3;
     int fnet_cap;   // pairs one FNet pass can hold
 
@@ -420,6 +423,9 @@ struct Layout {
             prop0[p] = A.take(p ? "prop0.1" : "prop0", B, 6, H2, W2);
             flow2[p] = A.take(p ? "flow2.1" : "flow2", B, 0, H2, W2, 1);
             flow8[p] = A.take(p ? "flow8.1" : "flow8", B, 0, H8, W8, 1);
+            const int gtiles = ((W8 + 63) / 64) * ((H8 + 15) / 16);
+            gate_b = ((long long)gtiles * 4 + 7) / 8 * 8;
+            gate[p] = A.take(p ? "gate.1" : "gate", B, 0, 1, (int)(gate_b / 8), 1);
         }
         prop_a = A.take("prop_a", B, 6, H2, W2);
         prop_b = A.take("prop_b", B, 6, H2, W2);
@@ -636,8 +642,9 @@ struct Runner {
     }
     // 8x-resolution stencils over the B clips of the call.  NB: tensors are {pointer, batch stride in elements of their own type}
     struct NB { const float* p = nullptr; long long bs = 0; NB() {} NB(const float* p_, long long bs_) : p(p_), bs(bs_) {} };
+    // gate_par >= 0: the mask-gated form over buffer set gate_par's flags, reading the "within gate_h pixels" byte
     void narrow(int id, int H, int W, std::vector<NB> srcs, NB dst, NB resid = NB(), NB flow = NB(), const uint8_t* mask = nullptr,
-                long long mask_bs = 0, int src0_pad = 0, int dst_pad = 0, NB base_lr = NB()) {
+                long long mask_bs = 0, int src0_pad = 0, int dst_pad = 0, NB base_lr = NB(), int gate_par = -1, int gate_h = 0) {
         if (rc) return;
         const Item& it = M.items[id];
         NarrowArgs a = it.nw;
@@ -653,6 +660,7 @@ struct Runner {
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
         a.ovf = ovf(); a.ovf_div = ovf_div; a.ovf_add = ovf_add;
+        if (gate_par >= 0 && mask_gate_enabled()) { a.gate = gate_ptr(gate_par); a.gate_bstride = L.gate_b; a.gate_h = gate_h; }
         rc = launch_narrow(a, it.name, s);
     }
     // two stencils in one pass: item idA (its output has no other reader) feeding item idB (conv_narrow.hip, launch_narrow_pair)
@@ -678,6 +686,15 @@ struct Runner {
     // single convs run on the bf16 MFMA and two of them beat the pair kernel (41 vs 47.5 us)
     static constexpr int pair_mask() { return kActBf16 ? 0 : 4; }
 #define RUN(expr) do { if (!rc) rc = (expr); } while (0)
+
+    // The fovea blend is a select under the mask (model/CRFP.py:1543-1544,1674-1675): what is computed only to be deselected -- the x8
+    // frame stack, encoder_hr and conv_tttf away from the fovea -- is skipped tile by tile, same output bits.  CRFP_MASK_GATE=0: dense launches
+    // (the skipped tiles of xin8 / enc_hr0 / x_hr then hold values again: tools/bisect_engine.py).
+    static bool mask_gate_enabled() {
+        static const bool on = !(getenv("CRFP_MASK_GATE") && atoi(getenv("CRFP_MASK_GATE")) == 0);   // read once
+        return on;
+    }
+    const uint8_t* gate_ptr(int par) const { return reinterpret_cast<const uint8_t*>(ws + L.gate[par]); }
 
     // fp32 build: n NCHW LR frames -> Q4 quads in slot s0.. of lr_q4 (see the Model); the bf16 build reads the fp32 frames directly
     // check_div: the frames are the call's own LR input, frame f of clip f / check_div (0: one sequence): values an fp16 operand cannot
@@ -837,17 +854,23 @@ struct Runner {
         const long long P8q = (long long)H8 * W8 * 4;
         if (parts & 1) {
             const Ten& xin = L.xin8[par];
-            RUN(launch_hr_prep(io.lr, io.fv, io.mk, F(xin), h, w, s, B, io.lr_b, io.fv_b, io.mk_b, xin.bs));
+            const bool gated = mask_gate_enabled();
+            if (gated) RUN(launch_mask_gate(io.mk, io.mk_b, const_cast<uint8_t*>(gate_ptr(par)), L.gate_b, B, H8, W8, s));
+            // conv_tttf works on the tiles that hold mask pixels and reads x_hr one pixel into their neighbours: encoder_hr's second conv runs on
+            // that ring of tiles too, its first conv on two rings, the frame stack on three -- no launch reads a tile nobody wrote.
+            // CRFP_DSV_CRA: slice1's output also feeds the three 2x levels, whose reach is wider: only conv_lv3 is gated there.
+            const int gp = (gated && !M.cra && !(pair_mask() & 1)) ? par : -1;
+            RUN(launch_hr_prep(io.lr, io.fv, io.mk, F(xin), h, w, s, B, io.lr_b, io.fv_b, io.mk_b, xin.bs, gp >= 0 ? gate_ptr(par) : nullptr, L.gate_b));
             // CRFP_DSV_CRA: slice1's output feeds conv_lv3 (-> x_hr, what conv_tttf blends in) and the three 2x levels
             const Ten& s1 = M.cra ? L.c_s1 : L.x_hr[par];
             if (pair_mask() & 1)
                 narrow_pair(IT_EH0, IT_EH1, "conv_narrow_pair:enc_hr", H8, W8, {{F(xin), xin.bs}, {adv(F(xin), P8q), xin.bs}}, {F(s1), s1.bs});
             else {
-                narrow(IT_EH0, H8, W8, {{F(xin), xin.bs}, {adv(F(xin), P8q), xin.bs}}, {F(L.eh[par]), L.eh[par].bs});
-                narrow(IT_EH1, H8, W8, {{F(L.eh[par]), L.eh[par].bs}}, {F(s1), s1.bs});
+                narrow(IT_EH0, H8, W8, {{F(xin), xin.bs}, {adv(F(xin), P8q), xin.bs}}, {F(L.eh[par]), L.eh[par].bs}, NB(), NB(), nullptr, 0, 0, 0, NB(), gp, 2);
+                narrow(IT_EH1, H8, W8, {{F(L.eh[par]), L.eh[par].bs}}, {F(s1), s1.bs}, NB(), NB(), nullptr, 0, 0, 0, NB(), gp, 1);
             }
             if (M.cra) {
-                narrow(IT_C_LV3, H8, W8, {{F(s1), s1.bs}}, {F(L.x_hr[par]), L.x_hr[par].bs});
+                narrow(IT_C_LV3, H8, W8, {{F(s1), s1.bs}}, {F(L.x_hr[par]), L.x_hr[par].bs}, NB(), NB(), nullptr, 0, 0, 0, NB(), par, 1);
                 const Q4 a = q(L.c_a, 4, H2, W2), b = q(L.c_b, 4, H2, W2);
                 auto lv = [&](int k) { return q(L.c_lv[par][k], 4, H2, W2); };
                 mfma(IT_C_S2A, B, H2, W2, {{F(s1), s1.bs, 0}}, {{a.p, a.bs(), 0, 4}});
@@ -994,7 +1017,7 @@ struct Runner {
             narrow(IT_R3_1, H8, W8, {nb(L.z0)}, nb(L.z1));
             narrow(IT_R3_2, H8, W8, {nb(L.z1)}, nb(L.feat), nb(L.z0));
         }
-        narrow(IT_TTTF, H8, W8, {nb(L.feat), nb(L.x_hr[par])}, nb(L.state_hr), NB(), NB(), io.mk, io.mk_b, 0, 1);
+        narrow(IT_TTTF, H8, W8, {nb(L.feat), nb(L.x_hr[par])}, nb(L.state_hr), NB(), NB(), io.mk, io.mk_b, 0, 1, NB(), par, 0);
         // output head: conv_last(state) + x8 bilinear LR;
         // the x8 bilinear base is recomputed from the LR frame in both builds (fp32: 39.0 vs 41.3 us against reading the quad hr_prep
         // stored -- identical values, 59 MB less traffic; bf16: a stored bf16 base would cost 2^-9 of the output range)

@@ -240,9 +240,11 @@ int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, i
 //   quad 1 = up8(lr) rgb, 0                 (also the base of the output head)
 __global__ void hr_prep_kernel(const float* __restrict__ lr, const float* __restrict__ fv,
                                const uint8_t* __restrict__ mk, act_t* __restrict__ out, int h, int w, long long lr_b,
-                               long long fv_b, long long mk_b, long long out_b) {
+                               long long fv_b, long long mk_b, long long out_b, const uint8_t* __restrict__ gate, long long gate_b) {
     const int OH = 8 * h, OW = 8 * w;
     const long long n = blockIdx.z;
+    // a 64 x 4 block lies inside the 64 x 16 gate tile (blockIdx.x, blockIdx.y / 4)
+    if (gate && !gate[n * gate_b + 4 * ((long long)(blockIdx.y >> 2) * gridDim.x + blockIdx.x) + 3]) return;
     lr += n * lr_b; fv += n * fv_b; mk += n * mk_b; out += n * out_b;
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -266,10 +268,57 @@ __global__ void hr_prep_kernel(const float* __restrict__ lr, const float* __rest
 }
 
 int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s, int N, long long lr_b,
-                   long long fv_b, long long mk_b, long long out_b) {
+                   long long fv_b, long long mk_b, long long out_b, const uint8_t* gate, long long gate_b) {
     ProfScope prof("hr_prep_up8_blend", s, (double)N * 64 * h * w * (12 + 1 + 32.0), 0);
     dim3 grid((8 * w + 63) / 64, (8 * h + 3) / 4, N);
-    hr_prep_kernel<<<grid, 256, 0, s>>>(lr, fv, mk, as_act(out_q4), h, w, lr_b, fv_b, mk_b, out_b);
+    hr_prep_kernel<<<grid, 256, 0, s>>>(lr, fv, mk, as_act(out_q4), h, w, lr_b, fv_b, mk_b, out_b, gate, gate_b);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// The fovea mask as a tile gate.  The fovea blend is a select (model/CRFP.py:1543-1544,1674), so everything computed only to be
+// deselected -- the x8 frame stack, encoder_hr and conv_tttf away from the fovea -- can be skipped tile by tile with identical results.
+// Per 64 x 16 tile (the tile grid of the 8x stencil kernels) 4 flag bytes: byte 0 = "a mask pixel is set inside the tile" (conv_tttf has work
+// there), byte k = "... inside a tile at most k tiles away" (Chebyshev).  A 3 x 3 conv on an active tile reads its input one pixel into the
+// neighbouring tiles, so each producer up the chain runs on one more ring of tiles and no launch ever reads a tile nobody wrote.
+__global__ void mask_gate_kernel(const uint8_t* __restrict__ mk, long long mk_b, uint8_t* __restrict__ gate, long long gate_b, int H, int W) {
+    const int tile_x = blockIdx.x, tile_y = blockIdx.y, n = blockIdx.z;
+    const uint8_t* m = mk + n * mk_b;
+    int mine = 0;
+    for (int i = threadIdx.x; i < 64 * 16 / 4; i += blockDim.x) {   // 4 mask bytes per thread and step (W is a multiple of 8: 4-byte aligned)
+        const int ry = i >> 4, rx = (i & 15) * 4;
+        const int y = tile_y * 16 + ry, x = tile_x * 64 + rx;
+        if (y < H && x < W) mine |= *reinterpret_cast<const unsigned*>(m + (long long)y * W + x) != 0u;
+    }
+    const int any = __syncthreads_or(mine);
+    if (threadIdx.x == 0) gate[n * gate_b + 4 * ((long long)tile_y * gridDim.x + tile_x)] = any ? 1 : 0;
+}
+
+__global__ void mask_gate_rings_kernel(uint8_t* __restrict__ gate, long long gate_b, int tiles_x, int tiles_y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (t >= tiles_x * tiles_y) return;
+    uint8_t* g = gate + n * gate_b;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    int ring = 4;   // distance to the nearest tile with mask pixels (4 = none within 3)
+    for (int dy = -3; dy <= 3; ++dy)
+        for (int dx = -3; dx <= 3; ++dx) {
+            const int y = ty + dy, x = tx + dx;
+            if (y < 0 || y >= tiles_y || x < 0 || x >= tiles_x || !g[4 * (y * tiles_x + x)]) continue;
+            const int d = max(abs(dy), abs(dx));
+            ring = min(ring, d);
+        }
+    for (int k = 1; k < 4; ++k) g[4 * t + k] = ring <= k ? 1 : 0;
+}
+
+int launch_mask_gate(const uint8_t* mk, long long mk_b, uint8_t* gate, long long gate_b, int N, int H8, int W8, hipStream_t s) {
+    const int tiles_x = (W8 + 63) / 64, tiles_y = (H8 + 15) / 16;
+    {
+        ProfScope prof("mask_gate", s, (double)N * H8 * W8, 0);
+        mask_gate_kernel<<<dim3(tiles_x, tiles_y, N), 64, 0, s>>>(mk, mk_b, gate, gate_b, H8, W8);
+        CRFP_CHECK_LAUNCH();
+    }
+    ProfScope prof("mask_gate_rings", s, (double)N * tiles_x * tiles_y * 8.0, 0);
+    mask_gate_rings_kernel<<<dim3((tiles_x * tiles_y + 255) / 256, N), 256, 0, s>>>(gate, gate_b, tiles_x, tiles_y);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
