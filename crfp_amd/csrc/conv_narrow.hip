@@ -780,8 +780,10 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     if (a.epi == NE_LAST) extra = 3;                 // base quad (3 used)
     if (a.epi == NE_OFFMASK3) extra = 2;             // flow
     if (a.resid) extra += 4;
-    ProfScope prof(name, s, px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * (double)sizeof(act_t),
-                   2.0 * px * in_ch * a.cout * 9.0);
+    // mask-gated launches touch a data-dependent share of the map: plain ones are booked with no algorithmic bytes / flops (their time
+    // still counts), the fovea blend with the bytes every pixel moves -- the state quad in and out and the mask
+    const double bytes = a.gate ? (a.epi == NE_BLEND ? px * (8.0 * sizeof(act_t) + 1.0) : 0.0) : px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * (double)sizeof(act_t);
+    ProfScope prof(name, s, bytes, a.gate ? 0.0 : 2.0 * px * in_ch * a.cout * 9.0);
 #if !defined(CRFP_ACT_BF16) && defined(CRFP_LAB)
     static const int direct = getenv("CRFP_NARROW_DIRECT") ? atoi(getenv("CRFP_NARROW_DIRECT")) : 0;
     bool q4only = true;

@@ -13,6 +13,7 @@
 //   * dcn_3's 9x replication of offset and mask (:343-347) -> never materialised
 //   * the i == 0 branch's zero tensors (:1637,1666) -> K-restricted weight packs (0*w == 0 exactly)
 //   * fovea blend + LeakyReLU (:1674-1675) and conv_last + bilinear base (:1678-1683) -> epilogues
+//   * everything the fovea select discards (:1543-1547 -> :1672-1675 away from the mask) -> mask-gated launches (Runner::mask_gate_enabled)
 #include "crfp_common.h"
 
 #include <cstdlib>

@@ -269,7 +269,7 @@ __global__ void hr_prep_kernel(const float* __restrict__ lr, const float* __rest
 
 int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s, int N, long long lr_b,
                    long long fv_b, long long mk_b, long long out_b, const uint8_t* gate, long long gate_b) {
-    ProfScope prof("hr_prep_up8_blend", s, (double)N * 64 * h * w * (12 + 1 + 32.0), 0);
+    ProfScope prof("hr_prep_up8_blend", s, gate ? 0.0 : (double)N * 64 * h * w * (12 + 1 + 32.0), 0);   // gated: a data-dependent share of the frame
     dim3 grid((8 * w + 63) / 64, (8 * h + 3) / 4, N);
     hr_prep_kernel<<<grid, 256, 0, s>>>(lr, fv, mk, as_act(out_q4), h, w, lr_b, fv_b, mk_b, out_b, gate, gate_b);
     CRFP_CHECK_LAUNCH();
@@ -299,13 +299,19 @@ __global__ void mask_gate_rings_kernel(uint8_t* __restrict__ gate, long long gat
     if (t >= tiles_x * tiles_y) return;
     uint8_t* g = gate + n * gate_b;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    int ring = 4;   // distance to the nearest tile with mask pixels (4 = none within 3)
+    // all 49 flags first (clamped addresses, independent loads), then the distance to the nearest tile with mask pixels (4 = none within 3)
+    uint8_t f[7][7];
+#pragma unroll
     for (int dy = -3; dy <= 3; ++dy)
+#pragma unroll
+        for (int dx = -3; dx <= 3; ++dx) f[dy + 3][dx + 3] = g[4 * (min(max(ty + dy, 0), tiles_y - 1) * tiles_x + min(max(tx + dx, 0), tiles_x - 1))];
+    int ring = 4;
+#pragma unroll
+    for (int dy = -3; dy <= 3; ++dy)
+#pragma unroll
         for (int dx = -3; dx <= 3; ++dx) {
-            const int y = ty + dy, x = tx + dx;
-            if (y < 0 || y >= tiles_y || x < 0 || x >= tiles_x || !g[4 * (y * tiles_x + x)]) continue;
-            const int d = max(abs(dy), abs(dx));
-            ring = min(ring, d);
+            const bool inb = ty + dy >= 0 && ty + dy < tiles_y && tx + dx >= 0 && tx + dx < tiles_x;
+            if (inb && f[dy + 3][dx + 3]) ring = min(ring, max(abs(dy), abs(dx)));
         }
     for (int k = 1; k < 4; ++k) g[4 * t + k] = ring <= k ? 1 : 0;
 }

@@ -200,7 +200,10 @@ size_t crfp_dsv_workspace_bytes(int t, int h, int w);
 size_t crfp_dsv_status_offset(int t, int h, int w);
 
 /* One clip: lrs[t,3,h,w], fvs[t,3,8h,8w] f32, mks[t,1,8h,8w] u8 (bool), out[t,3|1,8h,8w].
- * Zero initial state; flows from FNet(frame i, frame i-1).  (= crfp_dsv_forward_batch with n = 1.) */
+ * Zero initial state; flows from FNet(frame i, frame i-1).  (= crfp_dsv_forward_batch with n = 1.)
+ * mks is used as a select (0 / non-0), as the reference's 0 / 1 float mask acts in fvs * mk + x * (1 - mk): fvs is only ever read where mks is set, and the
+ * work whose result the select discards (the x8 frame stack, encoder_hr and conv_tttf away from the mask) is skipped per 64 x 16 tile, bit-identically
+ * (CRFP_MASK_GATE=0 in the environment launches it densely). */
 int crfp_dsv_forward_clip(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                           float* out, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -10,6 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("CRFP_MASK_GATE", "0")   # dense launches: xin8 / enc_hr0 / x_hr hold values away from the fovea as well (read once by the library)
 from crfp_amd import synth  # noqa: E402
 from crfp_amd.model import CRFP  # noqa: E402
 from oracle import crfp_oracle as orc  # noqa: E402
