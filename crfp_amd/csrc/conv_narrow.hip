@@ -90,9 +90,9 @@ __device__ __forceinline__ void narrow_src_index(int dst, float scale, int in_si
 }
 
 // GATE: NarrowArgs::gate holds, per 64 x 16 tile of this launch's map, whether the fovea mask has a set pixel within `gate_h` tiles of the
-// tile (mask_gate_kernel, resample.hip).  NE_PLAIN: tiles without one are not computed at all -- their outputs only ever feed pixels the
-// fovea blend deselects (encoder_hr, model/CRFP.py:1545-1547 -> conv_tttf's select, :1672-1675).  NE_BLEND: such tiles skip the second
-// source's loads and the MFMAs; the epilogue's `mask ? conv : centre` select picks the centre there anyway.
+// tile (mask_gate_kernel, resample.hip).  Tiles without one are not computed at all.  NE_PLAIN (encoder_hr, model/CRFP.py:1545-1547): their
+// outputs only ever feed pixels the fovea blend deselects.  NE_BLEND (conv_tttf + blend, :1672-1675): there the new state is lrelu(state),
+// which a plain streaming pass has written before this launch (launch_lrelu_q4_to_p4, resample.hip).
 template <int KQ, int EPI, bool GATE = false>
 __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_NARROW_OCC2 : CRFP_NARROW_OCC3)) void conv3x3_narrow_kernel(const NarrowArgs a) {
 #ifdef CRFP_ACT_BF16
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     // load (`if (inside) r = load`) makes hipcc wait for each load right behind its issue (the select that merges the
     // zero needs the data) -- the first version's ISA read `G V(0) G V(0) ...`, five full memory latencies per quad.
     // Outside-image elements are zeroed when the registers are written to LDS.
-#define CRFP_NARROW_LOAD(T, ACT)                                                                          \
+#define CRFP_NARROW_LOAD(T)                                                                               \
     {                                                                                                     \
         const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * NTW, y0_ = ty_ * NTH;                \
         int cgy[NST], cgx[NST];                                                                           \
@@ -221,7 +221,6 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         }                                                                                                 \
         if (!(NPROBE & 4))                                                                                \
         _Pragma("unroll") for (int k = 0; k < KQ; ++k) {                                                  \
-            if (GATE && EPI == NE_BLEND && k > 0 && !(ACT)) continue;   /* workgroup-uniform */               \
             if (qflow[k]) {   /* wave-uniform */                                                          \
                 _Pragma("unroll") for (int t = 0; t < NST; ++t)                                           \
                     r[k][t] = raw_flow(qbase[k] + ((long long)cgy[t] * W + cgx[t]) * 8);                  \
@@ -241,11 +240,10 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     int t_cur = BAND ? band0 + (blockIdx.x >> 3) : (int)blockIdx.x;
     // gate flags of this batch item: 4 bytes per tile (halo 0 .. 3), this launch reads byte gate_h
     const uint8_t* const gate = GATE ? a.gate + (long long)n * a.gate_bstride + a.gate_h : nullptr;
-    if (GATE && EPI != NE_BLEND)
+    if (GATE)
         while (t_cur < band1 && !gate[4 * t_cur]) t_cur += t_step;
     if (t_cur >= band1) return;
-    bool act_cur = !GATE || gate[4 * t_cur] != 0;
-    CRFP_NARROW_LOAD(t_cur, act_cur)
+    CRFP_NARROW_LOAD(t_cur)
     for (;;) {
 #pragma unroll
         for (int k = 0; k < KQ; ++k)
@@ -260,16 +258,14 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
             }
         __syncthreads();
         int t_next = t_cur + t_step;
-        if (GATE && EPI != NE_BLEND)
+        if (GATE)
             while (t_next < band1 && !gate[4 * t_next]) t_next += t_step;
-        const bool act_next = !GATE || (t_next < band1 && gate[4 * t_next] != 0);
-        if (t_next < band1) CRFP_NARROW_LOAD(t_next, act_next)     // flies during the FMAs and stores below
+        if (t_next < band1) CRFP_NARROW_LOAD(t_next)     // flies during the FMAs and stores below
 
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{bias.x, bias.y, bias.z, bias.w};
 #ifdef CRFP_ACT_BF16
-        if (!(GATE && EPI == NE_BLEND) || act_cur)
 #pragma unroll
         for (int k = 0; k < KQ; ++k)
 #pragma unroll
@@ -287,7 +283,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         // a quad needs 18 halo + 9 weight ds_read_b128 (27 instead of 45 when the rows shared by the ky are re-read) and
         // stays at 108 / 128 / 149 VGPRs for KQ = 1 / 2 / 3 (+0.7 % clip); the FMA form spilled when ky was unrolled.
 #pragma unroll 1
-        for (int k = 0; k < (((NPROBE & 1) || (GATE && EPI == NE_BLEND && !act_cur)) ? 0 : KQ); ++k) {
+        for (int k = 0; k < ((NPROBE & 1) ? 0 : KQ); ++k) {
 #pragma unroll (CRFP_NARROW_KY_UNROLL)
             for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -402,7 +398,6 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
         if (EPI == NE_BLEND && ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
         if (t_next >= band1) break;
         t_cur = t_next;
-        act_cur = act_next;
         // every wave is done reading the tile before it is overwritten.  LDS-only barrier: __syncthreads() would also
         // wait (vmcnt(0)) for the write acknowledgement of the stores above, which nobody in the workgroup reads
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -780,9 +775,8 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     if (a.epi == NE_LAST) extra = 3;                 // base quad (3 used)
     if (a.epi == NE_OFFMASK3) extra = 2;             // flow
     if (a.resid) extra += 4;
-    // mask-gated launches touch a data-dependent share of the map: plain ones are booked with no algorithmic bytes / flops (their time
-    // still counts), the fovea blend with the bytes every pixel moves -- the state quad in and out and the mask
-    const double bytes = a.gate ? (a.epi == NE_BLEND ? px * (8.0 * sizeof(act_t) + 1.0) : 0.0) : px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * (double)sizeof(act_t);
+    // mask-gated launches touch a data-dependent share of the map: they are booked with no algorithmic bytes / flops (their time still counts)
+    const double bytes = a.gate ? 0.0 : px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * (double)sizeof(act_t);
     ProfScope prof(name, s, bytes, a.gate ? 0.0 : 2.0 * px * in_ch * a.cout * 9.0);
 #if !defined(CRFP_ACT_BF16) && defined(CRFP_LAB)
     static const int direct = getenv("CRFP_NARROW_DIRECT") ? atoi(getenv("CRFP_NARROW_DIRECT")) : 0;

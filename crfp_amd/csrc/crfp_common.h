@@ -413,6 +413,8 @@ int launch_scale_q4(const float* src, int src_pad, float* dst, int nq, int H, in
 // Per 64 x 16 tile of the [H8][W8] u8 mask (W8 a multiple of 4), 4 flag bytes: byte k != 0 iff a tile at most k tiles away (Chebyshev) holds
 // a set mask pixel (k = 0 .. 3).  gate: [N] items of gate_b bytes each (>= 4 * tiles).  The tile grid is conv3x3_narrow_kernel's.
 int launch_mask_gate(const uint8_t* mk, long long mk_b, uint8_t* gate, long long gate_b, int N, int H8, int W8, hipStream_t s);
+// dst (one P4 quad per item) = lrelu_0.1(src (one Q4 quad)); raises the item's status word like the blend kernel when a value leaves the fp16 range
+int launch_lrelu_q4_to_p4(const float* src, long long src_b, float* dst, long long dst_b, int N, int H, int W, unsigned* ovf, int ovf_div, hipStream_t s);
 // CRFP_DSV_CRA level fusion: [prop | carry] = mk2 * fused + (1 - mk2) * y, mk2 = the x0.25 bilinear resample of the u8 mask [4H][4W]
 int launch_cra_blend(const float* y, long long y_b, const float* fused, long long f_b, const uint8_t* mk, long long mk_b, float* prop,
                      long long prop_b, float* carry, long long carry_b, int N, int H, int W, hipStream_t s);

@@ -1018,6 +1018,8 @@ struct Runner {
             narrow(IT_R3_1, H8, W8, {nb(L.z0)}, nb(L.z1));
             narrow(IT_R3_2, H8, W8, {nb(L.z1)}, nb(L.feat), nb(L.z0));
         }
+        // gated: the state is lrelu(feat) wherever the mask is clear -- one streaming pass -- and the blend kernel rewrites the tiles with mask pixels
+        if (mask_gate_enabled()) RUN(launch_lrelu_q4_to_p4(F(L.feat), L.feat.bs, F(L.state_hr), L.state_hr.bs, B, H8, W8, ovf(), ovf_div, s));
         narrow(IT_TTTF, H8, W8, {nb(L.feat), nb(L.x_hr[par])}, nb(L.state_hr), NB(), NB(), io.mk, io.mk_b, 0, 1, NB(), par, 0);
         // output head: conv_last(state) + x8 bilinear LR;
         // the x8 bilinear base is recomputed from the LR frame in both builds (fp32: 39.0 vs 41.3 us against reading the quad hr_prep

@@ -276,6 +276,28 @@ int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* o
     return 0;
 }
 
+// dst (P4 planes) = lrelu_0.1(src) for one quad per batch item: the new recurrent state wherever the fovea mask is clear
+// (model/CRFP.py:1674-1675 with mk = 0); the gated conv_tttf launch then rewrites the tiles that hold mask pixels.  The state feeds a
+// split-fp16 conv: the range guard of the blend kernel applies here as well.
+__global__ void lrelu_q4_to_p4_kernel(const act_t* __restrict__ src, long long src_b, act_t* __restrict__ dst, long long dst_b, int H, int W,
+                                      unsigned* __restrict__ ovf, int ovf_div) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const cf32x4 v = ldq(src + n * src_b + ((long long)y * W + x) * 4);
+    const cf32x4 o = cf32x4{v.x > 0.0f ? v.x : 0.1f * v.x, v.y > 0.0f ? v.y : 0.1f * v.y, v.z > 0.0f ? v.z : 0.1f * v.z, v.w > 0.0f ? v.w : 0.1f * v.w};
+    stq(dst + n * dst_b + ((long long)y * (W + 1) + x) * 4, o);
+    const float vmax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+    unsigned* w = ovf_word(ovf, ovf_div, 0, n);
+    if (w && !(vmax < 65504.0f)) atomicOr(w, 1u);
+}
+
+int launch_lrelu_q4_to_p4(const float* src, long long src_b, float* dst, long long dst_b, int N, int H, int W, unsigned* ovf, int ovf_div, hipStream_t s) {
+    ProfScope prof("state_lrelu_copy", s, (double)N * H * W * 8.0 * sizeof(act_t), 0);
+    lrelu_q4_to_p4_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(as_act(src), src_b, as_act(dst), dst_b, H, W, ovf, ovf_div);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
 // The fovea mask as a tile gate.  The fovea blend is a select (model/CRFP.py:1543-1544,1674), so everything computed only to be
 // deselected -- the x8 frame stack, encoder_hr and conv_tttf away from the fovea -- can be skipped tile by tile with identical results.
 // Per 64 x 16 tile (the tile grid of the 8x stencil kernels) 4 flag bytes: byte 0 = "a mask pixel is set inside the tile" (conv_tttf has work
