@@ -36,6 +36,8 @@ Extra objects on that line:
                 the time of ALL warp / DCN kernels of such a frame, the fused offset-head + DCN kernel included.
   lockstep_batch_frames_per_sec  (clip configs) n = 2 / 4 clips per crfp_dsv_forward_batch call (lock-step launches over the clips), bit-exactness against
                 one-clip calls; warp_dcn_8d_spec_weights: the 8(d) figure, frames/s and parity with SURVEY 8(d)'s own N(0, 0.02) DCN heads.
+  mask_gate     (default run only) what the mask-gated launches skip on this workload and the headline with dense launches instead (child process,
+                CRFP_MASK_GATE=0): same output bits, the dense rate is what rounds 1-3 measured.
   cra_engine    (config 2) CRFP_DSV_CRA, the reference's cross-resolution-fusion wiring, on its own one-call schedule: frames/s and the
                 difference to the per-operator composition of the same model.
   collectives   which backend ran the barrier / MAX / SUM reductions (CRFP_FORCE_DIST=1 initialises RCCL even with one rank).
@@ -644,6 +646,27 @@ def main():
                 others[str(c)] = {"error": f"{type(e).__name__}: {e}"[:300]}
         result["other_configs"] = others
 
+    if extras and mode == "clip" and args.config == 2 and not custom and not args.no_other_configs:
+        # The fovea blend is a select under the mask, and the engine skips, tile by tile, the work whose result the select discards
+        # (DESIGN.md 3.3).  For the record: the same headline with dense launches (CRFP_MASK_GATE=0 is read once per process -> child process),
+        # and what share of the frame this workload's fovea covers.
+        import subprocess
+        gate = {"enabled": os.environ.get("CRFP_MASK_GATE", "1") != "0",
+                "fovea": f"{fv} x {fv} of {8 * h} x {8 * w} pixels per frame (the reference's eval.sh: --FV_size 96), {100.0 * fv * fv / (64.0 * h * w):.2f} % of the frame",
+                "skipped_where_the_mask_is_clear": ["x8 frame stack (hr_prep)", "encoder_hr.slice1.0 / .2", "conv_tttf (the blend keeps lrelu(state) there)"],
+                "outputs": "bit-identical to the dense launches (tests/test_gpu_gate.py, 38 mask shapes x storage x wiring x schedule)"}
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", str(min(args.steps, 10)), "--warmup", "2", "--no-extras",
+               "--no-cpu-baseline", "--no-kernel-profile", "--no-other-configs"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CRFP_FORCE_DIST")}
+        env["CRFP_MASK_GATE"] = "0"
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+            gate["dense_frames_per_sec"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["value"]
+        except Exception as e:  # noqa: BLE001 -- a failed leg must not take the headline line down with it
+            gate["dense_frames_per_sec"] = None
+            gate["error"] = f"{type(e).__name__}: {e}"[:300]
+        result["mask_gate"] = gate
+
     if rank == 0 and not args.no_cpu_baseline:
         # The oracle (CPU port of the reference path; checker / baseline only, never on the product path) runs in a child
         # process so that a mis-sized host cannot stall the bench: bounded sample, hard timeout.
@@ -695,7 +718,8 @@ def main():
     if rank == 0:
         for key, src, field in (("strict_f32_frames_per_sec", "strict_f32", "frames_per_sec"), ("warp_dcn_8d_frac", "warp_dcn_8d", "frac"),
                                 ("warp_dcn_frac", "warp_dcn", "frac"), ("dcn_fused_avg_us", "dcn_fused", "avg_us"),
-                                ("cra_engine_frames_per_sec", "cra_engine", "frames_per_sec")):
+                                ("cra_engine_frames_per_sec", "cra_engine", "frames_per_sec"),
+                                ("dense_launch_frames_per_sec", "mask_gate", "dense_frames_per_sec")):
             if src in result:
                 result[key] = result[src][field]
         result["psnr_reduce"] = benchutil.psnr_reduce_record(vec, world)
