@@ -654,7 +654,7 @@ def main():
         gate = {"enabled": os.environ.get("CRFP_MASK_GATE", "1") != "0",
                 "fovea": f"{fv} x {fv} of {8 * h} x {8 * w} pixels per frame (the reference's eval.sh: --FV_size 96), {100.0 * fv * fv / (64.0 * h * w):.2f} % of the frame",
                 "skipped_where_the_mask_is_clear": ["x8 frame stack (hr_prep)", "encoder_hr.slice1.0 / .2", "conv_tttf (the blend keeps lrelu(state) there)"],
-                "outputs": "bit-identical to the dense launches (tests/test_gpu_gate.py, 38 mask shapes x storage x wiring x schedule)"}
+                "outputs": "bit-identical to the dense launches (tests/test_gpu_gate.py: 46 mask x storage x wiring x schedule cases)"}
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", str(min(args.steps, 10)), "--warmup", "2", "--no-extras",
                "--no-cpu-baseline", "--no-kernel-profile", "--no-other-configs"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CRFP_FORCE_DIST")}

@@ -70,5 +70,17 @@ with torch.no_grad():
                     res[f"{storage}.stream.{int(resident)}"] = m.forward_stream(lrs, fvs, mk).cpu().numpy()
                 m.inputs_resident = False
                 res[f"{storage}.y_only"] = model(cls, storage, y_only=True)(lrs, fvs, T(ms[4][1]).to(dev)).cpu().numpy()
+    # partial tiles on the right / bottom edge (8h, 8w not multiples of 16 / 64) and two sequences streamed in lock-step with different masks
+    for storage in ("f32", "bf16"):
+        m = model(CRFP.CRFP_DSV, storage)
+        t2, h2, w2 = 2, 25, 36
+        lr2, fv2, _ = (T(a).to(dev) for a in synth.make_clip(6, 1, t2, h2, w2, fv_size=64))
+        for name, mk in masks(t2, h2, w2, 8):
+            if name in ("corners", "window", "moving"):
+                res[f"{storage}.edge.{name}"] = m(lr2, fv2, T(mk).to(dev)).cpu().numpy()
+        ms = masks(t, h, w, 9)
+        mk2 = torch.cat([T(ms[6][1]), T(ms[5][1])], 0).to(dev)
+        m.clear_states()
+        res[f"{storage}.stream_batch"] = m.forward_stream(lrs.expand(2, -1, -1, -1, -1).contiguous(), fvs.expand(2, -1, -1, -1, -1).contiguous(), mk2).cpu().numpy()
 np.savez(sys.argv[1], **res)
 print("wrote", len(res), "cases")

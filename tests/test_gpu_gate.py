@@ -21,7 +21,7 @@ def test_mask_gated_launches_change_no_bit(tmp_path):
                            text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
     dense, gated = np.load(files["0"]), np.load(files["1"])
-    assert sorted(dense.files) == sorted(gated.files) and len(dense.files) >= 38
+    assert sorted(dense.files) == sorted(gated.files) and len(dense.files) >= 46
     for k in dense.files:
         a, b = dense[k], gated[k]
         assert np.isfinite(a).all(), k
