@@ -1,0 +1,54 @@
+"""Soak of the mask-gated two-stream schedules: the same call repeated, every output compared bit for bit with the first one.
+usage: python tools/soak_gate.py [--iters 200]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from crfp_amd import synth
+from crfp_amd.model import CRFP
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=200)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+T = torch.from_numpy
+
+
+def model(cls, storage):
+    m = cls(device=dev, mid_channels=32)
+    sd = synth.make_state_dict_like({k: tuple(v.shape) for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict({k: T(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    m.storage = storage
+    return m
+
+
+bad = 0
+with torch.no_grad():
+    for storage in ("f32", "bf16"):
+        for cls in (CRFP.CRFP_DSV, CRFP.CRFP_DSV_CRA):
+            for n in (1, 4):
+                m = model(cls, storage)
+                lrs, fvs, mks = (T(x).to(dev) for x in synth.make_clip(77 + n, n, 7, 180, 320, fv_size=96, sigma_t=50.0))
+                ref = m(lrs, fvs, mks).clone()
+                t0 = time.perf_counter()
+                diff = 0
+                for _ in range(a.iters // (2 if n == 4 else 1)):
+                    diff += int(not torch.equal(m(lrs, fvs, mks), ref))
+                torch.cuda.synchronize()
+                bad += diff
+                print(f"{cls.__name__:14s} {storage:4s} clips/call {n}: {a.iters // (2 if n == 4 else 1)} calls, {diff} differ, finite {bool(torch.isfinite(ref).all())}, {time.perf_counter() - t0:.1f} s", flush=True)
+        # one frame per call, resident inputs (the side stream runs ahead of the caller's): 3 passes over a 60-frame sequence
+        m = model(CRFP.CRFP_DSV, storage)
+        m.inputs_resident = True
+        lrs, fvs, mks = (T(x).to(dev) for x in synth.make_clip(5, 1, 60, 180, 320, fv_size=96, sigma_t=50.0))
+        mks = mks.contiguous()
+        torch.cuda.synchronize()
+        outs = []
+        for _ in range(3):
+            m.clear_states()
+            outs.append(m.forward_stream(lrs, fvs, mks).clone())
+        d = sum(int(not torch.equal(o, outs[0])) for o in outs[1:])
+        bad += d
+        print(f"stream resident {storage}: 3 x 60 frames, {d} passes differ", flush=True)
+print("SOAK", "FAILED" if bad else "OK")
+sys.exit(1 if bad else 0)
