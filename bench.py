@@ -327,7 +327,7 @@ def main():
         dom = table[0]
         domf = fam[dom["kernel"]]
         if dom["kernel"] == "conv3x3_mfma":
-            strict_env = os.environ.get("CRFP_PRECISION") == "f32" or os.environ.get("CRFP_CONV_MODE") == "f32"
+            strict_env = os.environ.get("CRFP_PRECISION") == "f32"
             if storage == "bf16":
                 peak, scheme = MFMA16_PEAK_TFLOPS, "bf16"
                 note = "one v_mfma_f32_32x32x16_bf16 per MAC on bf16 operands, fp32 accumulate: peak = 2.5 PF dense bf16"

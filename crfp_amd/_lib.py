@@ -79,6 +79,7 @@ SIGNATURES = {
     "crfp_rt_forward_clip": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "crfp_prof_enable": (C.c_int, [C.c_int]),
     "crfp_prof_reset": (C.c_int, []),
+    "crfp_debug_side_tables": (C.c_int, []),
     "crfp_prof_report": (C.c_int, [C.POINTER(ProfRecord), C.c_int]),
     "crfp_dsv_debug_fetch": (C.c_int, [C.c_char_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p] +
                              [C.POINTER(C.c_int)] * 3 + [C.c_void_p]),

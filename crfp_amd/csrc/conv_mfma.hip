@@ -2650,16 +2650,21 @@ int launch_conv_pack(const ConvArgs& a, const float* w, const float* bias, const
 // Precision of the engine's wide convolutions and of dcn_g8's GEMM.  Default: the split-fp16 scheme (fp32-grade, needs
 // |operand| < 65504, guarded by the overflow word, see ConvArgs::ovf).  Strict: plain fp32 MFMA everywhere -- selected per
 // call through ConvArgs::strict (CRFP_DSV_STRICT_F32 of the C-ABI) or for the whole process with CRFP_PRECISION=f32
-// (read once; CRFP_CONV_MODE=f32 / CRFP_DCN_MODE=f32 of round 1 still work).
+// (read once; the per-family knobs of round 1, CRFP_CONV_MODE=f32 / CRFP_DCN_MODE=f32, are read by the lab library only).
 #ifndef CRFP_ACT_BF16
 
 }  // namespace CRFP_NS
 namespace crfp {
-bool precision_env_strict(const char* legacy_knob) {
+bool precision_env_strict(int family) {
     const char* p = getenv("CRFP_PRECISION");
     if (p && !strcmp(p, "f32")) return true;
-    const char* l = getenv(legacy_knob);
+#ifdef CRFP_LAB   // the round-1 per-family knobs (CRFP_CONV_MODE / CRFP_DCN_MODE) live on in the lab library only
+    const char* l = getenv(family == 0 ? "CRFP_CONV_MODE" : "CRFP_DCN_MODE");
     return l && !strcmp(l, "f32");
+#else
+    (void)family;
+    return false;
+#endif
 }
 }  // namespace crfp
 namespace CRFP_NS {
@@ -2673,7 +2678,7 @@ static int lab_knob(const char* k, int dflt) { const char* v = getenv(k); return
 // SRC_S3 sources / s3_dst are understood by conv3x3_split_kernel<1,1,2> (the default) only
 bool conv_s3_supported() {
     static const bool ok = [] {
-        if (kActBf16 || precision_env_strict("CRFP_CONV_MODE")) return false;
+        if (kActBf16 || precision_env_strict(0)) return false;
 #ifdef CRFP_LAB
         if (strcmp(lab_conv_mode(), "f16x3")) return false;
         if (lab_knob("CRFP_SPLIT_WS", 0) || lab_knob("CRFP_SPLIT_IS", 0) || lab_knob("CRFP_SPLIT_PIPE", 0)) return false;
@@ -2746,7 +2751,7 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
             return CRFP_E_UNSUPPORTED;
         }
     }
-    static const bool env_strict = precision_env_strict("CRFP_CONV_MODE");
+    static const bool env_strict = precision_env_strict(0);
     const bool use_split = !(env_strict || a.strict);
     bool ct2 = a.ctiles % 2 == 0;
     bool nchw_src = false, s3_src = false;
@@ -2893,7 +2898,11 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
             }
         }
 #endif
-        static const int x8_max_wgs = getenv("CRFP_BF16_X8_MAX_WGS") ? atoi(getenv("CRFP_BF16_X8_MAX_WGS")) : 512;
+#ifdef CRFP_LAB
+        static const int x8_max_wgs = getenv("CRFP_BF16_X8_MAX_WGS") ? atoi(getenv("CRFP_BF16_X8_MAX_WGS")) : 512;   // A/B knob, lab library only
+#else
+        constexpr int x8_max_wgs = 512;   // fixed in the product: the x8 / 4-wave choice is part of the per-clip bit-identity contract
+#endif
         if (a.ctiles == 1 && ((a.kq >> 2) & 1) == 0 && (long long)a.N * ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH) <= x8_max_wgs) {
             const int tiles8 = ((a.W + TW - 1) / TW) * ((a.H + B8_TH - 1) / B8_TH);
             conv3x3_bf16x8_kernel<<<dim3(tiles8 * a.ctiles, 1, a.N), B8_NT, 0, s>>>(am);
@@ -2903,7 +2912,11 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // 8-wave single-accumulator kernel for the convs with one cout tile (the 32-cout layers: one round of 450 workgroups
         // instead of 1.17 rounds of 900; same-box: conv1 26.4 -> 24.6 us, conv2 28.7 -> 26.1, block0 46.0 -> 43.2, main0 40.0 ->
         // 38.0, clip -1.5 %); with several cout tiles the 4-wave kernel stays (offset/mask head 114.0 vs 117.7 us)
-        static const int s8_max_wgs = getenv("CRFP_F32_S8_MAX_WGS") ? atoi(getenv("CRFP_F32_S8_MAX_WGS")) : (1 << 30);   // A/B knob (round 4)
+#ifdef CRFP_LAB
+        static const int s8_max_wgs = getenv("CRFP_F32_S8_MAX_WGS") ? atoi(getenv("CRFP_F32_S8_MAX_WGS")) : (1 << 30);   // A/B knob (round 4), lab library only
+#else
+        constexpr int s8_max_wgs = 1 << 30;
+#endif
         if (a.ctiles == 1 && !uses_s3_dst_only_4wave(a) && (long long)a.N * ((a.W + TW - 1) / TW) * ((a.H + S8_TH - 1) / S8_TH) <= s8_max_wgs) {
 #ifdef CRFP_S8_NW
             constexpr int s8nw = CRFP_S8_NW;

@@ -42,7 +42,7 @@ struct ProfScope {
     int slot_;
 };
 bool prof_enabled();
-bool precision_env_strict(const char* legacy_knob);   // CRFP_PRECISION=f32 (or the round-1 knob) in the environment
+bool precision_env_strict(int family);   // CRFP_PRECISION=f32 in the environment (lab library: or the round-1 knob of family 0 = conv, 1 = DCN)
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // float-tensor helpers of the fp32 build that the bf16 engine borrows for its float tensors (flow fields, masks)
 int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,

@@ -509,26 +509,48 @@ struct SideStream {
     }
 };
 constexpr int kMaxDevices = 64;
-// One table per host thread, allocated on first use and kept in a process-wide registry: crfp_shutdown() walks ALL tables, so the
-// streams and events of worker threads that have exited are released as well (a thread_local destructor would have to call
-// into the HIP runtime while the process may already be tearing it down).
+// One table per host thread, taken on first use from a process-wide registry: crfp_shutdown() walks ALL tables, so the streams and
+// events of worker threads that have exited are released as well (a thread_local destructor would have to call into the HIP
+// runtime while the process may already be tearing it down).  Round 5: a thread that exits hands its table back to a
+// free list -- its destructor makes NO HIP call, it only forgets the per-sequence notes -- and the next new thread reuses it with its
+// stream and events, so a thread-per-request host no longer grows the registry by one table (64 slots, a stream, an event pool) per
+// thread.  The registry itself is heap-allocated and never destroyed: worker threads may outlive the static destructors.
 struct SideTable { SideStream dev[kMaxDevices]; };
-static std::mutex g_side_mu;
-static std::vector<SideTable*> g_side_tables;
-static thread_local SideTable* g_side_tl = nullptr;
-static SideStream* side_table() {
-    if (!g_side_tl) {
-        g_side_tl = new SideTable();
-        std::lock_guard<std::mutex> lk(g_side_mu);
-        g_side_tables.push_back(g_side_tl);
+struct SideRegistry { std::mutex mu; std::vector<SideTable*> all, idle; };
+static SideRegistry& side_registry() { static SideRegistry* r = new SideRegistry(); return *r; }
+struct SideLease {
+    SideTable* t = nullptr;
+    ~SideLease() {
+        if (!t) return;
+        for (int d = 0; d < kMaxDevices; ++d) t->dev[d].ctx.clear();   // sequences of the exiting thread: the next owner starts clean
+        SideRegistry& r = side_registry();
+        std::lock_guard<std::mutex> lk(r.mu);
+        r.idle.push_back(t);
     }
-    return g_side_tl->dev;
+};
+static thread_local SideLease g_side_tl;
+static SideStream* side_table() {
+    if (!g_side_tl.t) {
+        SideRegistry& r = side_registry();
+        std::lock_guard<std::mutex> lk(r.mu);
+        if (!r.idle.empty()) { g_side_tl.t = r.idle.back(); r.idle.pop_back(); }
+        else { g_side_tl.t = new SideTable(); r.all.push_back(g_side_tl.t); }
+    }
+    return g_side_tl.t->dev;
 }
 static void destroy_all_side_streams() {   // caller: no crfp_dsv_* call in flight on any thread
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    for (SideTable* t : g_side_tables)
+    SideRegistry& r = side_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    for (SideTable* t : r.all)
         for (int d = 0; d < kMaxDevices; ++d) t->dev[d].destroy();
 }
+#ifndef CRFP_ACT_BF16
+extern "C" int crfp_debug_side_tables(void) {   // tests: how many per-thread tables the fp32 engine's registry holds
+    SideRegistry& r = side_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    return (int)r.all.size();
+}
+#endif
 // streams and events belong to the device that was current when they were created; a device index outside the table
 // gets no side stream (the caller then runs the single-stream schedule) instead of aliasing another device's slot
 static SideStream* side_slot() {   // the calling thread's table entry for the current device; creates nothing
@@ -564,7 +586,7 @@ struct Runner {
     int ovf_div = 1, ovf_add = 0, ovf_off = 0, ovf_skip0 = 0;
     // null in strict mode: no kernel forms fp16 operands, the guard has nothing to watch (the words stay 0)
     unsigned* ovf() const {
-        static const bool env_strict = precision_env_strict("CRFP_CONV_MODE");
+        static const bool env_strict = precision_env_strict(0);
         return strict || env_strict ? nullptr : reinterpret_cast<unsigned*>(ws + L.status) + ovf_off;
     }
     float* F(size_t off) const { return reinterpret_cast<float*>(ws + off); }
@@ -1288,7 +1310,7 @@ int CRFP_API(crfp_dsv_stream_batch)(const void* packed, int flags, const float* 
     int rc = check_common(packed, B, 1, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     const bool resident = (flags & CRFP_DSV_INPUTS_RESIDENT) != 0;
-    if (!lr || !fv || !mk || !out || (!first && !resident && !lr_prev)) { set_error("dsv_stream_frame: null tensor"); return CRFP_E_BADARG; }
+    if (!lr || !fv || !mk || !out || (!first && !resident && !lr_prev)) { set_error("dsv_stream_batch: null tensor"); return CRFP_E_BADARG; }
     Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
     // one frame of every sequence: the call's arguments ARE the frames (batch stride = one frame); flows and encoder_lr features sit in the
@@ -1313,10 +1335,10 @@ int CRFP_API(crfp_dsv_stream_batch)(const void* packed, int flags, const float* 
         // alternate with the call parity, so everything of call i that depends on neither the state nor earlier work on `stream` --
         // FNet, encoder_lr, the fovea blend, encoder_hr, the upsample conv -- is enqueued on the side stream WITHOUT waiting for the
         // caller's stream: it runs beside frame i - 1's recurrent chain.
-        if (!ctx) { set_error("dsv_stream_frame: CRFP_DSV_INPUTS_RESIDENT needs the per-thread stream table (device index out of range)"); return CRFP_E_UNSUPPORTED; }
+        if (!ctx) { set_error("dsv_stream_batch: CRFP_DSV_INPUTS_RESIDENT needs the per-thread stream table (device index out of range)"); return CRFP_E_UNSUPPORTED; }
         if (first) *ctx = StreamCtx();
         else if (!ctx->kept) {
-            set_error("dsv_stream_frame: CRFP_DSV_INPUTS_RESIDENT without a kept previous frame -- start the sequence with first != 0 and the "
+            set_error("dsv_stream_batch: CRFP_DSV_INPUTS_RESIDENT without a kept previous frame -- start the sequence with first != 0 and the "
                       "same flag, on this host thread");
             return CRFP_E_BADARG;
         }
@@ -1325,7 +1347,7 @@ int CRFP_API(crfp_dsv_stream_batch)(const void* packed, int flags, const float* 
         // the kept copy: fp32 build = the Q4 quads FNet reads anyway (slot par of lr_q4); bf16 build = an fp32 NCHW copy (a Q4 copy would be bf16)
         auto keep_and_get = [&](const float** cur, const float** prev) {
             if (kActBf16) {
-                if (!R.rc && hipMemcpyAsync(R.F(L.lr_keep[par]), lr, lr_bytes, hipMemcpyDeviceToDevice, R.s) != hipSuccess) { set_error("dsv_stream_frame: hipMemcpyAsync failed"); R.rc = 1; }
+                if (!R.rc && hipMemcpyAsync(R.F(L.lr_keep[par]), lr, lr_bytes, hipMemcpyDeviceToDevice, R.s) != hipSuccess) { set_error("dsv_stream_batch: hipMemcpyAsync failed"); R.rc = 1; }
                 *cur = lr;
                 *prev = R.F(L.lr_keep[par ^ 1]);
             } else {
@@ -1353,7 +1375,7 @@ int CRFP_API(crfp_dsv_stream_batch)(const void* packed, int flags, const float* 
             hipEvent_t ej = ss.event(1);
             if (forked && ej && hipEventRecord(ej, ss.s) == hipSuccess) (void)hipStreamWaitEvent(main_s, ej, 0);
         };
-        auto fail = [&](const char* what) { join(); ctx->kept = ctx->chained = false; set_error("dsv_stream_frame: %s failed", what); return 1; };
+        auto fail = [&](const char* what) { join(); ctx->kept = ctx->chained = false; set_error("dsv_stream_batch: %s failed", what); return 1; };
         hipEvent_t ev_start = ss.event(0), ev_side = ss.event(1);
         if (!ss.ok) return fail("hipEventCreate");
         if (hipEventRecord(ev_start, main_s) != hipSuccess) return fail("record");
@@ -1398,7 +1420,7 @@ int CRFP_API(crfp_dsv_stream_batch)(const void* packed, int flags, const float* 
         hipEvent_t ej = ss.event(1);
         if (forked && ej && hipEventRecord(ej, ss.s) == hipSuccess) (void)hipStreamWaitEvent(main_s, ej, 0);
     };
-    auto fail = [&](const char* what) { join(); set_error("dsv_stream_frame: %s failed", what); return 1; };
+    auto fail = [&](const char* what) { join(); set_error("dsv_stream_batch: %s failed", what); return 1; };
     hipEvent_t ev_start = ss.event(0), ev_side = ss.event(1);
     if (!ss.ok) return fail("hipEventCreate");
     const float* lq = R.lr_to_q4(lr, B, 0, 1);   // before the fork: read on both streams

@@ -343,18 +343,29 @@ struct Lanes {
     }
 };
 constexpr int kRtMaxDevices = 64;
-// per-thread tables in a process-wide registry, as the CRFP_DSV side streams (engine.hip): crfp_shutdown() releases every thread's lanes
+// per-thread tables leased from a process-wide registry with a free list, as the CRFP_DSV side streams (engine.hip): crfp_shutdown()
+// releases every thread's lanes, an exiting thread hands its table to the next new one without calling HIP
 struct LaneTable { Lanes dev[kRtMaxDevices]; };
-static std::mutex g_lanes_mu;
-static std::vector<LaneTable*> g_lane_tables;
-static thread_local LaneTable* g_lanes_tl = nullptr;
-static Lanes* lane_table() {
-    if (!g_lanes_tl) {
-        g_lanes_tl = new LaneTable();
-        std::lock_guard<std::mutex> lk(g_lanes_mu);
-        g_lane_tables.push_back(g_lanes_tl);
+struct LaneRegistry { std::mutex mu; std::vector<LaneTable*> all, idle; };
+static LaneRegistry& lane_registry() { static LaneRegistry* r = new LaneRegistry(); return *r; }
+struct LaneLease {
+    LaneTable* t = nullptr;
+    ~LaneLease() {
+        if (!t) return;
+        LaneRegistry& r = lane_registry();
+        std::lock_guard<std::mutex> lk(r.mu);
+        r.idle.push_back(t);
     }
-    return g_lanes_tl->dev;
+};
+static thread_local LaneLease g_lanes_tl;
+static Lanes* lane_table() {
+    if (!g_lanes_tl.t) {
+        LaneRegistry& r = lane_registry();
+        std::lock_guard<std::mutex> lk(r.mu);
+        if (!r.idle.empty()) { g_lanes_tl.t = r.idle.back(); r.idle.pop_back(); }
+        else { g_lanes_tl.t = new LaneTable(); r.all.push_back(g_lanes_tl.t); }
+    }
+    return g_lanes_tl.t->dev;
 }
 static Lanes* lanes_for_current_device() {
     static const bool on = !(getenv("CRFP_SIDE_STREAM") && atoi(getenv("CRFP_SIDE_STREAM")) == 0);   // read once
@@ -613,8 +624,9 @@ struct Runner {
 
 }  // namespace rt
 void rt_shutdown_streams() {
-    std::lock_guard<std::mutex> lk(rt::g_lanes_mu);
-    for (rt::LaneTable* t : rt::g_lane_tables)
+    rt::LaneRegistry& r = rt::lane_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    for (rt::LaneTable* t : r.all)
         for (int d = 0; d < rt::kRtMaxDevices; ++d) t->dev[d].destroy();
 }
 }  // namespace crfp

@@ -894,6 +894,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
 }
 
+#ifdef CRFP_LAB   // lost its A/B (141.2 vs 136.6 us): lab library only (round 5)
 // ---------------------------------------------------------------- round 3: the same fusion with ROLE-SPECIALISED waves
 // dcn_fused_kernel<8> runs conv taps and sampler items in ONE instruction stream per wave: 246 VGPRs = two waves per SIMD, and
 // whatever stalls the stream (an LDS operand read in front of an MFMA, a gather that has not landed, a barrier) stalls both roles'
@@ -1072,6 +1073,7 @@ __global__ __launch_bounds__(D2_NT, 1) void dcn_fused2_kernel(const DcnFuseArgs 
     }
     if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
 }
+#endif   // CRFP_LAB (dcn_fused2_kernel)
 
 bool dcn_fused_enabled() {
     static const bool on = !(getenv("CRFP_DCN_FUSED") && atoi(getenv("CRFP_DCN_FUSED")) == 0);
@@ -1103,12 +1105,10 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     return 0;
 #endif
     // 8-wave workgroups: 151.6 vs 165.3 us per launch same-box against <4> (lab library: CRFP_DCN_FUSE_NW=4)
-    // CRFP_DCN_FUSE_V=2 (read once): the role-specialised 16-wave form above -- bit-identical, 141.2 vs 136.6 us per launch same-box @A:
+    // (lab library, CRFP_DCN_FUSE_V=2: the role-specialised 16-wave form above -- bit-identical, 141.2 vs 136.6 us per launch same-box @A:
     // both forms pay the same ~53 us of per-workgroup fixed cost (116 KB of tile / weight prologue and 258 KB of streamed head
-    // weights per 256 pixels, 15 barriers), and the specialised one overlaps only 17 of the 49 us its sampler role adds
-    static const int fuse_v = getenv("CRFP_DCN_FUSE_V") ? atoi(getenv("CRFP_DCN_FUSE_V")) : 1;
-    if (fuse_v == 2) dcn_fused2_kernel<<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), D2_NT, 0, s>>>(a);
-    else dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
+    // weights per 256 pixels, 15 barriers), and the specialised one overlaps only 17 of the 49 us its sampler role adds)
+    dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1318,10 +1318,14 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     const double px = (double)a.N * a.H * a.W;
     ProfScope prof("offset_mask_conv+dcnv2_g8_fused", s, px * (8.0 + (32 + 32 + 32) * sizeof(act_t)),
                    2.0 * px * 32 * 216 * 9 + 2.0 * px * 32 * 32 * 9 + px * 288 * 7);
-    // 8-wave workgroups: 91.9 vs 97.0 us per launch same-box against <4> (one clip); CRFP_DCN_FUSE_NW=4: A/B knob for multi-round launches
+    // 8-wave workgroups: 91.9 vs 97.0 us per launch same-box against <4> (one clip); -DCRFP_LAB builds: CRFP_DCN_FUSE_NW=4 = A/B knob for
+    // multi-round launches
+#ifdef CRFP_LAB
     static const int nw4 = getenv("CRFP_DCN_FUSE_NW") && atoi(getenv("CRFP_DCN_FUSE_NW")) == 4;
     if (nw4) dcn_fused_kernel<4><<<dim3((a.W + 31) / 32, (a.H + 3) / 4, a.N), 256, 0, s>>>(a);
-    else dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
+    else
+#endif
+    dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1356,7 +1360,7 @@ __global__ void dcn_g8_pack16_kernel(const float* __restrict__ w, unsigned short
 }
 
 bool dcn_g8_use_f16() {
-    static const bool f16 = !precision_env_strict("CRFP_DCN_MODE");
+    static const bool f16 = !precision_env_strict(1);
     return f16;
 }
 

@@ -102,7 +102,8 @@ class DSVEngine:
                 raise ValueError(f"unsupported clip shape n={n} t={t} h={h} w={w}")
             ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
             off = self._fn("crfp_dsv_batch_status_offset")(n, t, h, w)
-            ws[off:off + 256].zero_()   # a fresh workspace starts with a clear status word (crfp_fnet_forward never writes it)
+            # a fresh workspace starts with clear status words -- one per clip, so 4 n bytes (crfp_fnet_forward never writes them)
+            ws[off:off + max(256, 4 * n)].zero_()
             self._ws = {key: ws}        # keep one shape alive
         return self._ws[key]
 

@@ -15,8 +15,10 @@
  * alone (buffers may be reused once `stream` has drained).  Clips issued by one host thread on
  * several caller streams share that one side stream (their side work serialises; results are
  * unaffected).  CRFP_SIDE_STREAM=0 in the environment (read once) selects a single-stream
- * schedule that creates nothing.  crfp_shutdown() destroys the calling thread's side streams and
- * events (call it after the thread's last stream has drained).  Return value: 0 = success, negative = CRFP_E_* argument error,
+ * schedule that creates nothing.  A host thread that exits hands its table (stream + events) to the next
+ * new thread -- without calling HIP -- so short-lived worker threads do not accumulate streams.
+ * crfp_shutdown() destroys EVERY thread's side streams and events (call it when no library call is in
+ * flight on any thread and the streams have drained); the next call re-creates them lazily.  Return value: 0 = success, negative = CRFP_E_* argument error,
  * positive = hipError_t of a failed launch.  crfp_last_error_string() describes the last failure
  * on the calling thread.  No exceptions cross the boundary.
  *
@@ -63,7 +65,7 @@ extern "C" {
 
 int crfp_version(void);
 const char* crfp_last_error_string(void);
-/* destroy the calling thread's side streams / events (see "State kept between calls"); always 0 */
+/* destroy every host thread's side streams / events (see "State kept between calls"); always 0 */
 int crfp_shutdown(void);
 
 /* ---- flow_warp: x[n,c,h,w] (NCHW f32), flow[n,h,w,2] = (dx,dy) pixels, out[n,c,h,w].
@@ -306,6 +308,9 @@ typedef struct crfp_prof_record {
 int crfp_prof_enable(int on);
 int crfp_prof_reset(void);
 int crfp_prof_report(crfp_prof_record* out, int cap);
+/* diagnostic: how many per-host-thread side-stream tables the fp32 CRFP_DSV engine holds (tables of exited threads are
+ * reused by new threads, so a thread-per-request host keeps this at its peak thread count; crfp_shutdown() empties them) */
+int crfp_debug_side_tables(void);
 
 /* debug: copy a named intermediate of the last crfp_dsv_* call out of the workspace (Q4 layout
  * converted to NCHW).  Used by the parity tests to bisect; returns CRFP_E_BADARG for unknown names. */

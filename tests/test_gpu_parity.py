@@ -285,16 +285,15 @@ def _golden_check(env, lab=False, want="MAXDIFF"):
     return line[0]
 
 
-@pytest.mark.parametrize("env", [{"CRFP_PRECISION": "f32"}, {"CRFP_CONV_MODE": "f32"}, {"CRFP_DCN_MODE": "f32"},
-                                 {"CRFP_SIDE_STREAM": "0"}, {"CRFP_DCN_FUSED": "0"}])
+@pytest.mark.parametrize("env", [{"CRFP_PRECISION": "f32"}, {"CRFP_SIDE_STREAM": "0"}, {"CRFP_DCN_FUSED": "0"}, {"CRFP_MASK_GATE": "0"}])
 def test_alternate_kernel_paths(env):
-    """The process-wide switches the product library reads (strict fp32 MFMA for convs and / or the DCN GEMM, single-stream
-    schedule) give the same clip within the parity tolerance."""
+    """The process-wide switches the product library reads (strict fp32 MFMA for convs and the DCN GEMM, single-stream
+    schedule, two-kernel DCN path, dense fovea-side launches) give the same clip within the parity tolerance."""
     assert float(_golden_check(env).split()[1]) < 2e-4
 
 
 @pytest.mark.parametrize("env", [{"CRFP_SPLIT_WS": "1"}, {"CRFP_SPLIT_IS": "1"}, {"CRFP_SPLIT_RPW": "2"}, {"CRFP_SPLIT_PIPE": "1"},
-                                 {"CRFP_CONV_MODE": "bf16x6"}])
+                                 {"CRFP_CONV_MODE": "bf16x6"}, {"CRFP_CONV_MODE": "f32"}, {"CRFP_DCN_MODE": "f32"}])
 def test_lab_kernel_paths(env):
     """The lab library (-DCRFP_LAB: every conv main loop that was tried -- split-bf16 single-role / input-stationary /
     warp-specialised / pipelined, 4- and 8-row tiles) stays correct, so the A/B numbers in DESIGN.md remain reproducible."""

@@ -237,7 +237,24 @@ def test_product_library_carries_no_lab_kernels():
     for name in (b"conv3x3_split_pipe_kernel", b"conv3x3_split_is_kernel", b"conv3x3_split_ws_kernel"):
         assert name not in blob, name
     assert b"conv3x3_split_kernel" in blob
+    assert b"dcn_fused2_kernel" not in blob          # round 5: the role-specialised fused DCN (lost its A/B) is lab-only too
     assert os.path.getsize(so) < 4 << 20
+
+
+def test_product_library_reads_only_the_documented_switches():
+    """VERDICT r4 item 7 / SURVEY 8b ("no mutable global state after first-call init"): the product .so changes kernels only under
+    the five documented process-wide switches of INTEGRATION.md section 4.  Every tuning / probe / stamp knob is compiled only with
+    -DCRFP_LAB, so no other CRFP_* name may appear in the product's string table -- the lab library must still carry them."""
+    import re
+    documented = {b"CRFP_PRECISION", b"CRFP_SIDE_STREAM", b"CRFP_MASK_GATE", b"CRFP_DCN_FUSED", b"CRFP_CONV_PAIR"}
+    names = lambda path: set(re.findall(rb"(?<![A-Za-z0-9_])CRFP_[A-Z0-9_]+(?![A-Za-z0-9_])", open(path, "rb").read()))
+    prod = names(os.path.join(ROOT, "crfp_amd", "libcrfp_hip.so"))
+    # CRFP_E_* are the error-code names inside messages, CRFP_DSV_* the flag names inside messages: not environment variables
+    env_like = {n for n in prod if not n.startswith((b"CRFP_E_", b"CRFP_DSV_", b"CRFP_NS", b"CRFP_ACT_"))}
+    assert env_like == documented, sorted(env_like ^ documented)
+    lab = names(os.path.join(ROOT, "crfp_amd", "libcrfp_hip_lab.so"))
+    for knob in (b"CRFP_CONV_MODE", b"CRFP_DCN_MODE", b"CRFP_DCN_FUSE_V", b"CRFP_DCN_FUSE_NW", b"CRFP_F32_S8_MAX_WGS", b"CRFP_DCN_VARIANT"):
+        assert knob in lab and knob not in prod, knob
 
 
 def test_regional_engine_tables_and_argument_errors(lib):
