@@ -227,6 +227,54 @@ __global__ __launch_bounds__(64 * NW) void flow_warp_p4_dual_kernel(const float*
     }
 }
 
+// Round 5: the same launch with the quads of a pixel SPLIT over blockIdx.z groups of GQ quads.  The kernel above walks its 14 quads in
+// four dependent batches (16 gathers, 4 stores, next batch): ~4 memory round trips per thread on a grid that fills 44 % of the chip's wave
+// slots (900 workgroups of 4 waves on 256 CUs), which is why it sat at 0.50-0.56 of the HBM rate while the one-quad warp of the 8x state
+// (one batch per thread, 57 600 workgroups) reaches 0.70.  Here every thread owns ONE batch: group g of a pixel = GQ quads of prev2 or of
+// the carry, all its gathers in flight at once, (GA + GB) x as many workgroups; flow read and coordinate arithmetic are repeated per
+// group (8 of ~470 bytes per pixel).  Same operations on the same values per output element: bit-identical.
+template <int NQA, int NQB, int GQ>
+__global__ __launch_bounds__(256) void flow_warp_p4_dual_split_kernel(const float* __restrict__ xa, const float* __restrict__ xb_,
+                                                                      const float* __restrict__ flow, float* __restrict__ outa,
+                                                                      float* __restrict__ outb, int H, int W, const WarpDualStrides bs) {
+    constexpr int GA = (NQA + GQ - 1) / GQ, GB = (NQB + GQ - 1) / GQ, NG = GA + GB;
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    const int g = blockIdx.z % NG;
+    const long long n = blockIdx.z / NG;
+    flow += n * bs.flow;
+    const long long pix = (long long)py * W + px;
+    const float2 f = ldnt2(flow + pix * 2);
+    const float dw = (float)(W - 1 > 1 ? W - 1 : 1), dh = (float)(H - 1 > 1 ? H - 1 : 1);
+    const float gx = 2.0f * ((float)px + f.x) / dw - 1.0f;
+    const float gy = 2.0f * ((float)py + f.y) / dh - 1.0f;
+    float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f);
+    float iy = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+    ix = fminf(fmaxf(ix, -1.0f), (float)W);
+    iy = fminf(fmaxf(iy, -1.0f), (float)H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float lx = ix - fx, ly = iy - fy, hx = 1.0f - lx, hy = 1.0f - ly;
+    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+    const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
+    const int guard = pitch + QB;   // see flow_warp_p4_kernel
+    const long long oplane = (long long)H * W * 4;
+    const bool isb = g >= GA;       // workgroup-uniform
+    const int q0 = (isb ? g - GA : g) * GQ, nq = isb ? NQB : NQA;
+    const act_t* src = isb ? as_act(xb_) + n * bs.xb : as_act(xa) + n * bs.xa;
+    act_t* os = (isb ? as_act(outb) + n * bs.outb : as_act(outa) + n * bs.outa) + pix * 4 + q0 * oplane;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((char*)const_cast<act_t*>(src) - guard, 0, nq * plane_b + guard, 0x00020000);
+    const int voff = ((int)fy * PW + (int)fx) * QB + guard + q0 * plane_b;
+    const int cnt = min(GQ, nq - q0);
+    if (cnt == GQ) warp_quads<GQ>(r, voff, pitch, plane_b, w00, w01, w10, w11, os, oplane);
+    else if (GQ > 1 && cnt == 1) warp_quads<1>(r, voff, pitch, plane_b, w00, w01, w10, w11, os, oplane);
+    else if (GQ > 2 && cnt == 2) warp_quads<2>(r, voff, pitch, plane_b, w00, w01, w10, w11, os, oplane);
+    else if (GQ > 3 && cnt == 3) warp_quads<3>(r, voff, pitch, plane_b, w00, w01, w10, w11, os, oplane);
+}
+
+#ifndef CRFP_WARP_SPLIT_DEFAULT
+#define CRFP_WARP_SPLIT_DEFAULT 4
+#endif
 // prev2 (8 quads) + carry (6 quads) by flow2, one launch; zeros padding, P4 sources
 int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* flow, float* outa, float* outb, int H, int W,
                                  hipStream_t s, int N, const WarpDualStrides& bs) {
@@ -240,7 +288,18 @@ int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* 
         return 0;
     }
 #endif
-    flow_warp_p4_dual_kernel<8, 6, 4><<<dim3((W + 63) / 64, (H + 3) / 4, N), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
+#ifdef CRFP_LAB
+    static const int split = getenv("CRFP_WARP_SPLIT") ? atoi(getenv("CRFP_WARP_SPLIT")) : CRFP_WARP_SPLIT_DEFAULT;   // A/B: 0 = round-2 kernel, 1 / 2 / 4 = quads per group
+#else
+    constexpr int split = CRFP_WARP_SPLIT_DEFAULT;
+#endif
+    const dim3 g4((W + 63) / 64, (H + 3) / 4, N);
+    if (split == 4 && N * 4 <= 65535) flow_warp_p4_dual_split_kernel<8, 6, 4><<<dim3(g4.x, g4.y, N * 4), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
+    else if (split == 2 && N * 7 <= 65535) flow_warp_p4_dual_split_kernel<8, 6, 2><<<dim3(g4.x, g4.y, N * 7), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
+#ifdef CRFP_LAB
+    else if (split == 1 && N * 14 <= 65535) flow_warp_p4_dual_split_kernel<8, 6, 1><<<dim3(g4.x, g4.y, N * 14), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
+#endif
+    else flow_warp_p4_dual_kernel<8, 6, 4><<<g4, 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
