@@ -1794,7 +1794,7 @@ constexpr int RG_WCH = 9 * 64 * 16;                   // bytes of one chunk's A 
 constexpr int RG_NT = 320;
 
 template <int D>
-__global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvArgs a, int wgs_per_item, int probe) {
+__global__ __launch_bounds__(RG_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_bf16_ring_kernel(const ConvArgs a, int wgs_per_item, int probe) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
     unsigned char* const ring = rg_lds;                        // D units
     bf16x8* const wl = reinterpret_cast<bf16x8*>(rg_lds + D * RG_UNIT);   // [chunk][tap][lane]
@@ -1804,6 +1804,11 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
     const int tiles_x = (W + TW - 1) / TW, ntiles = tiles_x * ((H + 3) / 4);
     const int nch = a.kq >> 2;
     if (probe & 8) return;   // timing probe: launch + dispatch only
+    // diagnostic timeline (CRFP_STAMP_PTR / CRFP_STAMP_NAME, tools/stamp_ring.py): 16 words per workgroup -- loader: entry, preamble done, set-up +
+    // first D - 1 units issued, end, then cycle sums of (landing wait, fix, barrier, issue); consumer wave 0: entry, end, sums of (barrier, MFMAs, epilogue)
+    long long* const st = a.stamps ? a.stamps + ((long long)blockIdx.z * gridDim.x + blockIdx.x) * 16 : nullptr;
+    const long long t_in = st ? __builtin_amdgcn_s_memtime() : 0;
+#define RG_NOW() (st ? (long long)__builtin_amdgcn_s_memtime() : 0ll)
     // this workgroup's tiles: XCD x walks one contiguous band of the tile list (xcd_band_tile), split evenly among the XCD's workgroups
     const int G = wgs_per_item;                                 // a multiple of 8
     const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, wpx = G >> 3;
@@ -1825,24 +1830,39 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
     if (total <= 0 || (probe & 16)) return;   // probe 16: preamble only (A fragments into LDS)
 
     if (wave == 4) {
-        // ------------------------------------------------------------ loader
+        // ------------------------------------------------------------ loader (round 5: "ring v2" address path)
         // DMA instruction k of a unit covers pieces 51 k .. 51 k + 50 of the slot = a (row, quad) line of 34 and half of the next one, or the
-        // second half of a line and the whole next one: which quad a lane loads from is a select between two SCALAR-held plane pointers (a
-        // per-lane index into a.qd[] would become vector loads from the kernarg segment, which count on the same vmcnt as the DMAs).
-        // Per lane and k, once per workgroup: halo row (-1 .. 4), first pixel of the piece (-2 .. 64) and their offset inside a plane.
+        // second half of a line and the whole next one.  Round 4 formed every DMA address from two 64-bit selects between scalar-held plane
+        // pointers + a 64-bit add: ~250 dependent vector instructions per unit, which a lone wave issues at ~1.2-1.5 us -- the whole
+        // "skeleton cost" that sank the form (tools/micro/barrier_skeleton.hip, profiles/r05_barrier_skeleton.txt: 16 DMAs behind that
+        // arithmetic 1 510 ns per unit, behind loop-invariant addresses 223 ns).  Now the K quads of a tensor are required to lie at ONE plane
+        // stride (conv_ring_eligible), so the lane's line, quad and piece fold into ONE loop-invariant 32-bit byte offset per DMA
+        // (relb[k] >= 0 after a bias of one row + one piece), and a unit adds only a SCALAR 64-bit base: chunk plane 0 of the batch item +
+        // tile origin - bias.  Interior tiles: zero vector instructions per DMA besides the DMA.  Border tiles: clamped row / column in
+        // 32-bit arithmetic (two v_med3 + one v_mad per DMA), the same scalar base, fix() as before.
         typedef __attribute__((address_space(3))) void* lds_vp;
         typedef const __attribute__((address_space(1))) void* glb_vp;
         constexpr int QF = kQuadBytes / 4;              // floats per pixel quad
         const int rs = a.qd[0].rs;                      // floats per plane row: the same for every K quad (conv_ring_eligible)
-        int prow[RG_NDMA], pcol[RG_NDMA], rel[RG_NDMA];
-#pragma unroll
-        for (int k = 0; k < RG_NDMA; ++k) {
+        const int ps = (int)(a.qd[1].base - a.qd[0].base);   // floats per quad plane: the same between the quads of every chunk (conv_ring_eligible)
+        const int bias = rs + 2 * QF;                   // floats: one halo row + one piece, so that every interior offset is >= 0
+        // per lane and DMA k: halo row (-1 .. 4), first pixel of the piece (-2 .. 64), plane offset of its quad.  Only relb[] is kept in
+        // registers (the interior path); the border path and fix() recompute the three from the lane index (a few VALU per DMA on 22 % of
+        // the tiles) -- keeping all four arrays cost 48 VGPRs and pushed the kernel over the 168 that let TWO workgroups share a CU
+        auto geom = [&](int k, int& pr, int& pc, int& qo) {
             const int P0 = k * RG_PPI, lineA = P0 / RG_PC, offA = P0 - lineA * RG_PC, nA = RG_PC - offA;   // compile-time
             const int lineB = lineA + 1 < RG_ROWS * 4 ? lineA + 1 : lineA;
             const bool inB = lane >= nA;
-            prow[k] = (inB ? lineB / 4 : lineA / 4) - 1;
-            pcol[k] = 2 * (inB ? lane - nA : offA + lane) - 2;
-            rel[k] = prow[k] * rs + pcol[k] * QF;
+            pr = (inB ? lineB / 4 : lineA / 4) - 1;
+            pc = 2 * (inB ? lane - nA : offA + lane) - 2;
+            qo = (inB ? (lineB & 3) : (lineA & 3)) * ps;
+        };
+        unsigned relb[RG_NDMA];
+#pragma unroll
+        for (int k = 0; k < RG_NDMA; ++k) {
+            int pr, pc, qo;
+            geom(k, pr, pc, qo);
+            relb[k] = (unsigned)(qo + pr * rs + pc * QF + bias) * 4u;
         }
         // (tile, chunk) cursors of the unit being issued and of the unit being released: incremented, never divided
         struct Cur { int tx0, ty0, ch; };
@@ -1854,27 +1874,27 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
         auto interior = [&](const Cur& c) { return c.ty0 > 0 && c.ty0 + 5 <= H && c.tx0 > 0 && c.tx0 + 66 <= W; };
         auto issue = [&](int u, const Cur& c) {
             unsigned char* slot = ring + (u % D) * RG_UNIT;
-            const QuadDesc* qd = a.qd + 4 * c.ch;
-            const float* qb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) qb[q] = qd[q].base + (long long)n * qd[q].bstride;
-            if (interior(c)) {          // wave-uniform: plane pointer of the tile origin + the lane's constant offset
-                const long long torg = (long long)c.ty0 * rs + c.tx0 * QF;
+            const QuadDesc& q0 = a.qd[4 * c.ch];
+            const float* cb = q0.base + (long long)n * q0.bstride;     // scalar: quad plane 0 of this chunk, this batch item
+            if (interior(c)) {          // wave-uniform
+                const char* sb = reinterpret_cast<const char*>(cb + ((long long)c.ty0 * rs + c.tx0 * QF - bias));
 #pragma unroll
                 for (int k = 0; k < RG_NDMA; ++k) {
-                    const int P0 = k * RG_PPI, lineA = P0 / RG_PC, offA = P0 - lineA * RG_PC, nA = RG_PC - offA;
-                    const int lineB = lineA + 1 < RG_ROWS * 4 ? lineA + 1 : lineA;
-                    const float* g = (lane >= nA ? qb[lineB & 3] : qb[lineA & 3]) + torg + rel[k];
-                    if (!(probe & 1) && lane < RG_PPI && P0 + lane < RG_PIECES) __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)(slot + P0 * 16), 16, 0, 0);
+                    const int P0 = k * RG_PPI;
+                    if (!(probe & 1) && lane < RG_PPI && P0 + lane < RG_PIECES)
+                        __builtin_amdgcn_global_load_lds((glb_vp)(sb + relb[k]), (lds_vp)(slot + P0 * 16), 16, 0, 0);
                 }
             } else {                    // a tile at the image border: clamped addresses, fix() zeroes what lies outside
+                const char* sb = reinterpret_cast<const char*>(cb);
 #pragma unroll
                 for (int k = 0; k < RG_NDMA; ++k) {
-                    const int P0 = k * RG_PPI, lineA = P0 / RG_PC, offA = P0 - lineA * RG_PC, nA = RG_PC - offA;
-                    const int lineB = lineA + 1 < RG_ROWS * 4 ? lineA + 1 : lineA;
-                    const int gy = min(max(c.ty0 + prow[k], 0), H - 1), gx = min(max(c.tx0 + pcol[k], 0), W - 1);
-                    const float* g = (lane >= nA ? qb[lineB & 3] : qb[lineA & 3]) + (long long)gy * rs + gx * QF;
-                    if (!(probe & 1) && lane < RG_PPI && P0 + lane < RG_PIECES) __builtin_amdgcn_global_load_lds((glb_vp)g, (lds_vp)(slot + P0 * 16), 16, 0, 0);
+                    const int P0 = k * RG_PPI;
+                    int pr, pc, qo;
+                    geom(k, pr, pc, qo);
+                    const int gy = min(max(c.ty0 + pr, 0), H - 1), gx = min(max(c.tx0 + pc, 0), W - 1);
+                    const unsigned off = (unsigned)(qo + gy * rs + gx * QF) * 4u;
+                    if (!(probe & 1) && lane < RG_PPI && P0 + lane < RG_PIECES)
+                        __builtin_amdgcn_global_load_lds((glb_vp)(sb + off), (lds_vp)(slot + P0 * 16), 16, 0, 0);
                 }
             }
         };
@@ -1885,7 +1905,9 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
 #pragma unroll
             for (int k = 0; k < RG_NDMA; ++k) {
                 const int P0 = k * RG_PPI;
-                const int gy = c.ty0 + prow[k], gx = c.tx0 + pcol[k];
+                int pr, pc, qo;
+                geom(k, pr, pc, qo);
+                const int gy = c.ty0 + pr, gx = c.tx0 + pc;
                 const bool on = lane < RG_PPI && P0 + lane < RG_PIECES, vy = gy >= 0 && gy < H;
                 const bool v0 = vy && gx >= 0 && gx < W, v1 = vy && gx + 1 >= 0 && gx + 1 < W;
                 cu32x2* dst = reinterpret_cast<cu32x2*>(slot + (P0 + lane) * 16);
@@ -1893,21 +1915,35 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
                 if (on && !v1) dst[1] = cu32x2{0u, 0u};
             }
         };
+        const long long t_pre = RG_NOW();
         Cur ci = first(), cw = ci;
         for (int u = 0; u < D - 1 && u < total; ++u) { issue(u, ci); next(ci); }
+        const long long t_set = RG_NOW();
+        long long s_wait = 0, s_fix = 0, s_bar = 0, s_iss = 0;
         for (int u = 0; u < total; ++u) {
             // DMAs younger than unit u's: those of units u + 1 .. min(u + D - 2, total - 1)
             const int ahead = min(D - 2, total - 1 - u);
             static_assert(RG_NDMA == 16 && D <= 4, "the counted waits below");
+            const long long q0 = RG_NOW();
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long q1 = RG_NOW();
             fix(u, cw);
             next(cw);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long q2 = RG_NOW();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // unit u released; every consumer is done with unit u - 1
+            const long long q3 = RG_NOW();
             if (u + D - 1 < total) { issue(u + D - 1, ci); next(ci); }          // ... whose slot the next DMA takes
+            const long long q4 = RG_NOW();
+            s_wait += q1 - q0; s_fix += q2 - q1; s_bar += q3 - q2; s_iss += q4 - q3;
         }
         asm volatile("s_barrier" ::: "memory");                                  // the consumers' closing barrier
+        if (st && lane == 0) {
+            st[0] = t_in; st[1] = t_pre; st[2] = t_set; st[3] = RG_NOW();
+            st[4] = s_wait; st[5] = s_fix; st[6] = s_bar; st[7] = s_iss; st[15] = total;
+        }
         return;
     }
 
@@ -1919,6 +1955,7 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
     for (int g = 0; g < 4; ++g) bias4[g] = bp[2 * g + h];
     f32x16 acc[1][2];
     int tx0 = (t_first % tiles_x) * TW, ty0 = (t_first / tiles_x) * 4;
+    long long c_bar = 0, c_mma = 0, c_epi = 0;
     for (int tl = 0; tl < ntl; ++tl, tx0 += TW) {
         if (tx0 >= tiles_x * TW) { tx0 = 0; ty0 += 4; }
 #pragma unroll
@@ -1932,7 +1969,10 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
         }
         for (int ch = 0; ch < nch; ++ch) {
             const int u = tl * nch + ch;
+            const long long c0 = RG_NOW();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // unit u has landed (the loader waited for it)
+            const long long c1 = RG_NOW();
+            c_bar += c1 - c0;
             const unsigned char* slot = ring + (u % D) * RG_UNIT;
             const bf16x8* wc = wl + ch * 9 * 64;
             if (probe & 2) continue;   // timing probe: no operand reads, no MFMAs
@@ -1950,17 +1990,31 @@ __global__ __launch_bounds__(RG_NT, 2) void conv3x3_bf16_ring_kernel(const ConvA
                     acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bq8, acc[0][pt], 0, 0, 0);
                 }
             }
+            if (st) { asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[0][1][15])); c_mma += RG_NOW() - c1; }
         }
+        const long long e0 = RG_NOW();
         if (!(probe & 4)) conv_epilogue<1, 2, 1, 2>(ec, acc, 0, tx0, ty0, wave, j, h);
+        c_epi += RG_NOW() - e0;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // pairs with the loader's closing barrier
+    if (st && tid == 0) { st[8] = t_in; st[9] = RG_NOW(); st[10] = c_bar; st[11] = c_mma; st[12] = c_epi; }
+#undef RG_NOW
 }
 
 // all K quads are whole bf16 quads with unit pixel stride (SRC_Q4), in whole 16-channel chunks, one cout tile
 static bool conv_ring_eligible(const ConvArgs& a) {
     if (a.ctiles != 1 || (a.kq & 3) || a.kq < 4 || a.kq > 16 || a.W < 2) return false;
-    for (int q = 0; q < a.kq; ++q)
+    const long long ps = a.qd[1].base - a.qd[0].base;   // floats per quad plane
+    if (ps <= 0 || ps >= (1ll << 26)) return false;
+    for (int q = 0; q < a.kq; ++q) {
         if (a.qd[q].mask != 15 || a.qd[q].cs != kQuadBytes / 4 || a.qd[q].rs != a.qd[0].rs) return false;
+        // ring v2: the four quads of a 16-channel chunk lie at ONE plane stride from the chunk's first (and share its batch stride), so the
+        // loader folds the quad into a loop-invariant per-lane offset
+        const QuadDesc& c0 = a.qd[q & ~3];
+        if (a.qd[q].base - c0.base != (q & 3) * ps || a.qd[q].bstride != c0.bstride) return false;
+    }
+    // every per-lane byte offset (4 planes + a tile row) must fit 32 bits
+    if ((4 * ps + (long long)(a.H + 2) * a.qd[0].rs) * 4 >= (1ll << 31)) return false;
     return true;
 }
 #endif  // CRFP_BF16_RING
@@ -2780,7 +2834,7 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
                    2.0 * px * a.cout * in_ch * 9.0);
     ConvArgs& am = const_cast<ConvArgs&>(a);  // callers pass a private, mutable plan copy
     am.stamps = nullptr;
-#ifdef CRFP_LAB
+#if defined(CRFP_LAB) || defined(CRFP_BF16_RING)
     // diagnostic: CRFP_STAMP_PTR=<device address> CRFP_STAMP_NAME=<launch site> records phase cycles per block
     static const char* stamp_name = getenv("CRFP_STAMP_NAME");
     static long long* stamp_ptr = getenv("CRFP_STAMP_PTR") ? (long long*)strtoull(getenv("CRFP_STAMP_PTR"), nullptr, 0) : nullptr;
@@ -2887,6 +2941,13 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
                 if (D == 4) {
                     static const int once4 = hipFuncSetAttribute((const void*)conv3x3_bf16_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     (void)once4;
+                    static bool told = false;
+                    if (!told && getenv("CRFP_BF16_RING_OCC")) {
+                        told = true;
+                        int nb = -1;
+                        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv3x3_bf16_ring_kernel<4>, RG_NT, lds);
+                        fprintf(stderr, "conv3x3_bf16_ring_kernel<4>: %d workgroups per CU at %zu B of LDS (hip error %d), grid %d x %d\n", nb, lds, (int)e, G, a.N);
+                    }
                     conv3x3_bf16_ring_kernel<4><<<dim3(G, 1, a.N), RG_NT, lds, s>>>(am, G, ring_probe);
                 } else {
                     static const int once3 = hipFuncSetAttribute((const void*)conv3x3_bf16_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
