@@ -233,16 +233,22 @@ __global__ __launch_bounds__(64 * NW) void flow_warp_p4_dual_kernel(const float*
 // (one batch per thread, 57 600 workgroups) reaches 0.70.  Here every thread owns ONE batch: group g of a pixel = GQ quads of prev2 or of
 // the carry, all its gathers in flight at once, (GA + GB) x as many workgroups; flow read and coordinate arithmetic are repeated per
 // group (8 of ~470 bytes per pixel).  Same operations on the same values per output element: bit-identical.
-template <int NQA, int NQB, int GQ>
-__global__ __launch_bounds__(256) void flow_warp_p4_dual_split_kernel(const float* __restrict__ xa, const float* __restrict__ xb_,
+template <int NQA, int NQB, int GQ, int NW = 4, bool BAND = false>
+__global__ __launch_bounds__(64 * NW) void flow_warp_p4_dual_split_kernel(const float* __restrict__ xa, const float* __restrict__ xb_,
                                                                       const float* __restrict__ flow, float* __restrict__ outa,
                                                                       float* __restrict__ outb, int H, int W, const WarpDualStrides bs) {
     constexpr int GA = (NQA + GQ - 1) / GQ, GB = (NQB + GQ - 1) / GQ, NG = GA + GB;
-    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (BAND) {   // 1-D launch: XCD x walks one contiguous band of the (group, tile row, tile column) list (xcd_band_tile)
+        const int gx = (W + 63) / 64, gy = (H + NW - 1) / NW;
+        const int t = xcd_band_tile(blockIdx.x, gridDim.x);
+        bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy);
+    }
+    const int px = bx * 64 + (threadIdx.x & 63);
+    const int py = by * NW + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
-    const int g = blockIdx.z % NG;
-    const long long n = blockIdx.z / NG;
+    const int g = bz % NG;
+    const long long n = bz / NG;
     flow += n * bs.flow;
     const long long pix = (long long)py * W + px;
     const float2 f = ldnt2(flow + pix * 2);
@@ -294,6 +300,16 @@ int launch_flow_warp_p4_dual_8_6(const float* xa, const float* xb, const float* 
     constexpr int split = CRFP_WARP_SPLIT_DEFAULT;
 #endif
     const dim3 g4((W + 63) / 64, (H + 3) / 4, N);
+#ifdef CRFP_LAB
+    static const int snw = getenv("CRFP_WARP_SNW") ? atoi(getenv("CRFP_WARP_SNW")) : 4;   // A/B: rows per workgroup of the split kernel
+    static const int band = getenv("CRFP_WARP_BAND") ? atoi(getenv("CRFP_WARP_BAND")) : 0;
+    if (split == 4 && band && snw == 4) { flow_warp_p4_dual_split_kernel<8, 6, 4, 4, true><<<dim3(g4.x * g4.y * N * 4, 1, 1), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs); CRFP_CHECK_LAUNCH(); return 0; }
+    if (split == 4 && band && snw == 8) { flow_warp_p4_dual_split_kernel<8, 6, 4, 8, true><<<dim3(g4.x * ((H + 7) / 8) * N * 4, 1, 1), 512, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs); CRFP_CHECK_LAUNCH(); return 0; }
+    if (split == 4 && snw == 8) { flow_warp_p4_dual_split_kernel<8, 6, 4, 8><<<dim3(g4.x, (H + 7) / 8, N * 4), 512, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs); CRFP_CHECK_LAUNCH(); return 0; }
+    if (split == 4 && snw == 16) { flow_warp_p4_dual_split_kernel<8, 6, 4, 16><<<dim3(g4.x, (H + 15) / 16, N * 4), 1024, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs); CRFP_CHECK_LAUNCH(); return 0; }
+    if (split == 2 && snw == 8) { flow_warp_p4_dual_split_kernel<8, 6, 2, 8><<<dim3(g4.x, (H + 7) / 8, N * 7), 512, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs); CRFP_CHECK_LAUNCH(); return 0; }
+    if (split == 4 && snw == 2) { flow_warp_p4_dual_split_kernel<8, 6, 4, 2><<<dim3(g4.x, (H + 1) / 2, N * 4), 128, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs); CRFP_CHECK_LAUNCH(); return 0; }
+#endif
     if (split == 4 && N * 4 <= 65535) flow_warp_p4_dual_split_kernel<8, 6, 4><<<dim3(g4.x, g4.y, N * 4), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
     else if (split == 2 && N * 7 <= 65535) flow_warp_p4_dual_split_kernel<8, 6, 2><<<dim3(g4.x, g4.y, N * 7), 256, 0, s>>>(xa, xb, flow, outa, outb, H, W, bs);
 #ifdef CRFP_LAB
