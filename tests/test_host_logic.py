@@ -329,7 +329,8 @@ def test_bench_pmc_traffic_is_tagged_with_the_kernel_source_digest(tmp_path, mon
             {"kernel": "conv3x3_split8_kernel<8>", "calls": 492, "hbm_MB_per_launch_corrected": 81.2},
             {"kernel": "conv3x3_split_kernel<1, 1, 2>", "calls": 120, "hbm_MB_per_launch_corrected": 58.8}]
     (prof / "pmc_summary_latest.json").write_text(json.dumps(rows))
-    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    import benchlegs
+    monkeypatch.setattr(benchlegs, "ROOT", str(tmp_path))   # round 5: pmc_traffic lives in benchlegs.py (bench.py re-exports it)
     tr = bench.pmc_traffic("dcnv2_shared_c4_fused", "f32")
     assert tr and abs(tr["bytes_per_launch"] - 231.5e6) < 1 and tr["stale"] is None          # no digest file: unknown
     (prof / "pmc_summary_latest.meta.json").write_text(json.dumps({"kernels_src_sha": _lib.kernel_source_digest()}))
