@@ -794,6 +794,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     float ov[108];   // activated (dy, dx, mask) of position p at 3 p + c; every index below is a compile-time constant
     DcnPair Q0, Q1;
     const f32x4* wcur = &wst[0][0];
+    dcn_f16x8 pw0, pw1, pb0, pb1;   // operands of the next tap (round 5)
 
     // one (cout tile, chunk) stage = DF_BEGIN (weights registers -> LDS, next stage's loads) + 9 taps x 3 MFMAs (DF_TAPS)
 #define DF_WRITE(B)                                                                                       \
@@ -823,6 +824,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         __builtin_amdgcn_sched_barrier(0);   /* the next stage's loads leave before this stage's MFMAs */  \
         wcur = &wst[DB ? (s_ & 1) : 0][0];                                                                \
     }
+    // Round 5: the operands of the NEXT tap are read from LDS before the current tap's MFMAs (one register set ahead: +16 VGPRs, 234 -> 250).
+    // hipcc had placed every tap's four ds_read_b128 directly in front of its MFMAs behind s_waitcnt lgkmcnt(0 / 1): one exposed LDS round trip
+    // per tap on a kernel with two waves per SIMD (378 conv MFMAs per wave).  The whole-tile weight stage of the 8-wave form holds both chunks,
+    // so the prefetch runs across the chunk boundary; the first tap of a cout tile (behind the stage barrier) loads its own operands.  Same
+    // operations on the same values in the same order: bit-identical.
+#ifndef CRFP_DF_NO_PREFETCH
+#define DF_LDOPS(W0, W1, B0, B1, WB, CH_, TAP_)                                                           \
+    {                                                                                                     \
+        const int ky_ = (TAP_) / 3, kx_ = (TAP_) - 3 * ky_;                                               \
+        const int pix_ = (wave + ky_) * DF_LW + j + kx_;                                                  \
+        W0 = __builtin_bit_cast(dcn_f16x8, (WB)[((TAP_) * 2) * 64 + lane]);                               \
+        W1 = __builtin_bit_cast(dcn_f16x8, (WB)[((TAP_) * 2 + 1) * 64 + lane]);                           \
+        B0 = __builtin_bit_cast(dcn_f16x8, tile[2 * (CH_) + h][pix_]);                                    \
+        B1 = __builtin_bit_cast(dcn_f16x8, tile[4 + 2 * (CH_) + h][pix_]);                                \
+    }
+#define DF_TAPS(CH, TA, TB)                                                                               \
+    if (!(DF_PROBE & 2))                                                                                  \
+    _Pragma("unroll") for (int tap = (TA); tap < (TB); ++tap) {                                           \
+        dcn_f16x8 w0, w1, b0, b1;                                                                         \
+        const bool have_ = CPS == 2 ? !((CH) == 0 && tap == 0) : tap != 0;   /* prefetched by the tap before */ \
+        if (have_) { w0 = pw0; w1 = pw1; b0 = pb0; b1 = pb1; }                                            \
+        else DF_LDOPS(w0, w1, b0, b1, wcur, CH, tap)                                                      \
+        if (tap < 8) DF_LDOPS(pw0, pw1, pb0, pb1, wcur, CH, tap + 1)                                      \
+        else if (CPS == 2 && (CH) == 0) DF_LDOPS(pw0, pw1, pb0, pb1, wcur + DF_WCH, 1, 0)                 \
+        __builtin_amdgcn_sched_barrier(0);   /* the next tap's reads leave before this tap's MFMAs */      \
+        cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, cl, 0, 0, 0);                                 \
+        ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, ca, 0, 0, 0);                                 \
+        cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, cl, 0, 0, 0);                                 \
+    }
+#else
 #define DF_TAPS(CH, TA, TB)                                                                               \
     if (!(DF_PROBE & 2))                                                                                  \
     _Pragma("unroll") for (int tap = (TA); tap < (TB); ++tap) {                                           \
@@ -836,6 +867,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, ca, 0, 0, 0);                                 \
         cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, cl, 0, 0, 0);                                 \
     }
+#endif
     // the accumulators of cout tile T start at its bias, as in the two-kernel path: the 224 packed biases sit in 4 VGPRs
     // (lane L holds rows L, 64 + L, ...) and each value arrives through v_readlane -- scalar loads here cost a cache-miss
     // round trip per cout tile and quad (28 per wave, a third of the kernel's fixed cost when measured), per-lane vector
@@ -946,6 +978,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #undef DF_L
 #undef DF_S
 #undef DF_TAPS
+#ifdef DF_LDOPS
+#undef DF_LDOPS
+#endif
 #undef DF_BEGIN
 #undef DF_WRITE
 #undef DF_SB
@@ -1267,6 +1302,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     float ov[108];
     DcnPair Q0, Q1, Q2;
     const f32x4* wcur = &wst[0][0];
+    df_bf16x8 pw0, pb0;   // operands of the next MFMA (round 5)
 
 #define DF_WRITE(B)                                                                                       \
     _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) {                                                  \
@@ -1292,6 +1328,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         wcur = &wst[DB ? ((T) & 1) : 0][0];                                                               \
     }
     // MFMAs MA .. MB-1 of the cout tile's 18 (chunk-major, then taps: the K order of conv3x3_bf16_kernel)
+    // Round 5: MFMA m + 1's two operands are read from LDS before MFMA m issues (one register set ahead, +8 VGPRs; see the fp32 kernel).  The
+    // first MFMA of a cout tile (behind the stage barrier) loads its own.  Same operations, same order: bit-identical.
+#ifndef CRFP_DF_NO_PREFETCH
+#define DF_LDOPS(W0, B0, M_)                                                                              \
+    {                                                                                                     \
+        const int ch_ = (M_) / 9, tap_ = (M_) - 9 * ch_, ky_ = tap_ / 3, kx_ = tap_ - 3 * ky_;            \
+        const int pix_ = (wave + ky_) * DF_LW + j + kx_;                                                  \
+        W0 = __builtin_bit_cast(df_bf16x8, wcur[(M_) * 64 + lane]);                                       \
+        B0 = __builtin_bit_cast(df_bf16x8, *reinterpret_cast<const f32x4*>(&tile[2 * ch_ + h][pix_][0])); \
+    }
+#define DF_M(MA, MB)                                                                                      \
+    _Pragma("unroll") for (int m = (MA); m < (MB); ++m) {                                                 \
+        df_bf16x8 w0, b0;                                                                                 \
+        if (m != 0) { w0 = pw0; b0 = pb0; }                                                               \
+        else DF_LDOPS(w0, b0, m)                                                                          \
+        if (m + 1 < 18) DF_LDOPS(pw0, pb0, m + 1)                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, ca, 0, 0, 0);                                \
+    }
+#else
 #define DF_M(MA, MB)                                                                                      \
     _Pragma("unroll") for (int m = (MA); m < (MB); ++m) {                                                 \
         const int ch = m / 9, tap = m - 9 * ch, ky = tap / 3, kx = tap - 3 * ky;                          \
@@ -1300,6 +1356,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         const df_bf16x8 b0 = __builtin_bit_cast(df_bf16x8, *reinterpret_cast<const f32x4*>(&tile[2 * ch + h][pix][0])); \
         ca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b0, ca, 0, 0, 0);                                \
     }
+#endif
 #define DF_BIAS(T)                                                                                        \
     if (DB) {                                                                                             \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
