@@ -782,7 +782,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acl[e] = 0.0f; }
 #ifdef CRFP_LAB
-    const int DF_PROBE = a.probe;   // timing experiments (results wrong), bits: 1 = no sampling, 2 = no conv MFMAs, 4 = no barriers / weight streaming after stage 0, 8 = barriers but no weight streaming
+    const int DF_PROBE = a.probe;   // timing experiments (results wrong), bits: 1 = no sampling, 2 = no conv MFMAs, 4 = no barriers / weight streaming after stage 0, 8 = barriers but no weight streaming, 32 = conv MFMAs without operand reads, 64 = weight reads only
+#elif defined(CRFP_DF_PROBE_CT)   // A/B builds of the PRODUCT kernel with a compile-time probe (the lab build's run-time probe word costs registers)
+    constexpr int DF_PROBE = CRFP_DF_PROBE_CT;
 #else
     constexpr int DF_PROBE = 0;
 #endif
@@ -846,7 +848,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         const bool have_ = CPS == 2 ? !((CH) == 0 && tap == 0) : tap != 0;   /* prefetched by the tap before */ \
         if (have_) { w0 = pw0; w1 = pw1; b0 = pb0; b1 = pb1; }                                            \
         else DF_LDOPS(w0, w1, b0, b1, wcur, CH, tap)                                                      \
-        if (tap < 8) DF_LDOPS(pw0, pw1, pb0, pb1, wcur, CH, tap + 1)                                      \
+        if (DF_PROBE & 32) { /* lab probe: no operand reads after a tile's first tap (results wrong) */ }  \
+        else if ((DF_PROBE & 64) && tap < 8) { /* lab probe: weights only (no activation reads) */         \
+            pw0 = __builtin_bit_cast(dcn_f16x8, wcur[((tap + 1) * 2) * 64 + lane]);                       \
+            pw1 = __builtin_bit_cast(dcn_f16x8, wcur[((tap + 1) * 2 + 1) * 64 + lane]);                   \
+        }                                                                                                 \
+        else if (tap < 8) DF_LDOPS(pw0, pw1, pb0, pb1, wcur, CH, tap + 1)                                 \
         else if (CPS == 2 && (CH) == 0) DF_LDOPS(pw0, pw1, pb0, pb1, wcur + DF_WCH, 1, 0)                 \
         __builtin_amdgcn_sched_barrier(0);   /* the next tap's reads leave before this tap's MFMAs */      \
         cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, cl, 0, 0, 0);                                 \
