@@ -560,8 +560,13 @@ __device__ __forceinline__ void dcn_issue_one(DcnPair& P, int pi, __amdgpu_buffe
     P.w[pi][0] = a * hx; P.w[pi][1] = a * lx; P.w[pi][2] = b * hx; P.w[pi][3] = b * lx;
     // element index fy * PW + fx in float (exact below 2^24: a 2x-resolution plane has < 2^22 elements), one conversion
     const int vo = (int)__builtin_fmaf(fy, (float)PW, fx) * QB + hbase + gi * plane_b;
+#if defined(CRFP_DF_PROBE_CT) && (CRFP_DF_PROBE_CT & 128)   // A/B builds: coordinates and weights, but no corner gathers (results wrong)
+    P.tp[pi] = pairraw_t{}; P.bt[pi] = pairraw_t{};
+    asm volatile("" ::"v"(vo));
+#else
     P.tp[pi] = bload_pair(rx, vo, 0);
     P.bt[pi] = bload_pair(rx, vo, pitch);
+#endif
 }
 
 __device__ __forceinline__ void dcn_issue_pair(DcnPair& P, __amdgpu_buffer_rsrc_t rx, const DcnOff& O, int hb, int v, float fy0,
@@ -831,6 +836,27 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     // per tap on a kernel with two waves per SIMD (378 conv MFMAs per wave).  The whole-tile weight stage of the 8-wave form holds both chunks,
     // so the prefetch runs across the chunk boundary; the first tap of a cout tile (behind the stage barrier) loads its own operands.  Same
     // operations on the same values in the same order: bit-identical.
+    // Round 5: the scheduling region (sampler item + tap) is laid out as 4 DS reads, then 3 x (1 MFMA, CRFP_DF_SGB vector instructions) with
+    // sched_group_barrier, so that the sampler's vector work sits INSIDE each MFMA's shadow instead of in front of a burst of three MFMAs
+    // (gaps of one instruction between MFMAs: 196 -> 60; same-box 131.2 -> 128.4 us, bit-identical; 10 per MFMA: the same; GAP 3 / 7 / 9 / 12
+    // of the generated schedule: 130.0 / 128.8 / 131.8 / 139.4, profiles/r05_dcn_fused_sgb_ab.txt).  -DCRFP_DF_SGB=0: the fenced form.
+#ifndef CRFP_DF_SGB
+#define CRFP_DF_SGB 6
+#endif
+#if defined(CRFP_LAB) && !defined(CRFP_DF_NO_PREFETCH)
+#define CRFP_DF_NO_PREFETCH   // the lab build carries a run-time probe word in this kernel: with the 16 prefetch registers on top it spills (96 B, 255 us)
+#endif
+#if CRFP_DF_SGB > 0
+#define DF_TAP_FENCE
+#define DF_TAP_PIPELINE                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, CRFP_DF_SGB, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, CRFP_DF_SGB, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, CRFP_DF_SGB, 0);
+#else
+#define DF_TAP_FENCE __builtin_amdgcn_sched_barrier(0);   /* the next tap's reads leave before this tap's MFMAs */
+#define DF_TAP_PIPELINE
+#endif
 #ifndef CRFP_DF_NO_PREFETCH
 #define DF_LDOPS(W0, W1, B0, B1, WB, CH_, TAP_)                                                           \
     {                                                                                                     \
@@ -855,10 +881,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         }                                                                                                 \
         else if (tap < 8) DF_LDOPS(pw0, pw1, pb0, pb1, wcur, CH, tap + 1)                                 \
         else if (CPS == 2 && (CH) == 0) DF_LDOPS(pw0, pw1, pb0, pb1, wcur + DF_WCH, 1, 0)                 \
-        __builtin_amdgcn_sched_barrier(0);   /* the next tap's reads leave before this tap's MFMAs */      \
+        DF_TAP_FENCE                                                                                      \
         cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b1, cl, 0, 0, 0);                                 \
         ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0, ca, 0, 0, 0);                                 \
         cl = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b0, cl, 0, 0, 0);                                 \
+        DF_TAP_PIPELINE                                                                                   \
     }
 #else
 #define DF_TAPS(CH, TA, TB)                                                                               \
