@@ -761,7 +761,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #define DF_WLOAD(ST)                                                                                      \
     _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) rws[k] = wc[(ST) * DF_WST + min(tid + NT * k, DF_WST - 1)];
     DF_WLOAD(0)
-    for (int i = tid; i < 36 * 64; i += NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
+    // Round 5 (CRFP_DF_LATE_PROLOGUE, default on for the 8-wave form): only what the first MFMA needs -- the halo tile and weight stage 0 -- is
+    // fetched in front of the first barrier.  The DCN weight image (36 KB, first used by the sampler's MFMAs behind stage 1's barrier) and weight
+    // stage 1 used to be ingested there too: 153 KB per workgroup before any MFMA, four rounds per launch.  They now land during cout tile 0,
+    // which has no sampler work to hide anyway (DF_BEGIN).  Same values in the same places before their first use: bit-identical.
+#ifndef CRFP_DF_LATE_PROLOGUE
+#define CRFP_DF_LATE_PROLOGUE 1
+#endif
+    constexpr bool LATE = DB && CRFP_DF_LATE_PROLOGUE;
+    constexpr int DF_NWL = (36 * 64 + NT - 1) / NT;
+    f32x4 rwl[LATE ? DF_NWL : 1];
+    if (!LATE)
+        for (int i = tid; i < 36 * 64; i += NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
     const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
     const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
 #pragma unroll
@@ -809,18 +820,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         const int idx = tid + NT * k;                                                                     \
         if (idx < DF_WST) wst[B][idx] = rws[k];                                                           \
     }
-    if (DB) { DF_WRITE(0) DF_WLOAD(1) }   // stage 0 in LDS, stage 1 on its way
+    if (DB) { DF_WRITE(0) if (!LATE) { DF_WLOAD(1) } }   // stage 0 in LDS (LATE: stage 1 is requested behind the first barrier)
     // single buffer: barrier (everyone done with the previous stage), registers -> LDS, barrier, next stage's loads.
     // double buffer: one barrier (stage s complete in buffer s & 1 and everyone done with stage s - 1), then the registers
-    // (stage s + 1) go to the other buffer and stage s + 2's loads leave
+    // (stage s + 1) go to the other buffer and stage s + 2's loads leave.  LATE: stage 0 only requests stage 1 and the DCN weight image
+    // behind its barrier; they are written to LDS at the chunk boundary of cout tile 0 (DF_BEGIN(0, 1)), where stage 2's loads leave.
 #define DF_BEGIN(T, CH)                                                                                   \
     if (CPS == 2 && (CH) == 1) {                                                                          \
         wcur = &wst[(T) & 1][DF_WCH];                                                                     \
+        if (LATE && (T) == 0) {                                                                           \
+            DF_WRITE(1)                                                                                   \
+            _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                            \
+                if (tid + NT * k < 36 * 64) wl[tid + NT * k] = rwl[k];                                    \
+            DF_WLOAD(2)                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+        }                                                                                                 \
     } else {                                                                                              \
         constexpr int s_ = (2 * (T) + (CH)) / CPS;                                                        \
         const bool first_ = s_ == 0;                                                                      \
         if (first_ || !(DF_PROBE & 4)) df_lds_barrier();                                                  \
-        if (DB) {                                                                                         \
+        if (DB && LATE && first_) {                                                                       \
+            DF_WLOAD(1)                                                                                   \
+            _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                            \
+                rwl[k] = reinterpret_cast<const f32x4*>(a.wdcn)[min(tid + NT * k, 36 * 64 - 1)];          \
+        } else if (DB) {                                                                                  \
             if (s_ + 1 < NSTG) { DF_WRITE((s_ + 1) & 1) }                                                 \
             if (s_ + 2 < NSTG) { DF_WLOAD(s_ + 2) }                                                       \
         } else {                                                                                          \
@@ -1306,7 +1329,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #define DF_WLOAD(ST)                                                                                      \
     _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) rws[k] = wc[(ST) * DF_WST + min(tid + NT * k, DF_WST - 1)];
     DF_WLOAD(0)
-    for (int i = tid; i < 36 * 64; i += NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
+    // Round 5 (see the fp32 kernel): the DCN weight image and weight stage 1 are requested BEHIND the first barrier and written to LDS in the
+    // middle of cout tile 0 (DF_LATE_FILL), so that only the halo tile and stage 0 are ingested in front of the first MFMA.
+#ifndef CRFP_DF_LATE_PROLOGUE
+#define CRFP_DF_LATE_PROLOGUE 1
+#endif
+    constexpr bool LATE = DB && CRFP_DF_LATE_PROLOGUE;
+    constexpr int DF_NWL = (36 * 64 + NT - 1) / NT;
+    f32x4 rwl[LATE ? DF_NWL : 1];
+    if (!LATE)
+        for (int i = tid; i < 36 * 64; i += NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
     const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
     const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
 #pragma unroll
@@ -1343,14 +1375,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         const int idx = tid + NT * k;                                                                     \
         if (idx < DF_WST) wst[B][idx] = rws[k];                                                           \
     }
-    if (DB) { DF_WRITE(0) DF_WLOAD(1) }   // stage 0 in LDS, stage 1 on its way
+    if (DB) { DF_WRITE(0) if (!LATE) { DF_WLOAD(1) } }   // stage 0 in LDS (LATE: stage 1 is requested behind the first barrier)
     // single buffer: barrier (everyone done with the previous stage), registers -> LDS, barrier, next stage's loads.
     // double buffer: one barrier (stage T complete in buffer T & 1 and everyone done with stage T - 1), then the registers
     // (stage T + 1) go to the other buffer and stage T + 2's loads leave
+#define DF_LATE_FILL                                                                                      \
+    if (LATE) {                                                                                           \
+        DF_WRITE(1)                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                                \
+            if (tid + NT * k < 36 * 64) wl[tid + NT * k] = rwl[k];                                        \
+        DF_WLOAD(2)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
 #define DF_BEGIN(T)                                                                                       \
     {                                                                                                     \
         df_lds_barrier();                                                                                 \
-        if (DB) {                                                                                         \
+        if (DB && LATE && (T) == 0) {                                                                     \
+            DF_WLOAD(1)                                                                                   \
+            _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                            \
+                rwl[k] = reinterpret_cast<const f32x4*>(a.wdcn)[min(tid + NT * k, 36 * 64 - 1)];          \
+        } else if (DB) {                                                                                  \
             if ((T) + 1 < 7) { DF_WRITE(((T) + 1) & 1) }                                                  \
             if ((T) + 2 < 7) { DF_WLOAD((T) + 2) }                                                        \
         } else {                                                                                          \
@@ -1429,7 +1473,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #define DF_C(U, P) { dcn_consume_pair(P, acc, acl, wl, U, lane); }
     // cout tile T completes the sampling pairs up to (16 T + 10) / 6: 1, 4, 7, 9, 12, 15, 17; they are sampled inside tile T + 1.
     // Pair u lives in Q[u % 3]; I(u) follows C(u - 3).
-    DF_BEGIN(0) DF_BIAS(0) DF_M(0, 18) DF_RAW(0)   // (the bias table in LDS is complete behind the first barrier)
+    DF_BEGIN(0) DF_BIAS(0) DF_M(0, 9) DF_LATE_FILL DF_M(9, 18) DF_RAW(0)   // (the bias table in LDS is complete behind the first barrier)
     DF_BIAS(1)
     DF_BEGIN(1) DF_M(0, 6) DF_TRANS(0) DF_SB DF_M(6, 12) DF_I(0, Q0) DF_SB DF_M(12, 18) DF_I(1, Q1) DF_SB DF_RAW(1)
     DF_BIAS(2)
@@ -1455,6 +1499,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #undef DF_RAW
 #undef DF_BIAS
 #undef DF_M
+#undef DF_LATE_FILL
 #undef DF_BEGIN
 #undef DF_WRITE
 #undef DF_WLOAD
