@@ -18,6 +18,7 @@ Dependencies (all indices compile-time):
 import sys
 
 GAP = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+TAIL_I_FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 
 
 def build():
@@ -77,7 +78,10 @@ def build():
                 continue
         cands = [it for it in pending if ready(it, t)]
         if cands:
-            it = min(cands, key=lambda x: (prio[x[0]], pending.index(x)))
+            # behind the last tap nothing hides a gather's latency any more: issue every position whose pair buffer is free (I) before blending
+            # anything (L), so that the tail pays ONE exposed round trip instead of one per pair (round 5; TAIL_I_FIRST=0: the round-3 order)
+            pr = dict(prio, I=-1, TR=-2) if (TAIL_I_FIRST and t >= len(taps)) else prio
+            it = min(cands, key=lambda x: (pr[x[0]], pending.index(x)))
             pending.remove(it)
             done_at[it] = t
             (sched[t] if t < len(taps) else tail).append((t, it))
