@@ -1769,303 +1769,6 @@ __global__ __launch_bounds__(P2_NT, 2) void conv3x3_bf16_pair_kernel(const ConvA
     conv_epilogue<1, 2, 1, 2>(ec, acc, 0, tx0, ty0, wave, j, h);
 }
 
-// ---------------------------------------------------------------- LDS-DMA ring form (round 4): an experiment that LOST its A/B -- compiled only with
-// -DCRFP_BF16_RING (make EXTRA=-DCRFP_BF16_RING), then enabled per process with CRFP_BF16_RING=<min workgroups>.  Bit-identical to the shipped
-// kernels, but 16.3 us per clip against 9.3 for a 32 -> 32 conv in a 4-clip lock-step batch (profiles/r04_bf16_ring_ab.txt): with
-// every phase removed (no DMA, no MFMA, no stores) the barrier-per-13-KB-unit skeleton alone costs 8 us per clip.
-#ifdef CRFP_BF16_RING
-// What bounds the bf16 convs in throughput mode (a lock-step batch: several rounds of workgroups per launch) is memory-level
-// parallelism: a one-tile workgroup holds its halo tile in flight during its prologue and nothing afterwards, and its weights are
-// re-staged for every tile.  This form is persistent and role-split: a workgroup = 4 consumer waves + 1 loader wave walks the tiles of its
-// band; the unit of work is (tile, 16-channel chunk) = 4 K-quads x 6 halo rows x 68 pixels = 13 KB, which the loader wave brings into a
-// D-deep LDS ring with `global_load_lds_dwordx4` (no VGPR round trip, no conversion: the bf16 quads go to LDS as they lie in HBM) up to
-// D - 1 units ahead; ALL chunks' A fragments stay in LDS for the life of the workgroup.  One s_barrier per unit: the loader passes it
-// after `s_waitcnt vmcnt(16 (D - 2))` (its own counter holds nothing but the DMAs: the consumers' epilogue stores cannot disturb the
-// count), the consumers after their MFMAs of the previous unit -- which is also what frees that unit's slot for the next DMA.
-// LDS image of a unit: [halo row][quad of the chunk][34 pieces of 16 B = pixels tx0 - 2 .. tx0 + 65]; a piece = two adjacent pixels of
-// one quad plane = 16 contiguous bytes in HBM.  Pieces outside the image (the 3x3 zero padding) are loaded from a clamped address and
-// zeroed by the loader before it releases the unit.  Same K order, same accumulation order, same epilogue as conv3x3_bf16_kernel<1>:
-// identical values.
-// Round 5 ("ring v3"): NC consumer waves = NC tile rows per unit.  NC = 4 is the round-4 shape (unit 13 KB, 16 DMAs); NC = 8 puts TWO consumer
-// waves on every SIMD of the CU (one 9-wave workgroup per CU, unit 21.8 KB, 27 DMAs by the one loader wave), so one wave's operand-read and
-// epilogue stalls are filled by its partner's MFMAs -- what profiles/r05_bf16_ring_v2_ab.txt found missing.
-// One DMA instruction of the loader = one whole wave of 16-byte pieces (1 KiB): round 4 used 51-piece windows so that a window touched two
-// image lines at most (its addresses were selects between two plane pointers); with per-lane offsets any lane can fetch any piece, and an LDS-DMA
-// instruction costs its ~60-70 cycles of issue whether it moves 816 or 1 024 bytes (measured: 27 DMAs per unit 1 900-2 300 ticks).  NL loader
-// waves share a unit's DMAs (k % NL == loader index), each with its own counted vmcnt.
-constexpr int RG_PC = 34;
-constexpr int RG_PPI = 64;
-constexpr int RG_WCH = 9 * 64 * 16;                   // bytes of one chunk's A fragments
-template <int NC, int NL> struct RingGeom {
-    static constexpr int ROWS = NC + 2, PIECES = ROWS * 4 * RG_PC, UNIT = PIECES * 16, NDMA = (PIECES + RG_PPI - 1) / RG_PPI, NT = 64 * (NC + NL);
-    static constexpr int KPL = (NDMA + NL - 1) / NL;   // DMA instructions per loader wave and unit (the same for every loader: surplus ones re-fetch the last window)
-};
-
-template <int D, int NC, int NL>
-__global__ __launch_bounds__(64 * (NC + NL)) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_bf16_ring_kernel(const ConvArgs a, int wgs_per_item, int probe) {
-    typedef RingGeom<NC, NL> RGG;
-    constexpr int RG_ROWS = RGG::ROWS, RG_PIECES = RGG::PIECES, RG_UNIT = RGG::UNIT, RG_NDMA = RGG::NDMA, RG_NT = RGG::NT, RG_KPL = RGG::KPL;
-    extern __shared__ __attribute__((aligned(16))) unsigned char rg_lds[];
-    unsigned char* const ring = rg_lds;                        // D units
-    bf16x8* const wl = reinterpret_cast<bf16x8*>(rg_lds + D * RG_UNIT);   // [chunk][tap][lane]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int H = a.H, W = a.W, n = blockIdx.z;
-    const int tiles_x = (W + TW - 1) / TW, ntiles = tiles_x * ((H + NC - 1) / NC);
-    const int nch = a.kq >> 2;
-    if (probe & 8) return;   // timing probe: launch + dispatch only
-    // diagnostic timeline (CRFP_STAMP_PTR / CRFP_STAMP_NAME, tools/stamp_ring.py): 16 words per workgroup -- loader: entry, preamble done, set-up +
-    // first D - 1 units issued, end, then cycle sums of (landing wait, fix, barrier, issue); consumer wave 0: entry, end, sums of (barrier, MFMAs, epilogue)
-    long long* const st = a.stamps ? a.stamps + ((long long)blockIdx.z * gridDim.x + blockIdx.x) * 16 : nullptr;
-    const long long t_in = st ? __builtin_amdgcn_s_memtime() : 0;
-#define RG_NOW() (st ? (long long)__builtin_amdgcn_s_memtime() : 0ll)
-    // this workgroup's tiles: XCD x walks one contiguous band of the tile list (xcd_band_tile), split evenly among the XCD's workgroups
-    const int G = wgs_per_item;                                 // a multiple of 8
-    const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, wpx = G >> 3;
-    const int bq = ntiles >> 3, br = ntiles & 7;
-    const int band0 = xcd * bq + min(xcd, br), blen = bq + (xcd < br ? 1 : 0);
-    const int t_first = band0 + (int)((long long)blen * wi / wpx), t_end = band0 + (int)((long long)blen * (wi + 1) / wpx);
-    const int ntl = t_end - t_first, total = ntl * nch;
-    {   // A fragments of every chunk: once per workgroup, all loads in flight together (nch <= 4: at most 2 304 vectors / 320 threads = 8 each)
-        const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(a.wsplit16);
-        const int nw = nch * 9 * 64;
-        constexpr int NWR = (4 * 9 * 64 + RG_NT - 1) / RG_NT;
-        bf16x8 wr[NWR];
-#pragma unroll
-        for (int k = 0; k < NWR; ++k) wr[k] = wp[min(tid + RG_NT * k, nw - 1)];
-#pragma unroll
-        for (int k = 0; k < NWR; ++k)
-            if (tid + RG_NT * k < nw) wl[tid + RG_NT * k] = wr[k];
-    }
-    // hand-shake words in LDS (round 5: the per-unit s_barrier that kept loader and consumers in lock-step is gone).  full[l][slot] = u + 1 once
-    // loader wave l's share of unit u has landed (and its border pieces are zeroed); done[w][slot] = u + 1 once consumer wave w has read its last
-    // operand of unit u.  A consumer waits on full only, a loader -- before it refills the slot of unit u - 1 -- on done only, so the loaders run
-    // up to D - 1 units ahead while the consumers sit in an epilogue, and the consumers never wait for a loader that is busy issuing.
-    volatile unsigned* const hs_full = reinterpret_cast<volatile unsigned*>(rg_lds + D * RG_UNIT + 4 * RG_WCH + NL * D * 256);   // [NL][D]
-    volatile unsigned* const hs_done = hs_full + NL * D;                                                                          // [NC][D]
-    if (tid < (NL + NC) * D) hs_full[tid] = 0u;
-    __syncthreads();
-    if (total <= 0 || (probe & 16)) return;   // probe 16: preamble only (A fragments into LDS)
-
-    if (wave >= NC) {
-        // ------------------------------------------------------------ loader waves (round 5: "ring v3" address path)
-        // DMA instruction k of a unit fetches pieces 64 k .. 64 k + 63 of the slot image [halo row][quad][34 pieces]; loader wave lw issues the
-        // instructions k = lw, lw + NL, ...  Round 4 formed every DMA address from two 64-bit selects between scalar-held plane pointers + a 64-bit
-        // add: ~250 dependent vector instructions per unit, which a lone wave issues in 1.2-1.5 us (tools/micro/barrier_skeleton.hip).  Now the K
-        // quads of a tensor lie at ONE plane stride (conv_ring_eligible), so the lane's line, quad and piece fold into ONE loop-invariant 32-bit
-        // byte offset per DMA (relb[] >= 0 after a bias of one row + one piece) and a unit adds only a SCALAR 64-bit base (the saddr form of
-        // global_load_lds): no vector instruction per DMA on interior tiles.
-        typedef __attribute__((address_space(3))) void* lds_vp;
-        typedef const __attribute__((address_space(1))) void* glb_vp;
-        typedef unsigned u32x4_lds __attribute__((ext_vector_type(4)));
-        constexpr int QF = kQuadBytes / 4;              // floats per pixel quad
-        const int lw = wave - NC;
-        const int rs = a.qd[0].rs;                      // floats per plane row: the same for every K quad (conv_ring_eligible)
-        const int ps = (int)(a.qd[1].base - a.qd[0].base);   // floats per quad plane: the same between the quads of every chunk (conv_ring_eligible)
-        const int bias = rs + 2 * QF;                   // floats: one halo row + one piece, so that every interior offset is >= 0
-        // this wave's i-th DMA of a unit: instruction kk(i) = min(lw + NL i, NDMA - 1) (a surplus instruction repeats the last window: same
-        // bytes to the same place, so that every loader wave issues exactly KPL instructions per unit -- the counted waits need that)
-        unsigned relb[RG_KPL];
-        int pcx[RG_KPL];                                // position of the lane's piece in its line (0 .. 33); -1: lane beyond the image of the slot
-#pragma unroll
-        for (int i = 0; i < RG_KPL; ++i) {
-            const int kk = min(lw + NL * i, RG_NDMA - 1), P = kk * RG_PPI + lane;
-            const int line = P / RG_PC, pc = P - line * RG_PC;
-            relb[i] = (unsigned)((line & 3) * ps + ((line >> 2) - 1) * rs + (2 * pc - 2) * QF + bias) * 4u;
-            pcx[i] = P < RG_PIECES ? pc : -1;
-        }
-        // (tile, chunk) cursors of the unit being issued and of the unit being released: incremented, never divided
-        struct Cur { int tx0, ty0, ch; };
-        const int wtiles = tiles_x * TW;
-        auto first = [&]() { Cur c; c.tx0 = (t_first % tiles_x) * TW; c.ty0 = (t_first / tiles_x) * NC; c.ch = 0; return c; };
-        auto next = [&](Cur& c) {
-            if (++c.ch == nch) { c.ch = 0; c.tx0 += TW; if (c.tx0 >= wtiles) { c.tx0 = 0; c.ty0 += NC; } }
-        };
-        auto interior = [&](const Cur& c) { return c.ty0 > 0 && c.ty0 + NC + 1 <= H && c.tx0 > 0 && c.tx0 + 66 <= W; };
-        // Border tiles (24 % of the 8-row tiles of a 360 x 640 map).  Which pieces lie outside the image follows from the piece index (halo rows
-        // above / below the image = whole lines) and from the piece's position in its line (columns left / right of the image); W is even
-        // (conv_ring_eligible), so a piece is inside or outside as a whole.  issue() points such lanes at the tile origin (any valid address:
-        // every DMA instruction still executes, the counted vmcnt waits depend on that) and leaves their bits in a per-slot lane mask in LDS;
-        // fix() zeroes exactly those pieces once the unit has landed.  (Round 4 / v2: clamped row + column per DMA in issue() AND in fix().)
-        unsigned* const vmask = reinterpret_cast<unsigned*>(rg_lds + D * RG_UNIT + 4 * RG_WCH) + lw * D * 64;   // [NL][D][64] words behind the A fragments
-        auto issue = [&](int u, const Cur& c) {
-            unsigned char* slot = ring + (u % D) * RG_UNIT;
-            const QuadDesc& q0 = a.qd[4 * c.ch];
-            const float* cb = q0.base + (long long)n * q0.bstride;     // scalar: quad plane 0 of this chunk, this batch item
-            const char* sb = reinterpret_cast<const char*>(cb + ((long long)c.ty0 * rs + c.tx0 * QF - bias));
-            if (probe & 1) return;
-            if (interior(c)) {          // wave-uniform
-#pragma unroll
-                for (int i = 0; i < RG_KPL; ++i) {
-                    const int kk = min(lw + NL * i, RG_NDMA - 1);   // wave-uniform
-                    if (pcx[i] >= 0) __builtin_amdgcn_global_load_lds((glb_vp)(sb + relb[i]), (lds_vp)(slot + kk * RG_PPI * 16), 16, 0, 0);
-                }
-            } else {
-                // valid piece indices [plo, phi) (whole lines) and valid positions in a line [clo, chi)
-                const int plo = c.ty0 == 0 ? 4 * RG_PC : 0, phi = 4 * RG_PC * min(RG_ROWS, H - c.ty0 + 1);
-                const int clo = c.tx0 == 0 ? 1 : 0, chi = min(RG_PC, (W - c.tx0 + 2) >> 1);
-                const unsigned safe = (unsigned)bias * 4u;   // the tile origin
-                unsigned m = 0;
-#pragma unroll
-                for (int i = 0; i < RG_KPL; ++i) {
-                    const int kk = min(lw + NL * i, RG_NDMA - 1), pidx = kk * RG_PPI + lane;
-                    const bool on = pcx[i] >= 0;
-                    const bool ok = pidx >= plo && pidx < phi && pcx[i] >= clo && pcx[i] < chi;
-                    m |= (on && !ok) ? (1u << i) : 0u;
-                    if (on) __builtin_amdgcn_global_load_lds((glb_vp)(sb + (ok ? relb[i] : safe)), (lds_vp)(slot + kk * RG_PPI * 16), 16, 0, 0);
-                }
-                vmask[(u % D) * 64 + lane] = m;
-            }
-        };
-        // the zero padding: pieces outside the image, zeroed after the unit's DMAs have landed
-        auto fix = [&](int u, const Cur& c) {
-            if (interior(c)) return;
-            unsigned char* slot = ring + (u % D) * RG_UNIT;
-            const unsigned m = vmask[(u % D) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < RG_KPL; ++i) {
-                const int kk = min(lw + NL * i, RG_NDMA - 1);
-                if ((m >> i) & 1u) *reinterpret_cast<u32x4_lds*>(slot + (kk * RG_PPI + lane) * 16) = u32x4_lds{0u, 0u, 0u, 0u};
-            }
-        };
-        const long long t_pre = RG_NOW();
-        // wait until every consumer wave has released unit v (slot v % D): lanes 0 .. NC - 1 poll one word each
-        auto wait_done = [&](int v) {
-            const volatile unsigned* wsl = hs_done + (lane < NC ? lane : 0) * D + (v % D);
-            while (!__all((int)(*wsl >= (unsigned)(v + 1)))) __builtin_amdgcn_s_sleep(1);
-        };
-        Cur ci = first(), cw = ci;
-        for (int u = 0; u < D - 1 && u < total; ++u) { issue(u, ci); next(ci); }
-        const long long t_set = RG_NOW();
-        long long s_wait = 0, s_fix = 0, s_bar = 0, s_iss = 0;
-        for (int u = 0; u < total; ++u) {
-            // DMAs younger than unit u's: those of units u + 1 .. min(u + D - 2, total - 1)
-            const int ahead = min(D - 2, total - 1 - u);
-            static_assert(2 * RG_KPL <= 63 && D <= 4, "the counted waits below (vmcnt is a 6-bit counter)");
-            const long long q0 = RG_NOW();
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RG_KPL) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RG_KPL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const long long q1 = RG_NOW();
-            fix(u, cw);
-            next(cw);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) hs_full[lw * D + (u % D)] = (unsigned)(u + 1);           // unit u published (this loader's share)
-            const long long q2 = RG_NOW();
-            if (u + D - 1 < total) {
-                if (u >= 1) wait_done(u - 1);                                        // the slot of unit u - 1 is the one unit u + D - 1 takes
-                const long long q3 = RG_NOW();
-                issue(u + D - 1, ci); next(ci);
-                const long long q4 = RG_NOW();
-                s_bar += q3 - q2; s_iss += q4 - q3;
-            }
-            s_wait += q1 - q0; s_fix += q2 - q1;
-        }
-        if (st && lw == 0 && lane == 0) {
-            st[0] = t_in; st[1] = t_pre; st[2] = t_set; st[3] = RG_NOW();
-            st[4] = s_wait; st[5] = s_fix; st[6] = s_bar; st[7] = s_iss; st[15] = total;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------- consumers (waves 0 .. NC - 1: one output row of 64 pixels each)
-    const EpiCtx ec = epi_ctx(a, n);
-    const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
-    float4 bias4[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = bp[2 * g + h];
-    f32x16 acc[1][2];
-    int tx0 = (t_first % tiles_x) * TW, ty0 = (t_first / tiles_x) * NC;
-    long long c_bar = 0, c_mma = 0, c_epi = 0;
-    for (int tl = 0; tl < ntl; ++tl, tx0 += TW) {
-        if (tx0 >= tiles_x * TW) { tx0 = 0; ty0 += NC; }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {   // accumulators start at the bias
-            const float4 bq4 = bias4[g];
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                acc[0][pt][4 * g + 0] = bq4.x; acc[0][pt][4 * g + 1] = bq4.y;
-                acc[0][pt][4 * g + 2] = bq4.z; acc[0][pt][4 * g + 3] = bq4.w;
-            }
-        }
-        for (int ch = 0; ch < nch; ++ch) {
-            const int u = tl * nch + ch;
-            const long long c0 = RG_NOW();
-            {   // unit u has landed: every loader wave has published its share
-                const volatile unsigned* fsl = hs_full + (lane < NL ? lane : 0) * D + (u % D);
-                while (!__all((int)(*fsl >= (unsigned)(u + 1)))) __builtin_amdgcn_s_sleep(1);
-            }
-            const long long c1 = RG_NOW();
-            c_bar += c1 - c0;
-            const unsigned char* slot = ring + (u % D) * RG_UNIT;
-            const bf16x8* wc = wl + ch * 9 * 64;
-            if (probe & 2) { if (lane == 0) hs_done[wave * D + (u % D)] = (unsigned)(u + 1); continue; }   // timing probe: no operand reads, no MFMAs
-            // Round 5: operand reads software-pipelined by hand.  hipcc scheduled every tap as ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs with ONE
-            // register set for the A fragment, i.e. one exposed LDS round trip per tap (1 600-1 900 ticks per unit for 576 cycles of MFMA pipe,
-            // profiles/r05_bf16_ring_v2_ab.txt).  Now the nine A fragments of the chunk and the B operands of taps 0 .. PF - 1 are in flight before the
-            // first MFMA, and tap t + PF's operands are issued in front of tap t's MFMAs (a PF-deep register ring for A and B; sched_barrier pins the order).
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            constexpr int PF = 3;
-            bf16x8 wa[PF + 1];
-            cu32x2 blo[PF + 1][2], bhi[PF + 1][2];
-            auto rdB = [&](int tap) {
-                const int ky = tap / 3, kx = tap - 3 * ky;
-                wa[tap % (PF + 1)] = wc[tap * 64 + lane];
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    // lane half h: quads 2h, 2h + 1 of the chunk at pixel tx0 + 32 pt + j + kx - 1 = image column + 2 in the slot
-                    const unsigned char* e = slot + (((wave + ky) * 4 + 2 * h) * RG_PC) * 16 + (pt * 32 + j + kx + 1) * 8;
-                    blo[tap % (PF + 1)][pt] = *reinterpret_cast<const cu32x2*>(e);
-                    bhi[tap % (PF + 1)][pt] = *reinterpret_cast<const cu32x2*>(e + RG_PC * 16);
-                }
-            };
-#pragma unroll
-            for (int tap = 0; tap < PF; ++tap) rdB(tap);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap + PF < 9) rdB(tap + PF);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    const cu32x2 lo = blo[tap % (PF + 1)][pt], hi = bhi[tap % (PF + 1)][pt];
-                    const bf16x8 bq8 = __builtin_bit_cast(bf16x8, u32x4_t{lo.x, lo.y, hi.x, hi.y});
-                    acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tap % (PF + 1)], bq8, acc[0][pt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // every operand of unit u is in registers (the last counted wait sat in front of tap 8's MFMAs): release the slot
-            if (lane == 0) hs_done[wave * D + (u % D)] = (unsigned)(u + 1);
-            if (st) { asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[0][1][15])); c_mma += RG_NOW() - c1; }
-        }
-        const long long e0 = RG_NOW();
-        // ST_Q4 with the fast activations only (conv_ring_eligible): ONE instantiation of the epilogue instead of the five-way switch of
-        // conv_epilogue (6 000 ISA lines in this kernel, most of its register pressure)
-        if (!(probe & 4)) conv_epilogue_t<1, 2, 1, ST_Q4, 2, false>(ec, acc, 0, tx0, ty0, wave, j, h, nullptr);
-        c_epi += RG_NOW() - e0;
-    }
-    if (st && tid == 0) { st[8] = t_in; st[9] = RG_NOW(); st[10] = c_bar; st[11] = c_mma; st[12] = c_epi; }
-#undef RG_NOW
-}
-
-// all K quads are whole bf16 quads with unit pixel stride (SRC_Q4), in whole 16-channel chunks, one cout tile
-static bool conv_ring_eligible(const ConvArgs& a) {
-    if (a.ctiles != 1 || (a.kq & 3) || a.kq < 4 || a.kq > 16 || a.W < 2 || (a.W & 1)) return false;   // even W: a 2-pixel piece is inside or outside the image as a whole
-    if (a.store != ST_Q4 || a.act == CRFP_ACT_TANH || a.act == CRFP_ACT_SIGMOID) return false;   // the ring carries the ST_Q4 epilogue only
-    const long long ps = a.qd[1].base - a.qd[0].base;   // floats per quad plane
-    if (ps <= 0 || ps >= (1ll << 26)) return false;
-    for (int q = 0; q < a.kq; ++q) {
-        if (a.qd[q].mask != 15 || a.qd[q].cs != kQuadBytes / 4 || a.qd[q].rs != a.qd[0].rs) return false;
-        // ring v2: the four quads of a 16-channel chunk lie at ONE plane stride from the chunk's first (and share its batch stride), so the
-        // loader folds the quad into a loop-invariant per-lane offset
-        const QuadDesc& c0 = a.qd[q & ~3];
-        if (a.qd[q].base - c0.base != (q & 3) * ps || a.qd[q].bstride != c0.bstride) return false;
-    }
-    // every per-lane byte offset (4 planes + a tile row) must fit 32 bits
-    if ((4 * ps + (long long)(a.H + 2) * a.qd[0].rs) * 4 >= (1ll << 31)) return false;
-    return true;
-}
-#endif  // CRFP_BF16_RING
 #endif  // CRFP_ACT_BF16
 
 #ifdef CRFP_LAB   // experiments that lose to conv3x3_split_kernel<1,1,2>: built only into the lab library (make lab)
@@ -2882,7 +2585,7 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
                    2.0 * px * a.cout * in_ch * 9.0);
     ConvArgs& am = const_cast<ConvArgs&>(a);  // callers pass a private, mutable plan copy
     am.stamps = nullptr;
-#if defined(CRFP_LAB) || defined(CRFP_BF16_RING)
+#ifdef CRFP_LAB
     // diagnostic: CRFP_STAMP_PTR=<device address> CRFP_STAMP_NAME=<launch site> records phase cycles per block
     static const char* stamp_name = getenv("CRFP_STAMP_NAME");
     static long long* stamp_ptr = getenv("CRFP_STAMP_PTR") ? (long long*)strtoull(getenv("CRFP_STAMP_PTR"), nullptr, 0) : nullptr;
@@ -2973,42 +2676,6 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
         // batch of clips is several rounds, where tile granularity no longer matters and the 4-wave kernel's four workgroups per CU overlap
         // more of each other's load / MFMA / store phases (round 4, same box, 4 clips: res.main0 15.1 -> 14.1 us per clip, conv_fuse 14.7 -> 14.0,
         // conv1 9.9 -> 9.2; CRFP_BF16_X8_MAX_WGS overrides the threshold for A/B runs)
-#ifdef CRFP_BF16_RING
-        // LDS-DMA ring form (see the kernel): CRFP_BF16_RING=<min workgroups of the one-tile form> enables it for launches at least that large
-        static const int ring_min = getenv("CRFP_BF16_RING") ? atoi(getenv("CRFP_BF16_RING")) : (1 << 30);
-        if ((long long)a.N * tiles >= ring_min && conv_ring_eligible(am)) {
-            const int nch = a.kq >> 2;
-            static const int ring_nc = getenv("CRFP_BF16_RING_NC") ? atoi(getenv("CRFP_BF16_RING_NC")) : 8;     // consumer waves = tile rows: 4 (round 4) or 8
-            static const int ring_wgs = getenv("CRFP_BF16_RING_WGS") ? atoi(getenv("CRFP_BF16_RING_WGS")) : 0;
-            static const int ring_probe = getenv("CRFP_BF16_RING_PROBE") ? atoi(getenv("CRFP_BF16_RING_PROBE")) : 0;   // timing probes: results wrong by design
-            static const int ring_nl = getenv("CRFP_BF16_RING_NL") ? atoi(getenv("CRFP_BF16_RING_NL")) : 2;     // loader waves
-            const int NC = ring_nc == 4 ? 4 : 8, NL = ring_nl == 1 ? 1 : 2;
-            const int D = nch <= 2 ? 4 : 3;
-            const size_t unit = NC == 4 ? RingGeom<4, 1>::UNIT : RingGeom<8, 1>::UNIT;
-            const size_t lds = (size_t)D * unit + 4 * (size_t)RG_WCH + (size_t)NL * D * 256 + 256;   // ring + A fragments of up to 4 chunks + the per-slot border masks + hand-shake words
-            const int rtiles = ((a.W + TW - 1) / TW) * ((a.H + NC - 1) / NC);
-            int G = ring_wgs > 0 ? ring_wgs : (int)(((NC == 4 ? 512 : 256) + a.N - 1) / a.N);   // NC = 8: one workgroup per CU over the whole launch
-            G = (G + 7) / 8 * 8;
-            if (G > rtiles) G = rtiles / 8 * 8;
-            if (G >= 8 && lds <= 160 * 1024) {
-#define RG_LAUNCH(DD, NN, LL)                                                                                                      \
-    {                                                                                                                               \
-        static const int once_ = hipFuncSetAttribute((const void*)conv3x3_bf16_ring_kernel<DD, NN, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        (void)once_;                                                                                                                \
-        conv3x3_bf16_ring_kernel<DD, NN, LL><<<dim3(G, 1, a.N), RingGeom<NN, LL>::NT, lds, s>>>(am, G, ring_probe);                   \
-    }
-                if (NC == 4 && D == 4) RG_LAUNCH(4, 4, 1)
-                else if (NC == 4) RG_LAUNCH(3, 4, 1)
-                else if (D == 4 && NL == 1) RG_LAUNCH(4, 8, 1)
-                else if (NL == 1) RG_LAUNCH(3, 8, 1)
-                else if (D == 4) RG_LAUNCH(4, 8, 2)
-                else RG_LAUNCH(3, 8, 2)
-#undef RG_LAUNCH
-                CRFP_CHECK_LAUNCH();
-                return 0;
-            }
-        }
-#endif
 #ifdef CRFP_LAB
         static const int x8_max_wgs = getenv("CRFP_BF16_X8_MAX_WGS") ? atoi(getenv("CRFP_BF16_X8_MAX_WGS")) : 512;   // A/B knob, lab library only
 #else

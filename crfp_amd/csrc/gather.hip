@@ -717,16 +717,26 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
 // results are bit-identical to the two-kernel path.  LDS 81 408 B (NW = 4, two workgroups per CU) / 117 248 B (NW = 8, shipped).
 constexpr int DF_LW = 34;
 constexpr int DF_WCH = 9 * 2 * 64;                   // one (cout tile, chunk) of the fp16 pair image, 16-byte elements
+#ifndef CRFP_DF_PS_PROBE   // A/B builds, timing only (results wrong): 1 = the persistent form never requests the next tile's halo tile / weights,
+#define CRFP_DF_PS_PROBE 0 // 2 = ... never writes them to LDS
+#endif
+constexpr int DF_PS_PROBE = CRFP_DF_PS_PROBE;
 
 __device__ __forceinline__ void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // NW = 4: workgroup of 4 rows x 32 pixels, two per CU, one weight stage (two barriers per stage).  NW = 8: 8 rows, one workgroup
 // per CU, the weight stage double-buffered (one barrier per stage, half the L2 -> LDS weight and DCN-image traffic per pixel).
-template <int NW>
+// PS (round 6): the PERSISTENT form.  gridDim.x workgroups (one per CU) walk the tile list of the whole launch (all batch items), XCD x
+// taking the contiguous band x of it (xcd_band_tile's split).  The DCN weight image, the bias table and the kernel's registers are set up
+// once per workgroup instead of once per tile; the NEXT tile's halo tile and weight stage 0 are requested in the middle of the current
+// tile's last cout tile (their registers -- rt, rws -- are dead there) and go to LDS behind one barrier at the tile boundary, so only the
+// first tile of a workgroup pays the 80 KB prologue in front of its first MFMA.  Same per-pixel operations in the same order: bit-identical.
+template <int NW, bool PS = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(const DcnFuseArgs a) {
     constexpr int NT = 64 * NW, DF_NEL = (NW + 2) * DF_LW;   // halo tile of an NW x 32-pixel workgroup
     constexpr int DF_NIN = (8 * DF_NEL + NT - 1) / NT;       // 16-byte tile elements per thread
     constexpr bool DB = NW == 8;
+    static_assert(!PS || DB, "the persistent form is the 8-wave form");
     constexpr int CPS = DB ? 2 : 1;                          // chunks per weight stage: NW = 8 stages a whole cout tile (7 barriers per workgroup)
     constexpr int DF_WST = CPS * DF_WCH, NSTG = 14 / CPS;
     constexpr int DF_NWS = (DF_WST + NT - 1) / NT;
@@ -734,65 +744,112 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     __shared__ f32x4 wst[DB ? 2 : 1][DF_WST];
     __shared__ f32x4 wl[36 * 64];
     __shared__ f32x4 bl[DB ? 56 : 1];   // the head's 224 packed biases (NW = 8: LDS has room; NW = 4 keeps them in 4 VGPRs)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
 #ifdef CRFP_PRIO47   // A/B builds: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-    if (wave >= 4) __builtin_amdgcn_s_setprio(CRFP_PRIO47);
+    if ((tid0 >> 6) >= 4) __builtin_amdgcn_s_setprio(CRFP_PRIO47);
 #endif
-    const int j = lane & 31, h = lane >> 5;
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * NW, n = blockIdx.z;
     const int H = a.H, W = a.W;
-    const int px = tx0 + j, py = ty0 + wave;
-    const bool valid = px < W && py < H;
-    const int cx = min(px, W - 1), cy = min(py, H - 1);
-
-    const f32x4* __restrict__ s3 = reinterpret_cast<const f32x4*>(a.feat + (long long)n * a.feat_b);
-    f32x4 rt[DF_NIN];
-    bool tv[DF_NIN];
-#pragma unroll
-    for (int t = 0; t < DF_NIN; ++t) {
-        const int idx = tid + NT * t, idc = min(idx, 8 * DF_NEL - 1);
-        const int pl = idc / DF_NEL, pix = idc - pl * DF_NEL, r = pix / DF_LW, c = pix - r * DF_LW;
-        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
-        tv[t] = idx < 8 * DF_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        rt[t] = s3[((long long)pl * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1)];
+    // the tile list (PS): tile id = (n * tiles_y + ty) * tiles_x + tx; this workgroup takes t_cur, t_cur + t_step, ... below t_end
+    const int tiles_x = (W + 31) >> 5, tiles_y = (H + NW - 1) / NW;
+    int t_cur = 0, t_end = 0, t_step = 1;
+    if (PS) {
+        const int total = tiles_x * tiles_y * a.N, G = (int)gridDim.x;
+#ifdef CRFP_DF_PS_NOBAND   // A/B builds: natural order (tile = workgroup id + k * workgroups)
+        t_cur = (int)blockIdx.x; t_end = total; t_step = G;
+#else
+        const int q = total >> 3, r = total & 7, x = (int)blockIdx.x & 7;
+        const int band0 = x * q + min(x, r);
+        t_cur = band0 + ((int)blockIdx.x >> 3); t_end = band0 + q + (x < r ? 1 : 0); t_step = G >> 3;
+#endif
+        if (t_cur >= t_end) return;
     }
+    int tx0, ty0, n;
+#define DF_DECODE(T_, TX, TY, NN)                                                                         \
+    {                                                                                                     \
+        const int per_ = tiles_x * tiles_y, n_ = (T_) / per_, r_ = (T_) - n_ * per_, y_ = r_ / tiles_x;   \
+        NN = n_; TY = y_ * NW; TX = (r_ - y_ * tiles_x) * 32;                                             \
+    }
+    if (PS) DF_DECODE(t_cur, tx0, ty0, n)
+    else { tx0 = blockIdx.x * 32; ty0 = blockIdx.y * NW; n = blockIdx.z; }
+
+    f32x4 rt[DF_NIN];
+    // the offset feature's halo tile of tile (TX, TY, NN) into rt[] (clamped addresses; what lies outside the image is zeroed on the way to LDS)
+#define DF_TLOAD(TX, TY, NN)                                                                              \
+    {                                                                                                     \
+        const f32x4* __restrict__ s3_ = reinterpret_cast<const f32x4*>(a.feat + (long long)(NN) * a.feat_b); \
+        _Pragma("unroll") for (int t = 0; t < DF_NIN; ++t) {                                              \
+            const int idc = min(ltid + NT * t, 8 * DF_NEL - 1);                                           \
+            const int pl = idc / DF_NEL, pix = idc - pl * DF_NEL, r = pix / DF_LW, c = pix - r * DF_LW;   \
+            const int gy = (TY) + r - 1, gx = (TX) + c - 1;                                               \
+            rt[t] = s3_[((long long)pl * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1)];       \
+        }                                                                                                 \
+    }
+    int ltid = tid0;  // the thread id as the tile loop sees it: re-defined (opaquely) per tile in the persistent form, so that everything derived
+                      // from it (lane / wave / LDS addresses / the loaders' index math) is recomputed where it is used instead of being hoisted
+                      // out of the tile loop into long-lived registers -- the kernel has none to spare
+    DF_TLOAD(tx0, ty0, n)
     const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(a.wconv);
     f32x4 rws[DF_NWS];
 #define DF_WLOAD(ST)                                                                                      \
-    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) rws[k] = wc[(ST) * DF_WST + min(tid + NT * k, DF_WST - 1)];
+    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) rws[k] = wc[(ST) * DF_WST + min(ltid + NT * k, DF_WST - 1)];
     DF_WLOAD(0)
     // Round 5 (CRFP_DF_LATE_PROLOGUE, default on for the 8-wave form): only what the first MFMA needs -- the halo tile and weight stage 0 -- is
     // fetched in front of the first barrier.  The DCN weight image (36 KB, first used by the sampler's MFMAs behind stage 1's barrier) and weight
     // stage 1 used to be ingested there too: 153 KB per workgroup before any MFMA, four rounds per launch.  They now land during cout tile 0,
     // which has no sampler work to hide anyway (DF_BEGIN).  Same values in the same places before their first use: bit-identical.
+    // (PS: the DCN weight image is fetched once per workgroup, in front of the tile loop.)
 #ifndef CRFP_DF_LATE_PROLOGUE
 #define CRFP_DF_LATE_PROLOGUE 1
 #endif
     constexpr bool LATE = DB && CRFP_DF_LATE_PROLOGUE;
+    static_assert(!PS || LATE, "the persistent form builds on the late prologue");
+    constexpr bool LATE_WL = LATE && !PS;   // the DCN weight image rides in rwl through cout tile 0
     constexpr int DF_NWL = (36 * 64 + NT - 1) / NT;
-    f32x4 rwl[LATE ? DF_NWL : 1];
-    if (!LATE)
-        for (int i = tid; i < 36 * 64; i += NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
-    const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
-    const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
+    f32x4 rwl[LATE_WL ? DF_NWL : 1];
+    if (!LATE_WL)
+        for (int i = tid0; i < 36 * 64; i += NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
+    if (DB && tid0 < 56) bl[tid0] = reinterpret_cast<const f32x4*>(a.bconv)[tid0];
+    float bv[4];   // NW = 4: no LDS left for the bias table
 #pragma unroll
-    for (int t = 0; t < DF_NIN; ++t) {
-        const int idx = tid + NT * t;
-        if (idx < 8 * DF_NEL) (&tile[0][0])[idx] = tv[t] ? rt[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-
-    // sampler set-up (dcn_g8_pipe_kernel)
+    for (int k = 0; k < 4; ++k) bv[k] = DB ? 0.0f : a.bconv[min(64 * k + (tid0 & 63), 223)];
     const long long plane = (long long)H * W * 4;
     const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
     const int guard = pitch + QB;
+    const float fH = (float)H, fW = (float)W;
+    // the halo tile in rt[] (tile at (TX, TY)) and weight stage 0 in rws[] go to LDS
+#define DF_WRITE(B)                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) {                                                  \
+        const int idx = ltid + NT * k;                                                                    \
+        if (idx < DF_WST) wst[B][idx] = rws[k];                                                           \
+    }
+#define DF_TWRITE(TX, TY)                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < DF_NIN; ++t) {                                                  \
+        const int idx = ltid + NT * t;                                                                    \
+        const int pl = idx / DF_NEL, pix = idx - pl * DF_NEL, r = pix / DF_LW, c = pix - r * DF_LW;       \
+        const int gy = (TY) + r - 1, gx = (TX) + c - 1;                                                   \
+        const bool tv = gy >= 0 && gy < H && gx >= 0 && gx < W;                                           \
+        if (idx < 8 * DF_NEL) (&tile[0][0])[idx] = tv ? rt[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};            \
+    }
+    DF_TWRITE(tx0, ty0)
+    if (DB) { DF_WRITE(0) if (!LATE) { DF_WLOAD(1) } }   // stage 0 in LDS (LATE: stage 1 is requested behind the first barrier)
+
+    for (;;) {   // one tile per trip (not PS: one trip)
+    if (PS) asm volatile("" : "+v"(ltid));
+    const int tid = ltid, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int hbase = 4 * h * plane_b + guard;
+    const int px = tx0 + j, py = ty0 + wave;
+    const bool valid = px < W && py < H;
+    const int cx = min(px, W - 1), cy = min(py, H - 1);
+    const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
+    const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
+    int ntx0 = 0, nty0 = 0, nn = 0;   // (PS) the workgroup's next tile
+    const bool has_next = PS && t_cur + t_step < t_end;
+
+    // sampler set-up (dcn_g8_pipe_kernel)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (char*)const_cast<act_t*>(as_act(a.x) + (long long)n * a.xb) - guard, 0, 8 * plane_b + guard, 0x00020000);
-    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
-    const int hbase = 4 * h * plane_b + guard;
-    float bv[4];   // NW = 4: no LDS left for the bias table
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bv[k] = DB ? 0.0f : a.bconv[min(64 * k + lane, 223)];
-    if (DB && tid < 56) bl[tid] = reinterpret_cast<const f32x4*>(a.bconv)[tid];
+    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1);
 
     f32x16 acc, acl, ca, cl;
 #pragma unroll
@@ -815,12 +872,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     dcn_f16x8 pw0, pw1, pb0, pb1;   // operands of the next tap (round 5)
 
     // one (cout tile, chunk) stage = DF_BEGIN (weights registers -> LDS, next stage's loads) + 9 taps x 3 MFMAs (DF_TAPS)
-#define DF_WRITE(B)                                                                                       \
-    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) {                                                  \
-        const int idx = tid + NT * k;                                                                     \
-        if (idx < DF_WST) wst[B][idx] = rws[k];                                                           \
-    }
-    if (DB) { DF_WRITE(0) if (!LATE) { DF_WLOAD(1) } }   // stage 0 in LDS (LATE: stage 1 is requested behind the first barrier)
     // single buffer: barrier (everyone done with the previous stage), registers -> LDS, barrier, next stage's loads.
     // double buffer: one barrier (stage s complete in buffer s & 1 and everyone done with stage s - 1), then the registers
     // (stage s + 1) go to the other buffer and stage s + 2's loads leave.  LATE: stage 0 only requests stage 1 and the DCN weight image
@@ -830,8 +881,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         wcur = &wst[(T) & 1][DF_WCH];                                                                     \
         if (LATE && (T) == 0) {                                                                           \
             DF_WRITE(1)                                                                                   \
-            _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                            \
-                if (tid + NT * k < 36 * 64) wl[tid + NT * k] = rwl[k];                                    \
+            if (LATE_WL) {                                                                                \
+                _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                        \
+                    if (tid + NT * k < 36 * 64) wl[tid + NT * k] = rwl[k];                                \
+            }                                                                                             \
             DF_WLOAD(2)                                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
@@ -841,8 +894,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         if (first_ || !(DF_PROBE & 4)) df_lds_barrier();                                                  \
         if (DB && LATE && first_) {                                                                       \
             DF_WLOAD(1)                                                                                   \
-            _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                            \
-                rwl[k] = reinterpret_cast<const f32x4*>(a.wdcn)[min(tid + NT * k, 36 * 64 - 1)];          \
+            if (LATE_WL) {                                                                                \
+                _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                        \
+                    rwl[k] = reinterpret_cast<const f32x4*>(a.wdcn)[min(tid + NT * k, 36 * 64 - 1)];      \
+            }                                                                                             \
         } else if (DB) {                                                                                  \
             if (s_ + 1 < NSTG) { DF_WRITE((s_ + 1) & 1) }                                                 \
             if (s_ + 2 < NSTG) { DF_WLOAD(s_ + 2) }                                                       \
@@ -991,6 +1046,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #define DF_L(U, PI, P) if (!(DF_PROBE & 1)) { dcn_lerp_one(P, PI, xs); }
 #define DF_S(U) if (!(DF_PROBE & 1)) { dcn_split_mfma(xs, acc, acl, wl, U, lane); }
     float xs[8];
+    // (PS) hooks in the schedule's tail (behind the last conv MFMA, where rt, rws, the conv accumulators and the operand prefetch registers are
+    // dead).  DF_TAIL_REQUEST, behind the last gather issue: the next tile's halo tile and weight stage 0 are requested (no gather queues behind
+    // them in the in-order vmcnt).  DF_TAIL_COMMIT, behind the last DCN MFMA: one barrier (every wave is past its last conv operand read), then
+    // they go to LDS -- the next tile's first barrier publishes them.  Their registers never live across the loop's back edge.
+#define DF_TAIL_REQUEST                                                                                   \
+    if (PS) {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        DF_DECODE(has_next ? t_cur + t_step : t_cur, ntx0, nty0, nn)                                      \
+        if (!(DF_PS_PROBE & 1)) { DF_TLOAD(ntx0, nty0, nn) DF_WLOAD(0) }                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+#define DF_TAIL_COMMIT                                                                                    \
+    if (PS && has_next) {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        df_lds_barrier();                                                                                 \
+        if (!(DF_PS_PROBE & 2)) { DF_TWRITE(ntx0, nty0) DF_WRITE(0) }                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
 #ifdef CRFP_DF_SCHED_R2
     // Cout tile T completes the sampling pairs up to (16 T + 10) / 6: 1, 4, 7, 9, 12, 15, 17.  The pairs of tile T are sampled
     // INSIDE the two stages of tile T + 1, between its taps: the MFMA runs 32 clocks in its own pipe while the wave issues the
@@ -1016,7 +1089,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     DF_BIAS(6)
     DF_BEGIN(6, 0) DF_TAPS(0, 0, 2) DF_TRANS(5) DF_SB DF_TAPS(0, 2, 4) DF_I(13, Q1) DF_SB DF_TAPS(0, 4, 7) DF_SB DF_C(12, Q0) DF_SB DF_TAPS(0, 7, 9) DF_I(14, Q0) DF_SB
     DF_BEGIN(6, 1) DF_TAPS(1, 0, 3) DF_SB DF_C(13, Q1) DF_SB DF_TAPS(1, 3, 6) DF_SB DF_C(14, Q0) DF_SB DF_TAPS(1, 6, 9) DF_I(15, Q1) DF_SB DF_RAW(6)
-    DF_TRANS(6) DF_I(16, Q0) DF_SB DF_C(15, Q1) DF_SB DF_I(17, Q1) DF_SB DF_C(16, Q0) DF_SB DF_C(17, Q1)
+    DF_TRANS(6) DF_I(16, Q0) DF_SB DF_C(15, Q1) DF_SB DF_I(17, Q1) DF_SB DF_TAIL_REQUEST DF_C(16, Q0) DF_SB DF_C(17, Q1) DF_TAIL_COMMIT
 #else
     // Round 3: ONE micro-item in front of EVERY tap instead of whole pairs between groups of 2-4 taps (tools/gen/dcn_fused_schedule.py
     // holds the dependency rules and writes the table): <= ~30 vector instructions per 3 MFMAs, the regime in which
@@ -1044,21 +1117,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #undef DF_TRANS
 #undef DF_RAW
 #undef DF_BIAS
-#undef DF_WLOAD
-    if (!valid) return;
+    if (valid) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
-    act_t* o = as_act(a.out) + (long long)n * a.ob + ((long long)py * W + px) * 4;
-    float vmax = 0.0f;
+        for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
+        act_t* o = as_act(a.out) + (long long)n * a.ob + ((long long)py * W + px) * 4;
+        float vmax = 0.0f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int cq = 2 * g + h;
-        const float4 bb = *reinterpret_cast<const float4*>(a.bdcn + 4 * cq);
-        const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
-        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
+        for (int g = 0; g < 4; ++g) {
+            const int cq = 2 * g + h;
+            const float4 bb = *reinterpret_cast<const float4*>(a.bdcn + 4 * cq);
+            const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
+        }
+        if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
     }
-    if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
+    if (!has_next) break;
+    t_cur += t_step;
+    tx0 = ntx0; ty0 = nty0; n = nn;
+    }   // tiles
+#undef DF_TAIL_REQUEST
+#undef DF_TAIL_COMMIT
+#undef DF_TWRITE
+#undef DF_WLOAD
+#undef DF_TLOAD
+#undef DF_DECODE
 }
 
 #ifdef CRFP_LAB   // lost its A/B (141.2 vs 136.6 us): lab library only (round 5)
@@ -1247,6 +1330,8 @@ bool dcn_fused_enabled() {
     return on;
 }
 
+constexpr int kFusedPersistWgs = 256;   // workgroups of the persistent form = CUs of an MI355X (one 8-wave workgroup per CU: 155 KB of LDS, 250 VGPRs)
+
 int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     if ((long long)(a.H + 1) * (a.W + 1) >= (1ll << 24)) { set_error("dcn_g8: plane of %d x %d exceeds the sampler's 2^24-element index range", a.H, a.W); return CRFP_E_UNSUPPORTED; }
     const double px = (double)a.N * a.H * a.W;
@@ -1275,7 +1360,13 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     // (lab library, CRFP_DCN_FUSE_V=2: the role-specialised 16-wave form above -- bit-identical, 141.2 vs 136.6 us per launch same-box @A:
     // both forms pay the same ~53 us of per-workgroup fixed cost (116 KB of tile / weight prologue and 258 KB of streamed head
     // weights per 256 pixels, 15 barriers), and the specialised one overlaps only 17 of the 49 us its sampler role adds)
-    dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
+    // Round 6: more tiles than CUs -> the persistent form (one workgroup per CU walks its XCD's band of the tile list)
+#ifndef CRFP_DF_PERSIST
+#define CRFP_DF_PERSIST 1
+#endif
+    const int tiles = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.N;
+    if (CRFP_DF_PERSIST && tiles > kFusedPersistWgs) dcn_fused_kernel<8, true><<<dim3(kFusedPersistWgs, 1, 1), 512, 0, s>>>(a);
+    else dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1289,78 +1380,123 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
 // workgroups per CU.
 constexpr int DF_LW = 34;
 constexpr int DF_WST = 2 * 9 * 64;                   // one cout tile of the bf16 image, 16-byte elements
+#ifndef CRFP_DF_PS_PROBE   // A/B builds, timing only (results wrong): see the fp32 kernel
+#define CRFP_DF_PS_PROBE 0
+#endif
+constexpr int DF_PS_PROBE = CRFP_DF_PS_PROBE;
 typedef __bf16 df_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void df_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // NW = 4: workgroup of 4 rows x 32 pixels, two per CU, one weight stage (two barriers per stage).  NW = 8: 8 rows, one workgroup
 // per CU, the weight stage double-buffered (one barrier per stage, half the L2 -> LDS weight and DCN-image traffic per pixel).
-template <int NW>
+// PS (round 6): the persistent form -- see the fp32 kernel.
+template <int NW, bool PS = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(const DcnFuseArgs a) {
     constexpr int NT = 64 * NW, DF_NEL = (NW + 2) * DF_LW;
     constexpr int DF_NIN = (8 * DF_NEL + NT - 1) / NT;     // 8-byte quads of the tile per thread
     constexpr int DF_NWS = (DF_WST + NT - 1) / NT;
     constexpr bool DB = NW == 8;
+    static_assert(!PS || DB, "the persistent form is the 8-wave form");
     __shared__ cu32x2 tile[4][DF_NEL][2];   // [8-channel group][halo pixel][quad of the pair]
     __shared__ f32x4 wst[DB ? 2 : 1][DF_WST];
     __shared__ f32x4 wl[36 * 64];
     __shared__ f32x4 bl[DB ? 56 : 1];   // the head's 224 packed biases (NW = 8: LDS has room; NW = 4 keeps them in 4 VGPRs)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * NW, n = blockIdx.z;
+    const int tid0 = threadIdx.x;
     const int H = a.H, W = a.W;
-    const int px = tx0 + j, py = ty0 + wave;
-    const bool valid = px < W && py < H;
-    const int cx = min(px, W - 1), cy = min(py, H - 1);
-
-    const cu32x2* __restrict__ fq = reinterpret_cast<const cu32x2*>(as_act(a.feat) + (long long)n * a.feat_b);
-    cu32x2 rt[DF_NIN];
-    bool tv[DF_NIN];
-#pragma unroll
-    for (int t = 0; t < DF_NIN; ++t) {
-        const int idx = tid + NT * t, idc = min(idx, 8 * DF_NEL - 1);
-        const int q = idc / DF_NEL, pix = idc - q * DF_NEL, r = pix / DF_LW, c = pix - r * DF_LW;
-        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
-        tv[t] = idx < 8 * DF_NEL && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        rt[t] = fq[((long long)q * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1)];
+    const int tiles_x = (W + 31) >> 5, tiles_y = (H + NW - 1) / NW;
+    int t_cur = 0, t_end = 0, t_step = 1;
+    if (PS) {
+        const int total = tiles_x * tiles_y * a.N, G = (int)gridDim.x;
+#ifdef CRFP_DF_PS_NOBAND   // A/B builds: natural order (tile = workgroup id + k * workgroups)
+        t_cur = (int)blockIdx.x; t_end = total; t_step = G;
+#else
+        const int q = total >> 3, r = total & 7, x = (int)blockIdx.x & 7;
+        const int band0 = x * q + min(x, r);
+        t_cur = band0 + ((int)blockIdx.x >> 3); t_end = band0 + q + (x < r ? 1 : 0); t_step = G >> 3;
+#endif
+        if (t_cur >= t_end) return;
     }
+    int tx0, ty0, n;
+#define DF_DECODE(T_, TX, TY, NN)                                                                         \
+    {                                                                                                     \
+        const int per_ = tiles_x * tiles_y, n_ = (T_) / per_, r_ = (T_) - n_ * per_, y_ = r_ / tiles_x;   \
+        NN = n_; TY = y_ * NW; TX = (r_ - y_ * tiles_x) * 32;                                             \
+    }
+    if (PS) DF_DECODE(t_cur, tx0, ty0, n)
+    else { tx0 = blockIdx.x * 32; ty0 = blockIdx.y * NW; n = blockIdx.z; }
+
+    int ltid = tid0;   // the thread id as the tile loop sees it (opaquely re-defined per tile: see the fp32 kernel)
+    cu32x2 rt[DF_NIN];
+#define DF_TLOAD(TX, TY, NN)                                                                              \
+    {                                                                                                     \
+        const cu32x2* __restrict__ fq_ = reinterpret_cast<const cu32x2*>(as_act(a.feat) + (long long)(NN) * a.feat_b); \
+        _Pragma("unroll") for (int t = 0; t < DF_NIN; ++t) {                                              \
+            const int idc = min(ltid + NT * t, 8 * DF_NEL - 1);                                           \
+            const int q = idc / DF_NEL, pix = idc - q * DF_NEL, r = pix / DF_LW, c = pix - r * DF_LW;     \
+            const int gy = (TY) + r - 1, gx = (TX) + c - 1;                                               \
+            rt[t] = fq_[((long long)q * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1)];        \
+        }                                                                                                 \
+    }
+#define DF_TWRITE(TX, TY)                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < DF_NIN; ++t) {                                                  \
+        const int idx = ltid + NT * t;                                                                    \
+        const int q = idx / DF_NEL, pix = idx - q * DF_NEL, r = pix / DF_LW, c = pix - r * DF_LW;         \
+        const int gy = (TY) + r - 1, gx = (TX) + c - 1;                                                   \
+        const bool tv = gy >= 0 && gy < H && gx >= 0 && gx < W;                                           \
+        if (idx < 8 * DF_NEL) tile[q >> 1][pix][q & 1] = tv ? rt[t] : cu32x2{0u, 0u};                     \
+    }
+    DF_TLOAD(tx0, ty0, n)
     const f32x4* __restrict__ wc = reinterpret_cast<const f32x4*>(a.wconv);
     f32x4 rws[DF_NWS];
 #define DF_WLOAD(ST)                                                                                      \
-    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) rws[k] = wc[(ST) * DF_WST + min(tid + NT * k, DF_WST - 1)];
+    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) rws[k] = wc[(ST) * DF_WST + min(ltid + NT * k, DF_WST - 1)];
     DF_WLOAD(0)
     // Round 5 (see the fp32 kernel): the DCN weight image and weight stage 1 are requested BEHIND the first barrier and written to LDS in the
     // middle of cout tile 0 (DF_LATE_FILL), so that only the halo tile and stage 0 are ingested in front of the first MFMA.
+    // (PS: the DCN weight image is fetched once per workgroup, in front of the tile loop.)
 #ifndef CRFP_DF_LATE_PROLOGUE
 #define CRFP_DF_LATE_PROLOGUE 1
 #endif
     constexpr bool LATE = DB && CRFP_DF_LATE_PROLOGUE;
+    static_assert(!PS || LATE, "the persistent form builds on the late prologue");
+    constexpr bool LATE_WL = LATE && !PS;
     constexpr int DF_NWL = (36 * 64 + NT - 1) / NT;
-    f32x4 rwl[LATE ? DF_NWL : 1];
-    if (!LATE)
-        for (int i = tid; i < 36 * 64; i += NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
-    const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
-    const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
-#pragma unroll
-    for (int t = 0; t < DF_NIN; ++t) {
-        const int idx = tid + NT * t;
-        if (idx < 8 * DF_NEL) {
-            const int q = idx / DF_NEL, pix = idx - q * DF_NEL;
-            tile[q >> 1][pix][q & 1] = tv[t] ? rt[t] : cu32x2{0u, 0u};
-        }
-    }
+    f32x4 rwl[LATE_WL ? DF_NWL : 1];
+    if (!LATE_WL)
+        for (int i = tid0; i < 36 * 64; i += NT) wl[i] = reinterpret_cast<const f32x4*>(a.wdcn)[i];
+    DF_TWRITE(tx0, ty0)
 
     const long long plane = (long long)H * W * 4;
     const int PW = W + 1, pitch = PW * QB, plane_b = (H + 1) * pitch;
     const int guard = pitch + QB;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        (char*)const_cast<act_t*>(as_act(a.x) + (long long)n * a.xb) - guard, 0, 8 * plane_b + guard, 0x00020000);
-    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1), fH = (float)H, fW = (float)W;
-    const int hbase = 4 * h * plane_b + guard;
+    const float fH = (float)H, fW = (float)W;
     float bv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bv[k] = DB ? 0.0f : a.bconv[min(64 * k + lane, 223)];
-    if (DB && tid < 56) bl[tid] = reinterpret_cast<const f32x4*>(a.bconv)[tid];
+    for (int k = 0; k < 4; ++k) bv[k] = DB ? 0.0f : a.bconv[min(64 * k + (tid0 & 63), 223)];
+    if (DB && tid0 < 56) bl[tid0] = reinterpret_cast<const f32x4*>(a.bconv)[tid0];
+#define DF_WRITE(B)                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) {                                                  \
+        const int idx = ltid + NT * k;                                                                    \
+        if (idx < DF_WST) wst[B][idx] = rws[k];                                                           \
+    }
+    if (DB) { DF_WRITE(0) if (!LATE) { DF_WLOAD(1) } }   // stage 0 in LDS (LATE: stage 1 is requested behind the first barrier)
+
+    for (;;) {   // one tile per trip (not PS: one trip)
+    if (PS) asm volatile("" : "+v"(ltid));
+    const int tid = ltid, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int px = tx0 + j, py = ty0 + wave;
+    const bool valid = px < W && py < H;
+    const int cx = min(px, W - 1), cy = min(py, H - 1);
+    const float2 fl = *reinterpret_cast<const float2*>(a.flow + (long long)n * a.flow_b + ((long long)cy * W + cx) * 2);
+    const float cfy = 10.0f + fl.y, cfx = 10.0f + fl.x;
+    int ntx0 = 0, nty0 = 0, nn = 0;   // (PS) the workgroup's next tile
+    const bool has_next = PS && t_cur + t_step < t_end;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (char*)const_cast<act_t*>(as_act(a.x) + (long long)n * a.xb) - guard, 0, 8 * plane_b + guard, 0x00020000);
+    const float fy0 = (float)(cy - 1), fx0 = (float)(cx - 1);
+    const int hbase = 4 * h * plane_b + guard;
 
     f32x16 acc, acl, ca;
 #pragma unroll
@@ -1370,20 +1506,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     const f32x4* wcur = &wst[0][0];
     df_bf16x8 pw0, pb0;   // operands of the next MFMA (round 5)
 
-#define DF_WRITE(B)                                                                                       \
-    _Pragma("unroll") for (int k = 0; k < DF_NWS; ++k) {                                                  \
-        const int idx = tid + NT * k;                                                                     \
-        if (idx < DF_WST) wst[B][idx] = rws[k];                                                           \
-    }
-    if (DB) { DF_WRITE(0) if (!LATE) { DF_WLOAD(1) } }   // stage 0 in LDS (LATE: stage 1 is requested behind the first barrier)
     // single buffer: barrier (everyone done with the previous stage), registers -> LDS, barrier, next stage's loads.
     // double buffer: one barrier (stage T complete in buffer T & 1 and everyone done with stage T - 1), then the registers
     // (stage T + 1) go to the other buffer and stage T + 2's loads leave
 #define DF_LATE_FILL                                                                                      \
     if (LATE) {                                                                                           \
         DF_WRITE(1)                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                                \
-            if (tid + NT * k < 36 * 64) wl[tid + NT * k] = rwl[k];                                        \
+        if (LATE_WL) {                                                                                    \
+            _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                            \
+                if (tid + NT * k < 36 * 64) wl[tid + NT * k] = rwl[k];                                    \
+        }                                                                                                 \
         DF_WLOAD(2)                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                \
     }
@@ -1392,8 +1524,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         df_lds_barrier();                                                                                 \
         if (DB && LATE && (T) == 0) {                                                                     \
             DF_WLOAD(1)                                                                                   \
-            _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                            \
-                rwl[k] = reinterpret_cast<const f32x4*>(a.wdcn)[min(tid + NT * k, 36 * 64 - 1)];          \
+            if (LATE_WL) {                                                                                \
+                _Pragma("unroll") for (int k = 0; k < DF_NWL; ++k)                                        \
+                    rwl[k] = reinterpret_cast<const f32x4*>(a.wdcn)[min(tid + NT * k, 36 * 64 - 1)];      \
+            }                                                                                             \
         } else if (DB) {                                                                                  \
             if ((T) + 1 < 7) { DF_WRITE(((T) + 1) & 1) }                                                  \
             if ((T) + 2 < 7) { DF_WLOAD((T) + 2) }                                                        \
@@ -1471,6 +1605,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         dcn_issue_one(P, 1, rx, ov[6 * (U) + 3], ov[6 * (U) + 4], ov[6 * (U) + 5], 2 * (U) + 1, fy0, fx0, fH, fW, PW, pitch, plane_b, hbase); \
     }
 #define DF_C(U, P) { dcn_consume_pair(P, acc, acl, wl, U, lane); }
+    // (PS) the hooks of the schedule's tail: see the fp32 kernel
+#define DF_TAIL_REQUEST                                                                                   \
+    if (PS) {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        DF_DECODE(has_next ? t_cur + t_step : t_cur, ntx0, nty0, nn)                                      \
+        if (!(DF_PS_PROBE & 1)) { DF_TLOAD(ntx0, nty0, nn) DF_WLOAD(0) }                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+#define DF_TAIL_COMMIT                                                                                    \
+    if (PS && has_next) {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        df_lds_barrier();                                                                                 \
+        if (!(DF_PS_PROBE & 2)) { DF_TWRITE(ntx0, nty0) DF_WRITE(0) }                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
     // cout tile T completes the sampling pairs up to (16 T + 10) / 6: 1, 4, 7, 9, 12, 15, 17; they are sampled inside tile T + 1.
     // Pair u lives in Q[u % 3]; I(u) follows C(u - 3).
     DF_BEGIN(0) DF_BIAS(0) DF_M(0, 9) DF_LATE_FILL DF_M(9, 18) DF_RAW(0)   // (the bias table in LDS is complete behind the first barrier)
@@ -1491,7 +1640,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
     DF_BIAS(6)
     DF_BEGIN(6) DF_M(0, 3) DF_TRANS(5) DF_SB DF_M(3, 6) DF_SB DF_C(10, Q1) DF_SB DF_M(6, 9) DF_I(13, Q1) DF_SB DF_M(9, 12) DF_SB DF_C(11, Q2) DF_SB
                 DF_M(12, 15) DF_I(14, Q2) DF_SB DF_M(15, 18) DF_SB DF_C(12, Q0) DF_SB DF_I(15, Q0) DF_SB DF_RAW(6)
-    DF_TRANS(6) DF_SB DF_C(13, Q1) DF_SB DF_I(16, Q1) DF_SB DF_C(14, Q2) DF_SB DF_I(17, Q2) DF_SB DF_C(15, Q0) DF_SB DF_C(16, Q1) DF_SB DF_C(17, Q2)
+    DF_TRANS(6) DF_SB DF_C(13, Q1) DF_SB DF_I(16, Q1) DF_SB DF_C(14, Q2) DF_SB DF_I(17, Q2) DF_SB DF_TAIL_REQUEST DF_C(15, Q0) DF_SB DF_C(16, Q1) DF_SB DF_C(17, Q2) DF_TAIL_COMMIT
 #undef DF_C
 #undef DF_I
 #undef DF_SB
@@ -1502,27 +1651,39 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
 #undef DF_LATE_FILL
 #undef DF_BEGIN
 #undef DF_WRITE
-#undef DF_WLOAD
-    if (!valid) return;
+    if (valid) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
-    act_t* o = as_act(a.out) + (long long)n * a.ob + ((long long)py * W + px) * 4;
-    float vmax = 0.0f;
+        for (int e = 0; e < 16; ++e) acc[e] += acl[e] * (1.0f / 2048.0f);
+        act_t* o = as_act(a.out) + (long long)n * a.ob + ((long long)py * W + px) * 4;
+        float vmax = 0.0f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int cq = 2 * g + h;
-        const float4 bb = *reinterpret_cast<const float4*>(a.bdcn + 4 * cq);
-        const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
-        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
+        for (int g = 0; g < 4; ++g) {
+            const int cq = 2 * g + h;
+            const float4 bb = *reinterpret_cast<const float4*>(a.bdcn + 4 * cq);
+            const float4 v = make_float4(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y, acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            stq(o + cq * plane, cf32x4{v.x, v.y, v.z, v.w});
+        }
+        if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
     }
-    if (a.ovf && !(vmax < 65504.0f)) atomicOr(ovf_word(a.ovf, a.ovf_div, 0, n), 1u);
+    if (!has_next) break;
+    t_cur += t_step;
+    tx0 = ntx0; ty0 = nty0; n = nn;
+    }   // tiles
+#undef DF_TAIL_REQUEST
+#undef DF_TAIL_COMMIT
+#undef DF_TWRITE
+#undef DF_WLOAD
+#undef DF_TLOAD
+#undef DF_DECODE
 }
 
 bool dcn_fused_enabled() {
     static const bool on = !(getenv("CRFP_DCN_FUSED") && atoi(getenv("CRFP_DCN_FUSED")) == 0);
     return on;
 }
+
+constexpr int kFusedPersistWgs = 256;   // workgroups of the persistent form = CUs of an MI355X (one 8-wave workgroup per CU)
 
 int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     if ((long long)(a.H + 1) * (a.W + 1) >= (1ll << 24)) { set_error("dcn_g8: plane of %d x %d exceeds the sampler's 2^24-element index range", a.H, a.W); return CRFP_E_UNSUPPORTED; }
@@ -1536,7 +1697,15 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     if (nw4) dcn_fused_kernel<4><<<dim3((a.W + 31) / 32, (a.H + 3) / 4, a.N), 256, 0, s>>>(a);
     else
 #endif
-    dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
+    {
+        // Round 6: more tiles than CUs -> the persistent form (one workgroup per CU walks its XCD's band of the tile list)
+#ifndef CRFP_DF_PERSIST
+#define CRFP_DF_PERSIST 1
+#endif
+        const int tiles = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.N;
+        if (CRFP_DF_PERSIST && tiles > kFusedPersistWgs) dcn_fused_kernel<8, true><<<dim3(kFusedPersistWgs, 1, 1), 512, 0, s>>>(a);
+        else dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
+    }
     CRFP_CHECK_LAUNCH();
     return 0;
 }

@@ -125,10 +125,16 @@ def emit(taps, sched, tail):
         if ch == 1 and tap == 8:
             line += f"DF_SB DF_RAW({T}) "
         out.append("    " + line.rstrip())
+    # the tail (behind the last tap).  Round 6: two hooks for the persistent form of the kernel (no-ops otherwise) -- DF_TAIL_REQUEST behind the
+    # last gather issue (the next tile's halo tile and weight stage 0 are requested), DF_TAIL_COMMIT behind the last DCN MFMA (they go to LDS)
     line = "    "
-    for _, it in tail:
-        if it[0] != "WAIT":
-            line += macro(it) + " DF_SB "
+    real = [it for _, it in tail if it[0] != "WAIT"]
+    last_i = max(i for i, it in enumerate(real) if it[0] == "I")
+    for i, it in enumerate(real):
+        line += macro(it) + " DF_SB "
+        if i == last_i:
+            line += "DF_TAIL_REQUEST "
+    line += "DF_TAIL_COMMIT"
     out.append(line.rstrip())
     return "\n".join(out) + "\n"
 

@@ -18,7 +18,12 @@ objs=""
 for f in runtime conv_mfma conv_narrow gather resample metrics engine engine_rt api spynet; do   # = SRCS of csrc/Makefile
   if [ $f = $base ]; then objs="$objs $ROOT/_ab/obj/$base.$name.o"; else objs="$objs $C/$OBJDIR/$f.o"; fi
 done
-if [[ "$extra" == *CRFP_ACT_BF16_VARIANT* ]]; then echo "bf16 variants: build by hand"; fi
-for f in conv_mfma conv_narrow gather resample engine; do objs="$objs $C/build/$f.bf16.o"; done
+# BF16=1: the bf16-storage object of the same source is recompiled with the same flags too (default: the product's bf16 objects)
+for f in conv_mfma conv_narrow gather resample engine; do
+  if [ "${BF16:-0}" = 1 ] && [ $f = $base ]; then
+    /opt/rocm/bin/hipcc $FLAGS -DCRFP_ACT_BF16 $SCHED $extra -c $C/$base.hip -o $ROOT/_ab/obj/$base.$name.bf16.o 2>&1 | grep -v "not a recognized feature" | grep -E "error|warning: fail" || true
+    objs="$objs $ROOT/_ab/obj/$base.$name.bf16.o"
+  else objs="$objs $C/build/$f.bf16.o"; fi
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/_ab/libcrfp_$name.so $objs
 echo built _ab/libcrfp_$name.so
