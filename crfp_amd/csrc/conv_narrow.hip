@@ -89,6 +89,17 @@ __device__ __forceinline__ void narrow_src_index(int dst, float scale, int in_si
     l0 = 1.0f - l1;
 }
 
+// the second destination of an NE_PLAIN epilogue (NarrowArgs::dst2): the arithmetic of lrelu_q4_to_p4_kernel (resample.hip) on the value
+// as dst holds it (bf16 storage: after its rounding)
+__device__ __forceinline__ void narrow_store_state(act_t* d2, long long ppix, cf32x4 v, float& vmax) {
+#ifdef CRFP_ACT_BF16
+    v = quad_from_bits(quad_to_bits(v));
+#endif
+    const cf32x4 o = cf32x4{v.x > 0.0f ? v.x : 0.1f * v.x, v.y > 0.0f ? v.y : 0.1f * v.y, v.z > 0.0f ? v.z : 0.1f * v.z, v.w > 0.0f ? v.w : 0.1f * v.w};
+    stq(d2 + ppix * 4, o);
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+}
+
 // GATE: NarrowArgs::gate holds, per 64 x 16 tile of this launch's map, whether the fovea mask has a set pixel within `gate_h` tiles of the
 // tile (mask_gate_kernel, resample.hip).  Tiles without one are not computed at all.  NE_PLAIN (encoder_hr, model/CRFP.py:1545-1547): their
 // outputs only ever feed pixels the fovea blend deselects.  NE_BLEND (conv_tttf + blend, :1672-1675): there the new state is lrelu(state),
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     act_t* const dsta = as_act(a.dst) + (long long)n * a.dst_bstride;   // NE_PLAIN / NE_BLEND: activation (act_t) tensors
     const int dpitch = W + a.dst_pad;                       // Q4 destination may be padded (P4)
     const act_t* const resid = a.resid ? as_act(a.resid) + (long long)n * a.resid_bstride : nullptr;
+    act_t* const dst2 = EPI == NE_PLAIN && a.dst2 ? as_act(a.dst2) + (long long)n * a.dst2_bstride : nullptr;
     const uint8_t* const mask = EPI == NE_BLEND ? a.mask + (long long)n * a.mask_bstride : nullptr;
     const act_t* const basep = EPI == NE_LAST && a.base ? as_act(a.base) + (long long)n * a.base_bstride : nullptr;
     const float* const baselr = EPI == NE_LAST && !a.base ? a.base_lr + (long long)n * a.base_bstride : nullptr;
@@ -347,6 +359,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                         v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                     }
                     stq(dsta + dpix * 4, cf32x4{v[0], v[1], v[2], v[3]});
+                    if (dst2) narrow_store_state(dst2, (long long)y * (W + 1) + x, cf32x4{v[0], v[1], v[2], v[3]}, vmax);
                 } else if (EPI == NE_BLEND) {
 #ifdef CRFP_ACT_BF16
                     const cf32x4 centre = quad_from_bits(tile[0][4 * ty + i + 1][tx + 1]);
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                 }
             }
         }
-        if (EPI == NE_BLEND && ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
+        if ((EPI == NE_BLEND || (EPI == NE_PLAIN && dst2)) && ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
         if (t_next >= band1) break;
         t_cur = t_next;
         // every wave is done reading the tile before it is overwritten.  LDS-only barrier: __syncthreads() would also
@@ -488,6 +501,133 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_direct_kernel(const Narrow
 }
 #endif
 
+#ifndef CRFP_ACT_BF16
+// ---------------------------------------------------------------- quad-sequential form of the multi-quad stencils (round 6, fp32 build)
+// conv3x3_narrow_kernel stages ALL KQ input quads of a tile at once: 57 KB of LDS and 149 VGPRs for KQ = 3 = two workgroups per CU, whose
+// load / MFMA / store phases then add up instead of overlapping (destructive probes, profiles/r06_narrow_probes.txt: dcn3.block0 67.0 us,
+// without its MFMAs 51.0, without its loads 50.8, without both 23.7).  Here the unit of work is (tile, input quad): ONE quad's halo in LDS
+// (19 KB) and in the prefetch registers (20 VGPRs), the 4 x 4 accumulators carried over the KQ units of a tile, the next unit's loads in
+// flight during this unit's MFMAs -- the resources of the KQ = 1 kernel, four workgroups per CU.  Same products in the same order (k outer,
+// then ky, kx, channel): bit-identical to conv3x3_narrow_kernel<KQ, NE_PLAIN>.
+template <int KQ>
+__global__ __launch_bounds__(256, CRFP_NARROW_OCC1) void conv3x3_narrow_seq_kernel(const NarrowArgs a) {
+    __shared__ float4 tile[NLH][NLW];
+    __shared__ float4 wl[9 * KQ * 4];   // [tap][kq][cout] -> float4 over cin comp (lane reads row cout = lane & 3)
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    if (tid < 9 * KQ * 4) {
+        const float4 wv = reinterpret_cast<const float4*>(a.wpk)[tid];
+        float* wf = reinterpret_cast<float*>(wl) + (tid >> 2) * 16 + (tid & 3);
+        wf[0] = wv.x; wf[4] = wv.y; wf[8] = wv.z; wf[12] = wv.w;
+    }
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + NTW - 1) / NTW, ntiles = tiles_x * ((H + NTH - 1) / NTH);
+    const char* qbase[KQ];
+    int qpitch[KQ];
+    bool qflow[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        int kql = k, s = 0;
+        while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
+        const ConvSrc src = a.src[s];
+        qflow[k] = src.kind == SRC_FLOW2;
+        qpitch[k] = W + src.pad;
+        qbase[k] = qflow[k] ? reinterpret_cast<const char*>(src.p + (long long)n * src.bstride)
+                            : reinterpret_cast<const char*>(src.p + (long long)n * src.bstride + (long long)kql * (H + src.pad) * qpitch[k] * 4);
+    }
+    const float4 bias = *reinterpret_cast<const float4*>(a.bpk);
+    const int cout = a.cout, act = a.act;
+    const float slope = act == CRFP_ACT_RELU ? 0.0f : (act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const float post = a.post_scale;
+    float* const dsta = a.dst + (long long)n * a.dst_bstride;
+    const int dpitch = W + a.dst_pad;
+    const float* const resid = a.resid ? a.resid + (long long)n * a.resid_bstride : nullptr;
+
+    f32x4 r[NST];
+    bool okr[NST];
+    // the halo of quad K_ of tile T: every load issued unconditionally at clamped coordinates (see conv3x3_narrow_kernel)
+#define CRFP_SEQ_LOAD(T, K_)                                                                              \
+    {                                                                                                     \
+        const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * NTW, y0_ = ty_ * NTH;                \
+        const char* qb_ = qbase[0]; int qp_ = qpitch[0]; bool qf_ = qflow[0];                             \
+        _Pragma("unroll") for (int kk = 1; kk < KQ; ++kk)                                                 \
+            if ((K_) == kk) { qb_ = qbase[kk]; qp_ = qpitch[kk]; qf_ = qflow[kk]; }                       \
+        _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                                 \
+            const int idx = min(tid + 256 * t, NLH * NLW - 1);                                            \
+            const int rr = idx / NLW, c = idx - rr * NLW;                                                 \
+            const int gy = y0_ + rr - 1, gx = x0_ + c - 1;                                                \
+            okr[t] = tid + 256 * t < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W;                 \
+            const int cgy = min(max(gy, 0), H - 1), cgx = min(max(gx, 0), W - 1);                         \
+            if (qf_) r[t] = raw_flow(qb_ + ((long long)cgy * W + cgx) * 8);                               \
+            else r[t] = *reinterpret_cast<const f32x4*>(qb_ + ((long long)cgy * qp_ + cgx) * 16);         \
+        }                                                                                                 \
+    }
+    const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+    const int band0 = xcd * xq + min(xcd, xr), band1 = band0 + xq + (xcd < xr ? 1 : 0);
+    const int t_step = ((int)gridDim.x - xcd + 7) >> 3;   // workgroups on this XCD
+    int t_cur = band0 + (blockIdx.x >> 3), k_cur = 0;
+    if (t_cur >= band1) return;
+    CRFP_SEQ_LOAD(t_cur, 0)
+    f32x4 acc[4];
+    for (;;) {
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            const int idx = tid + 256 * t;
+            if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[0][0])[idx] = okr[t] ? r[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        __syncthreads();
+        // the next unit: the next quad of this tile, or quad 0 of the workgroup's next tile
+        const bool last_k = k_cur == KQ - 1;
+        const int t_next = last_k ? t_cur + t_step : t_cur, k_next = last_k ? 0 : k_cur + 1;
+        if (t_next < band1) CRFP_SEQ_LOAD(t_next, k_next)     // flies during the MFMAs (and stores) below
+        if (k_cur == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = f32x4{bias.x, bias.y, bias.z, bias.w};
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 wv = wl[((ky * 3 + kx) * KQ + k_cur) * 4 + (tx & 3)];
+                f32x4 u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = reinterpret_cast<const f32x4&>(tile[4 * ty + ky + i][tx + kx]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, u[i].x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, u[i].y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, u[i].z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, u[i].w, acc[i], 0, 0, 0);
+            }
+        }
+        if (last_k) {
+            const int tyi = t_cur / tiles_x, x = (t_cur - tyi * tiles_x) * NTW + tx, y0 = tyi * NTH;
+            if (x < W) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int y = y0 + 4 * ty + i;
+                    if (y >= H) break;
+                    float v[4];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) v[o] = o < cout ? fmaxf(acc[i][o], slope * acc[i][o]) * post : 0.0f;
+                    if (resid) {
+                        const cf32x4 rv = ldq(resid + ((long long)y * W + x) * 4);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    stq(dsta + ((long long)y * dpitch + x) * 4, cf32x4{v[0], v[1], v[2], v[3]});
+                }
+            }
+        }
+        if (t_next >= band1) break;
+        t_cur = t_next; k_cur = k_next;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier (see conv3x3_narrow_kernel)
+    }
+#undef CRFP_SEQ_LOAD
+}
+#endif
+
 // ---------------------------------------------------------------- two stencils in one pass (A -> B)
 // conv A (KQA input quads -> 4 channels, activation) feeding conv B (that quad -> 4 channels, NE_PLAIN with optional residual
 // or the dcn_3 offset/mask epilogue) without the round trip of A's output through HBM: at 8x resolution every tensor is
@@ -544,6 +684,9 @@ __global__ __launch_bounds__(256, KQA == 1 ? 3 : 2) void conv3x3_narrow_pair_ker
     const int dpitch = W + b.dst_pad;
     const act_t* const resid = b.resid ? as_act(b.resid) + (long long)n * b.resid_bstride : nullptr;
     const float* const flowp = EPIB == NE_OFFMASK3 ? b.flow + (long long)n * b.flow_bstride : nullptr;
+    act_t* const dst2 = EPIB == NE_PLAIN && b.dst2 ? as_act(b.dst2) + (long long)n * b.dst2_bstride : nullptr;
+    unsigned* const ovfw = dst2 ? ovf_word(b.ovf, b.ovf_div, b.ovf_add, n) : nullptr;
+    float vmax = 0.0f;
 
 #ifdef CRFP_ACT_BF16
     typedef cu32x2 rawq_t;
@@ -676,6 +819,7 @@ __global__ __launch_bounds__(256, KQA == 1 ? 3 : 2) void conv3x3_narrow_pair_ker
                         v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                     }
                     stq(dsta + dpix * 4, cf32x4{v[0], v[1], v[2], v[3]});
+                    if (dst2) narrow_store_state(dst2, (long long)y * (W + 1) + x, cf32x4{v[0], v[1], v[2], v[3]}, vmax);
                 } else {   // NE_OFFMASK3
                     const float2 f = *reinterpret_cast<const float2*>(flowp + pix * 2);
                     *reinterpret_cast<float4*>(dst + dpix * 4) =
@@ -683,6 +827,7 @@ __global__ __launch_bounds__(256, KQA == 1 ? 3 : 2) void conv3x3_narrow_pair_ker
                 }
             }
         }
+        if (ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
         if (t_next >= band1) break;
         t_cur = t_next;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -700,7 +845,7 @@ int launch_narrow_pair(const NarrowArgs& a, const NarrowArgs& b, const char* nam
     double in_ch = 0;
     for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].nch;
     const double px = (double)a.N * a.H * a.W;
-    const double outb = b.epi == NE_OFFMASK3 ? (3 + 2) * 4.0 : (b.cout + (b.resid ? 4 : 0)) * (double)sizeof(act_t);
+    const double outb = b.epi == NE_OFFMASK3 ? (3 + 2) * 4.0 : (b.cout + (b.resid ? 4 : 0) + (b.dst2 ? 4 : 0)) * (double)sizeof(act_t);
     ProfScope prof(name, s, px * (in_ch * (double)sizeof(act_t) + outb), 2.0 * px * 9.0 * (in_ch * a.cout + 4.0 * b.cout));
     const int ntl = ((a.W + NTW - 1) / NTW) * ((a.H + NTH - 1) / NTH);
     const int per_cu = a.kq == 1 ? 3 : 2;
@@ -775,6 +920,7 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     if (a.epi == NE_LAST) extra = 3;                 // base quad (3 used)
     if (a.epi == NE_OFFMASK3) extra = 2;             // flow
     if (a.resid) extra += 4;
+    if (a.dst2) extra += 4;
     // mask-gated launches touch a data-dependent share of the map: they are booked with no algorithmic bytes / flops (their time still counts)
     const double bytes = a.gate ? 0.0 : px * (in_ch + (a.epi == NE_OFFMASK3 ? 3 : a.cout) + extra) * (double)sizeof(act_t);
     ProfScope prof(name, s, bytes, a.gate ? 0.0 : 2.0 * px * in_ch * a.cout * 9.0);
@@ -806,6 +952,20 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? CRFP_NARROW_OCC1 : (a.kq == 2 ? CRFP_NARROW_OCC2 : CRFP_NARROW_OCC3));
     const int share = (ntl + 256 * per_cu - 1) / (256 * per_cu);
     dim3 grid((ntl + share - 1) / share, 1, a.N);
+#ifndef CRFP_ACT_BF16
+    // Round 6: the multi-quad plain stencils (dcn_3.dcn_block.0, dcn_3.conv_fuse, forward_resblocks_3.main.0) in the quad-sequential form
+#ifndef CRFP_NARROW_SEQ
+#define CRFP_NARROW_SEQ 1
+#endif
+    if (CRFP_NARROW_SEQ && !a.gate && !a.dst2 && a.epi == NE_PLAIN && a.kq >= 2 && a.act != CRFP_ACT_TANH && a.act != CRFP_ACT_SIGMOID) {
+        const int share4 = (ntl + 256 * CRFP_NARROW_OCC1 - 1) / (256 * CRFP_NARROW_OCC1);
+        dim3 grid4((ntl + share4 - 1) / share4, 1, a.N);
+        if (a.kq == 2) conv3x3_narrow_seq_kernel<2><<<grid4, 256, 0, s>>>(a);
+        else conv3x3_narrow_seq_kernel<3><<<grid4, 256, 0, s>>>(a);
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
+#endif
     if (a.gate) {   // mask-gated forms (engine.hip: encoder_hr and the fovea blend)
         if (a.epi == NE_PLAIN && a.kq == 1) conv3x3_narrow_kernel<1, NE_PLAIN, true><<<grid, 256, 0, s>>>(a);
         else if (a.epi == NE_PLAIN && a.kq == 2) conv3x3_narrow_kernel<2, NE_PLAIN, true><<<grid, 256, 0, s>>>(a);

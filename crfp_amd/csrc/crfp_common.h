@@ -279,6 +279,11 @@ struct NarrowArgs {
     const uint8_t* gate;    // mask gate (launch_mask_gate): 4 flag bytes per 64 x 16 tile of the map, null = dense launch
     long long gate_bstride; // bytes between batch items
     int gate_h;             // which flag this launch reads: "a mask pixel within gate_h tiles of the tile" (0 .. 3)
+    // NE_PLAIN, round 6: optional second destination -- P4 planes ((H+1) x (W+1)) that receive lrelu_0.1 of what dst receives, under the range
+    // guard `ovf`.  The new recurrent state wherever the fovea mask is clear (model/CRFP.py:1674-1675 with mk = 0), written by the epilogue of
+    // forward_resblocks_3's last conv instead of by a separate streaming pass over the 8x map (launch_lrelu_q4_to_p4).
+    float* dst2;
+    long long dst2_bstride;
 };
 
 // Activations of the offset/mask heads (DCN modules, model/CRFP.py:338-340): hardware exp2/rcp, ~1 ulp each.

@@ -667,7 +667,7 @@ struct Runner {
     struct NB { const float* p = nullptr; long long bs = 0; NB() {} NB(const float* p_, long long bs_) : p(p_), bs(bs_) {} };
     // gate_par >= 0: the mask-gated form over buffer set gate_par's flags, reading the "within gate_h pixels" byte
     void narrow(int id, int H, int W, std::vector<NB> srcs, NB dst, NB resid = NB(), NB flow = NB(), const uint8_t* mask = nullptr,
-                long long mask_bs = 0, int src0_pad = 0, int dst_pad = 0, NB base_lr = NB(), int gate_par = -1, int gate_h = 0) {
+                long long mask_bs = 0, int src0_pad = 0, int dst_pad = 0, NB base_lr = NB(), int gate_par = -1, int gate_h = 0, NB dst2 = NB()) {
         if (rc) return;
         const Item& it = M.items[id];
         NarrowArgs a = it.nw;
@@ -683,11 +683,12 @@ struct Runner {
         a.wpk = packed + it.off_w;
         a.bpk = packed + it.off_b;
         a.ovf = ovf(); a.ovf_div = ovf_div; a.ovf_add = ovf_add;
+        a.dst2 = const_cast<float*>(dst2.p); a.dst2_bstride = dst2.bs;
         if (gate_par >= 0 && mask_gate_enabled()) { a.gate = gate_ptr(gate_par); a.gate_bstride = L.gate_b; a.gate_h = gate_h; }
         rc = launch_narrow(a, it.name, s);
     }
     // two stencils in one pass: item idA (its output has no other reader) feeding item idB (conv_narrow.hip, launch_narrow_pair)
-    void narrow_pair(int idA, int idB, const char* name, int H, int W, std::vector<NB> srcsA, NB dst, NB residB = NB(), NB flowB = NB()) {
+    void narrow_pair(int idA, int idB, const char* name, int H, int W, std::vector<NB> srcsA, NB dst, NB residB = NB(), NB flowB = NB(), NB dst2B = NB()) {
         if (rc) return;
         NarrowArgs a = M.items[idA].nw, b = M.items[idB].nw;
         for (size_t i = 0; i < srcsA.size(); ++i) { a.src[i].p = srcsA[i].p; a.src[i].bstride = srcsA[i].bs; a.src[i].pad = 0; }
@@ -698,6 +699,8 @@ struct Runner {
         b.resid = residB.p; b.resid_bstride = residB.bs;
         b.flow = flowB.p; b.flow_bstride = flowB.bs;
         b.dst_pad = 0;
+        b.dst2 = const_cast<float*>(dst2B.p); b.dst2_bstride = dst2B.bs;
+        b.ovf = ovf(); b.ovf_div = ovf_div; b.ovf_add = ovf_add;
         rc = launch_narrow_pair(a, b, name, s);
     }
     // which 8x-resolution conv pairs run fused (bit 0: encoder_hr.0->.2, 1: dcn_3 conv_fuse->offset/mask, 2: res3 conv1->conv2,
@@ -708,6 +711,10 @@ struct Runner {
     // narrow conv pairs fused into one launch: res3.conv1 -> conv2(+x) wins in the fp32 build; in the bf16 build the
     // single convs run on the bf16 MFMA and two of them beat the pair kernel (41 vs 47.5 us)
     static constexpr int pair_mask() { return kActBf16 ? 0 : 4; }
+#ifndef CRFP_STATE_FROM_EPILOGUE
+#define CRFP_STATE_FROM_EPILOGUE 1   // A/B builds: 0 = the separate lrelu pass
+#endif
+    static constexpr bool state_from_epilogue() { return CRFP_STATE_FROM_EPILOGUE != 0; }
 #define RUN(expr) do { if (!rc) rc = (expr); } while (0)
 
     // The fovea blend is a select under the mask (model/CRFP.py:1543-1544,1674-1675): what is computed only to be deselected -- the x8
@@ -1034,14 +1041,16 @@ struct Runner {
             mfma(IT_UPP, B, H2, W2, {{prop, bs6}}, {{F(L.up), L.up.bs, 0, 1}}, H8, W8);
             narrow(IT_R3_0F, H8, W8, {nb(L.up)}, nb(L.z0));
         }
+        // gated: the state is lrelu(feat) wherever the mask is clear -- written by the epilogue of forward_resblocks_3's last conv (round 6: its second
+        // destination; it was a separate streaming pass over the 8x map, 21 us per frame) -- and the blend kernel rewrites the tiles with mask pixels
+        const NB st2 = mask_gate_enabled() && state_from_epilogue() ? nb(L.state_hr) : NB();
         if (pair_mask() & 4)
-            narrow_pair(IT_R3_1, IT_R3_2, "conv_narrow_pair:res3.conv1_conv2_add", H8, W8, {nb(L.z0)}, nb(L.feat), nb(L.z0));
+            narrow_pair(IT_R3_1, IT_R3_2, "conv_narrow_pair:res3.conv1_conv2_add", H8, W8, {nb(L.z0)}, nb(L.feat), nb(L.z0), NB(), st2);
         else {
             narrow(IT_R3_1, H8, W8, {nb(L.z0)}, nb(L.z1));
-            narrow(IT_R3_2, H8, W8, {nb(L.z1)}, nb(L.feat), nb(L.z0));
+            narrow(IT_R3_2, H8, W8, {nb(L.z1)}, nb(L.feat), nb(L.z0), NB(), nullptr, 0, 0, 0, NB(), -1, 0, st2);
         }
-        // gated: the state is lrelu(feat) wherever the mask is clear -- one streaming pass -- and the blend kernel rewrites the tiles with mask pixels
-        if (mask_gate_enabled()) RUN(launch_lrelu_q4_to_p4(F(L.feat), L.feat.bs, F(L.state_hr), L.state_hr.bs, B, H8, W8, ovf(), ovf_div, s));
+        if (mask_gate_enabled() && !st2.p) RUN(launch_lrelu_q4_to_p4(F(L.feat), L.feat.bs, F(L.state_hr), L.state_hr.bs, B, H8, W8, ovf(), ovf_div, s));
         narrow(IT_TTTF, H8, W8, {nb(L.feat), nb(L.x_hr[par])}, nb(L.state_hr), NB(), NB(), io.mk, io.mk_b, 0, 1, NB(), par, 0);
         // output head: conv_last(state) + x8 bilinear LR;
         // the x8 bilinear base is recomputed from the LR frame in both builds (fp32: 39.0 vs 41.3 us against reading the quad hr_prep
