@@ -502,6 +502,9 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_direct_kernel(const Narrow
 #endif
 
 #ifndef CRFP_ACT_BF16
+#ifndef CRFP_SEQ_FAST
+#define CRFP_SEQ_FAST 1   // A/B builds: 0 = the general loader / epilogue for every tile (quad-sequential and chain kernels)
+#endif
 // ---------------------------------------------------------------- quad-sequential form of the multi-quad stencils (round 6, fp32 build)
 // conv3x3_narrow_kernel stages ALL KQ input quads of a tile at once: 57 KB of LDS and 149 VGPRs for KQ = 3 = two workgroups per CU, whose
 // load / MFMA / store phases then add up instead of overlapping (destructive probes, profiles/r06_narrow_probes.txt: dcn3.block0 67.0 us,
@@ -542,24 +545,54 @@ __global__ __launch_bounds__(256, CRFP_NARROW_OCC1) void conv3x3_narrow_seq_kern
     float* const dsta = a.dst + (long long)n * a.dst_bstride;
     const int dpitch = W + a.dst_pad;
     const float* const resid = a.resid ? a.resid + (long long)n * a.resid_bstride : nullptr;
+    const bool plain_out = CRFP_SEQ_FAST && cout == 4 && post == 1.0f;   // (uniform) nothing to mask or scale in the epilogue
 
     f32x4 r[NST];
     bool okr[NST];
-    // the halo of quad K_ of tile T: every load issued unconditionally at clamped coordinates (see conv3x3_narrow_kernel)
+    bool r_in = false;   // (uniform) the halo held in r[] lies inside the image as a whole: it goes to LDS without the zero-padding selects
+    // this thread's halo elements as byte offsets from the halo's first pixel in a Q4 plane of pitch W -- the same for every tile
+    unsigned hoff[NST];
+    bool pitch_w = CRFP_SEQ_FAST != 0;   // (uniform) every source plane has pitch W (no padded source): the fast path's precondition
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) pitch_w = pitch_w && qpitch[k] == W;
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+        const int idx = min(tid + 256 * t, NLH * NLW - 1), rr = idx / NLW;
+        hoff[t] = (unsigned)(rr * W + (idx - rr * NLW)) * 16u;
+    }
+    // The halo of quad K_ of tile T.  The stencils are bound by instruction issue as much as by HBM (the 4x4x1 MFMAs of a quad are 1 152
+    // issue cycles per wave; the index arithmetic of the general loader was about as many), so tiles whose halo lies inside the image (93 % of a
+    // 1440 x 2560 map) take a fast path: a scalar tile base + one 32-bit multiply-add per element, no clamps, no validity flags.  General path:
+    // every load issued unconditionally at clamped coordinates (see conv3x3_narrow_kernel).
 #define CRFP_SEQ_LOAD(T, K_)                                                                              \
     {                                                                                                     \
         const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * NTW, y0_ = ty_ * NTH;                \
         const char* qb_ = qbase[0]; int qp_ = qpitch[0]; bool qf_ = qflow[0];                             \
         _Pragma("unroll") for (int kk = 1; kk < KQ; ++kk)                                                 \
             if ((K_) == kk) { qb_ = qbase[kk]; qp_ = qpitch[kk]; qf_ = qflow[kk]; }                       \
-        _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                                 \
-            const int idx = min(tid + 256 * t, NLH * NLW - 1);                                            \
-            const int rr = idx / NLW, c = idx - rr * NLW;                                                 \
-            const int gy = y0_ + rr - 1, gx = x0_ + c - 1;                                                \
-            okr[t] = tid + 256 * t < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W;                 \
-            const int cgy = min(max(gy, 0), H - 1), cgx = min(max(gx, 0), W - 1);                         \
-            if (qf_) r[t] = raw_flow(qb_ + ((long long)cgy * W + cgx) * 8);                               \
-            else r[t] = *reinterpret_cast<const f32x4*>(qb_ + ((long long)cgy * qp_ + cgx) * 16);         \
+        r_in = pitch_w && x0_ >= 1 && y0_ >= 1 && x0_ + NLW - 1 <= W && y0_ + NLH - 1 <= H;               \
+        if (r_in) {   /* raw buffer loads: scalar tile offset + the thread's 32-bit element offset, no 64-bit address arithmetic */ \
+            const int so_ = ((y0_ - 1) * W + (x0_ - 1)) * 16;                                             \
+            if (qf_) {                                                                                    \
+                const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qb_), 0, H * W * 8, 0x00020000); \
+                _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                         \
+                    const cf32x2 f_ = __builtin_bit_cast(cf32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)(hoff[t] >> 1), so_ >> 1, 0)); \
+                    r[t] = f32x4{f_.x, f_.y, 0.0f, 0.0f};                                                 \
+                }                                                                                         \
+            } else {                                                                                      \
+                const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qb_), 0, H * W * 16, 0x00020000); \
+                _Pragma("unroll") for (int t = 0; t < NST; ++t)                                           \
+                    r[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)hoff[t], so_, 0)); \
+            }                                                                                             \
+        } else {                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                             \
+                const int idx_ = min(tid + 256 * t, NLH * NLW - 1), hr_ = idx_ / NLW, hc_ = idx_ - hr_ * NLW; \
+                const int gy = y0_ + hr_ - 1, gx = x0_ + hc_ - 1;                                         \
+                okr[t] = tid + 256 * t < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W;             \
+                const int cgy = min(max(gy, 0), H - 1), cgx = min(max(gx, 0), W - 1);                     \
+                if (qf_) r[t] = raw_flow(qb_ + ((long long)cgy * W + cgx) * 8);                           \
+                else r[t] = *reinterpret_cast<const f32x4*>(qb_ + ((long long)cgy * qp_ + cgx) * 16);     \
+            }                                                                                             \
         }                                                                                                 \
     }
     const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
@@ -570,10 +603,16 @@ __global__ __launch_bounds__(256, CRFP_NARROW_OCC1) void conv3x3_narrow_seq_kern
     CRFP_SEQ_LOAD(t_cur, 0)
     f32x4 acc[4];
     for (;;) {
+        if (r_in) {
 #pragma unroll
-        for (int t = 0; t < NST; ++t) {
-            const int idx = tid + 256 * t;
-            if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[0][0])[idx] = okr[t] ? r[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int t = 0; t < NST; ++t)
+                if (256 * t + 255 < NLH * NLW || tid + 256 * t < NLH * NLW) reinterpret_cast<f32x4*>(&tile[0][0])[tid + 256 * t] = r[t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < NST; ++t) {
+                const int idx = tid + 256 * t;
+                if (idx < NLH * NLW) reinterpret_cast<f32x4*>(&tile[0][0])[idx] = okr[t] ? r[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
         }
         __syncthreads();
         // the next unit: the next quad of this tile, or quad 0 of the workgroup's next tile
@@ -603,8 +642,22 @@ __global__ __launch_bounds__(256, CRFP_NARROW_OCC1) void conv3x3_narrow_seq_kern
             }
         }
         if (last_k) {
-            const int tyi = t_cur / tiles_x, x = (t_cur - tyi * tiles_x) * NTW + tx, y0 = tyi * NTH;
-            if (x < W) {
+            const int tyi = t_cur / tiles_x, x0 = (t_cur - tyi * tiles_x) * NTW, x = x0 + tx, y0 = tyi * NTH;
+            if (plain_out && x0 + NTW <= W && y0 + NTH <= H) {   // (uniform) a whole tile, four couts, no scale: 32-bit offsets from the tile's base
+                float* const dt = dsta + ((long long)y0 * dpitch + x0) * 4;
+                const float* const rt_ = resid ? resid + ((long long)y0 * W + x0) * 4 : nullptr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cf32x4 v;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) v[o] = fmaxf(acc[i][o], slope * acc[i][o]);
+                    if (rt_) {
+                        const cf32x4 rv = ldq(rt_ + (unsigned)((4 * ty + i) * W + tx) * 4u);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    stq(dt + (unsigned)((4 * ty + i) * dpitch + tx) * 4u, v);
+                }
+            } else if (x < W) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int y = y0 + 4 * ty + i;
@@ -835,6 +888,296 @@ __global__ __launch_bounds__(256, KQA == 1 ? 3 : 2) void conv3x3_narrow_pair_ker
 #undef CRFP_PAIR_LOAD
 }
 
+#ifndef CRFP_ACT_BF16
+// ---------------------------------------------------------------- three stencils in one pass (A -> B -> C), round 6, fp32 build
+// The 8x-resolution chains of the reference run conv after conv on 59 MB tensors (fp32 @A) that have exactly one reader:
+//   dcn_3:  dcn_block.0 (up, warped state, flow -> 4) -> dcn_block.2 (4 -> 4) -> conv_fuse (cat(., pre-offset) -> 4)      model/CRFP.py:303-308,333-336
+//   forward_resblocks_3:  main.0 (cat(up, aligned) -> 4) -> conv1 (4 -> 4, ReLU) -> conv2 (4 -> 4) + x                     model/CRFP.py:1626-1630
+// As three launches each chain writes and re-reads two such tensors (236 MB of the 501 MB / 354 MB the chain moves).  Here a workgroup
+// produces a 16 x 60 tile of C's output from the (16+6) x (60+6) halo of A's inputs: A is evaluated on the 20 x 64 region B needs -- lane =
+// column, wave w = rows 5 w .. 5 w + 4, so a lane's five vertically adjacent pixels share their halo rows as in the single-conv kernel
+// (conv3x3_narrow_pair_kernel's flat pixel map cost twice the LDS reads) -- its activated output goes to an LDS tile, ZERO where the pixel
+// lies outside the image (B's zero padding pads A's OUTPUT); B likewise on 18 x 62 into a second tile; C on 16 x 60 from that tile (and, for
+// conv_fuse, from one more global quad).  Global quads pass through LDS one at a time (the quad-sequential form above): 47 KB of LDS and
+// ~110 VGPRs = three workgroups per CU.  RES: C adds A's output of the same pixel (the residual block's x, still in A's tile) and may write
+// the second destination (NarrowArgs::dst2).  Each conv accumulates bias, then k-outer / ky / kx / channel as its single kernel does:
+// bit-identical to the three launches.  Cost: A runs on 1.33x and B on 1.16x the pixels.
+constexpr int KCW = 60, KCH = 16;                   // C's output tile
+constexpr int KAW = KCW + 4, KAH = KCH + 4;         // A's region (64 x 20)
+constexpr int KBW = KCW + 2, KBH = KCH + 2;         // B's region (62 x 18)
+constexpr int KIW = KCW + 6, KIH = KCH + 6;         // halo of A's inputs (66 x 22)
+constexpr int KST = (KIH * KIW + 255) / 256;        // 6 halo elements per thread and quad
+
+template <int KQA, int KQG, bool RES>   // KQA: A's input quads (global); KQG: global quads of C behind its LDS quad (0 / 1)
+__global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const NarrowArgs a, const NarrowArgs b, const NarrowArgs c) {
+    __shared__ float4 buf0[KIH][KIW];   // one global quad of A (22 x 66); later B's output (rows < 18, columns < 62)
+    __shared__ float4 t1[KAH][KAW];     // A's output (20 x 64); KQG: later C's global quad (rows < 18, columns < 62)
+    __shared__ float4 wlA[9 * KQA * 4], wlB[9 * 4], wlC[9 * (1 + KQG) * 4];   // [tap][kq][cout] -> float4 over cin comp
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define CRFP_CHAIN_W(WL, ARGS, NQ)                                                                        \
+    if (tid < 9 * (NQ) * 4) {                                                                             \
+        const float4 wv = reinterpret_cast<const float4*>((ARGS).wpk)[tid];                               \
+        float* wf = reinterpret_cast<float*>(WL) + (tid >> 2) * 16 + (tid & 3);                           \
+        wf[0] = wv.x; wf[4] = wv.y; wf[8] = wv.z; wf[12] = wv.w;                                          \
+    }
+    CRFP_CHAIN_W(wlA, a, KQA) CRFP_CHAIN_W(wlB, b, 1) CRFP_CHAIN_W(wlC, c, 1 + KQG)
+#undef CRFP_CHAIN_W
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + KCW - 1) / KCW, ntiles = tiles_x * ((H + KCH - 1) / KCH);
+    // global quads: A's KQA, then C's (its quad 1)
+    const char* qbase[KQA + KQG];
+    int qpitch[KQA + KQG];
+    bool qflow[KQA + KQG];
+#pragma unroll
+    for (int k = 0; k < KQA + KQG; ++k) {
+        const NarrowArgs& g = k < KQA ? a : c;
+        int kql = k < KQA ? k : 1, s = 0;
+        while (s < g.nsrc - 1 && kql >= g.src[s].nq) { kql -= g.src[s].nq; ++s; }
+        const ConvSrc src = g.src[s];
+        qflow[k] = src.kind == SRC_FLOW2;
+        qpitch[k] = W + src.pad;
+        qbase[k] = qflow[k] ? reinterpret_cast<const char*>(src.p + (long long)n * src.bstride)
+                            : reinterpret_cast<const char*>(src.p + (long long)n * src.bstride + (long long)kql * (H + src.pad) * qpitch[k] * 4);
+    }
+    const float4 biasA = *reinterpret_cast<const float4*>(a.bpk), biasB = *reinterpret_cast<const float4*>(b.bpk),
+                 biasC = *reinterpret_cast<const float4*>(c.bpk);
+    const float slopeA = a.act == CRFP_ACT_RELU ? 0.0f : (a.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const float slopeB = b.act == CRFP_ACT_RELU ? 0.0f : (b.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const float slopeC = c.act == CRFP_ACT_RELU ? 0.0f : (c.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    float* const dst = c.dst + (long long)n * c.dst_bstride;
+    const int dpitch = W + c.dst_pad;
+    float* const dst2 = c.dst2 ? c.dst2 + (long long)n * c.dst2_bstride : nullptr;
+    unsigned* const ovfw = dst2 ? ovf_word(c.ovf, c.ovf_div, c.ovf_add, n) : nullptr;
+    float vmax = 0.0f;
+
+    f32x4 r[KST];
+    bool okr[KST];
+    bool r_in = false;   // (uniform) the region held in r[] lies inside the image as a whole (see conv3x3_narrow_seq_kernel's fast path)
+    // this thread's elements of A's input halo as byte offsets from the halo's first pixel in a Q4 plane of pitch W
+    unsigned hoff[KST];
+    bool pitch_w = CRFP_SEQ_FAST != 0;
+#pragma unroll
+    for (int k = 0; k < KQA; ++k) pitch_w = pitch_w && qpitch[k] == W;
+#pragma unroll
+    for (int t = 0; t < KST; ++t) {
+        const int idx = min(tid + 256 * t, KIH * KIW - 1), rr = idx / KIW;
+        hoff[t] = (unsigned)(rr * W + (idx - rr * KIW)) * 16u;
+    }
+    const bool plain_out = CRFP_SEQ_FAST && c.cout == 4 && c.post_scale == 1.0f;
+    // global quad Q_ over the RW x RH region whose top-left pixel is (x0 - OFF, y0 - OFF) of tile T.  A's quads (OFF == 3) of a tile whose halo
+    // lies inside the image: raw buffer loads at scalar tile offset + hoff[]; otherwise unconditional loads at clamped coordinates
+#define CRFP_CHAIN_LOAD(T, Q_, RW, RH, OFF)                                                               \
+    {                                                                                                     \
+        const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * KCW, y0_ = ty_ * KCH;                \
+        const char* qb_ = qbase[Q_]; const int qp_ = qpitch[Q_];                                          \
+        r_in = (OFF) == 3 && pitch_w && x0_ >= 3 && y0_ >= 3 && x0_ - 3 + KIW <= W && y0_ - 3 + KIH <= H; \
+        if (r_in) {                                                                                       \
+            const int so_ = ((y0_ - 3) * W + (x0_ - 3)) * 16;                                             \
+            if (qflow[Q_]) {                                                                              \
+                const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qb_), 0, H * W * 8, 0x00020000); \
+                _Pragma("unroll") for (int t = 0; t < KST; ++t) {                                         \
+                    const cf32x2 f_ = __builtin_bit_cast(cf32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)(hoff[t] >> 1), so_ >> 1, 0)); \
+                    r[t] = f32x4{f_.x, f_.y, 0.0f, 0.0f};                                                 \
+                }                                                                                         \
+            } else {                                                                                      \
+                const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qb_), 0, H * W * 16, 0x00020000); \
+                _Pragma("unroll") for (int t = 0; t < KST; ++t)                                           \
+                    r[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)hoff[t], so_, 0)); \
+            }                                                                                             \
+        } else                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < KST; ++t) {                                                 \
+            const int idx = min(tid + 256 * t, (RW) * (RH) - 1);                                          \
+            const int rr = idx / (RW), cc = idx - rr * (RW);                                              \
+            const int gy = y0_ + rr - (OFF), gx = x0_ + cc - (OFF);                                       \
+            okr[t] = tid + 256 * t < (RW) * (RH) && gy >= 0 && gy < H && gx >= 0 && gx < W;               \
+            const int cgy = min(max(gy, 0), H - 1), cgx = min(max(gx, 0), W - 1);                         \
+            if (qflow[Q_]) r[t] = raw_flow(qb_ + ((long long)cgy * W + cgx) * 8);                         \
+            else r[t] = *reinterpret_cast<const f32x4*>(qb_ + ((long long)cgy * qp_ + cgx) * 16);         \
+        }                                                                                                 \
+    }
+#define CRFP_CHAIN_SYNC asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier (see conv3x3_narrow_kernel)
+    // NR rows x 9 taps of one input quad out of LDS tile SRC (any row pitch) into acc[0 .. NR - 1]: rows R0 + i, column C0 of the stage's region
+#define CRFP_CHAIN_MFMA(SRC, WL, KQT, K_, NR, R0, C0)                                                     \
+    _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                                    \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                \
+            const float4 wv = (WL)[((ky * 3 + kx) * (KQT) + (K_)) * 4 + (lane & 3)];                      \
+            f32x4 u[NR];                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < (NR); ++i) u[i] = reinterpret_cast<const f32x4&>((SRC)[(R0) + i + ky][(C0) + kx]); \
+            _Pragma("unroll") for (int i = 0; i < (NR); ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, u[i].x, acc[i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < (NR); ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, u[i].y, acc[i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < (NR); ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, u[i].z, acc[i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < (NR); ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, u[i].w, acc[i], 0, 0, 0); \
+        }                                                                                                 \
+    }
+    const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+    const int band0 = xcd * xq + min(xcd, xr), band1 = band0 + xq + (xcd < xr ? 1 : 0);
+    const int t_step = ((int)gridDim.x - xcd + 7) >> 3;
+    int t_cur = band0 + (blockIdx.x >> 3);
+    if (t_cur >= band1) return;
+    CRFP_CHAIN_LOAD(t_cur, 0, KIW, KIH, 3)
+    // B's rows / column of this thread (18 x 62 region on the 20 x 64 thread grid: surplus threads recompute the last row / column, unwritten)
+    const int rB0 = min(5 * wave, KBH - 5), cB = min(lane, KBW - 1), cC = min(lane, KCW - 1);
+    for (;;) {
+        const int tyi = t_cur / tiles_x, x0 = (t_cur - tyi * tiles_x) * KCW, y0 = tyi * KCH;
+        const int t_next = t_cur + t_step;
+        // (uniform) A's 20 x 64 region lies inside the image: no zero padding to apply to A's and B's outputs
+        const bool reg_in = CRFP_SEQ_FAST && x0 >= 2 && y0 >= 2 && x0 - 2 + KAW <= W && y0 - 2 + KAH <= H;
+        f32x4 acc[5];
+        // ---- conv A: its global quads one after the other through buf0
+#pragma unroll
+        for (int k = 0; k < KQA; ++k) {
+            if (r_in) {
+#pragma unroll
+                for (int t = 0; t < KST; ++t)
+                    if (256 * t + 255 < KIH * KIW || tid + 256 * t < KIH * KIW) reinterpret_cast<f32x4*>(&buf0[0][0])[tid + 256 * t] = r[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < KST; ++t) {
+                    const int idx = tid + 256 * t;
+                    if (idx < KIH * KIW) reinterpret_cast<f32x4*>(&buf0[0][0])[idx] = okr[t] ? r[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+            CRFP_CHAIN_SYNC
+            // the next global quad flies during these MFMAs: A's next one, C's, or quad 0 of the workgroup's next tile
+            if (k + 1 < KQA) CRFP_CHAIN_LOAD(t_cur, k + 1, KIW, KIH, 3)
+            else if (KQG) CRFP_CHAIN_LOAD(t_cur, KQA, KBW, KBH, 1)
+            else if (t_next < band1) CRFP_CHAIN_LOAD(t_next, 0, KIW, KIH, 3)
+            if (k == 0) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[i] = f32x4{biasA.x, biasA.y, biasA.z, biasA.w};
+            }
+            CRFP_CHAIN_MFMA(buf0, wlA, KQA, k, 5, 5 * wave, lane)
+            CRFP_CHAIN_SYNC   // every wave is done reading buf0
+        }
+        // A's activated output -> t1, zero outside the image
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int gy = y0 - 2 + 5 * wave + i, gx = x0 - 2 + lane;
+            const bool in = reg_in || (gy >= 0 && gy < H && gx >= 0 && gx < W);
+            f32x4 v;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[o] = (in && o < a.cout) ? fmaxf(acc[i][o], slopeA * acc[i][o]) * a.post_scale : 0.0f;
+            reinterpret_cast<f32x4&>(t1[5 * wave + i][lane]) = v;
+        }
+        CRFP_CHAIN_SYNC
+        // ---- conv B out of t1 on the 18 x 62 region
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = f32x4{biasB.x, biasB.y, biasB.z, biasB.w};
+        CRFP_CHAIN_MFMA(t1, wlB, 1, 0, 5, rB0, cB)
+        if (KQG) CRFP_CHAIN_SYNC   // t1 is about to receive C's global quad: every wave is done reading A's output
+        if (5 * wave < KBH && lane < KBW) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int row = rB0 + i;
+                if (row < 5 * wave) continue;   // (wave 3: rows 13, 14 belong to wave 2)
+                const int gy = y0 - 1 + row, gx = x0 - 1 + lane;
+                const bool in = reg_in || (gy >= 0 && gy < H && gx >= 0 && gx < W);
+                f32x4 v;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) v[o] = (in && o < b.cout) ? fmaxf(acc[i][o], slopeB * acc[i][o]) * b.post_scale : 0.0f;
+                reinterpret_cast<f32x4&>(buf0[row][lane]) = v;
+            }
+        }
+        if (KQG) {
+#pragma unroll
+            for (int t = 0; t < KST; ++t) {
+                const int idx = tid + 256 * t, rr = idx / KBW, cc = idx - rr * KBW;
+                if (idx < KBH * KBW) reinterpret_cast<f32x4&>(t1[rr][cc]) = okr[t] ? r[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            if (t_next < band1) CRFP_CHAIN_LOAD(t_next, 0, KIW, KIH, 3)
+        }
+        CRFP_CHAIN_SYNC
+        // ---- conv C on the 16 x 60 tile: quad 0 = B's output (buf0), quad 1 = its global quad (t1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{biasC.x, biasC.y, biasC.z, biasC.w};
+        CRFP_CHAIN_MFMA(buf0, wlC, 1 + KQG, 0, 4, 4 * wave, cC)
+        if (KQG) CRFP_CHAIN_MFMA(t1, wlC, 1 + KQG, 1, 4, 4 * wave, cC)
+        const int x = x0 + lane;
+        if (plain_out && x0 + KCW <= W && y0 + KCH <= H) {   // (uniform) a whole tile, four couts, no scale: 32-bit offsets from the tile's base
+            if (lane < KCW) {
+                float* const dt = dst + ((long long)y0 * dpitch + x0) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cf32x4 v;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) v[o] = fmaxf(acc[i][o], slopeC * acc[i][o]);
+                    if (RES) {
+                        const f32x4 rv = reinterpret_cast<const f32x4&>(t1[4 * wave + i + 2][lane + 2]);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    }
+                    stq(dt + (unsigned)((4 * wave + i) * dpitch + lane) * 4u, v);
+                    if (dst2) narrow_store_state(dst2 + ((long long)y0 * (W + 1) + x0) * 4, (long long)(unsigned)((4 * wave + i) * (W + 1) + lane), v, vmax);
+                }
+            }
+        } else if (lane < KCW && x < W) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = y0 + 4 * wave + i;
+                if (y >= H) break;
+                float v[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) v[o] = o < c.cout ? fmaxf(acc[i][o], slopeC * acc[i][o]) * c.post_scale : 0.0f;
+                if (RES) {   // + A's output of this pixel (what the three-launch path re-reads from HBM as conv2's residual)
+                    const f32x4 rv = reinterpret_cast<const f32x4&>(t1[4 * wave + i + 2][lane + 2]);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
+                stq(dst + ((long long)y * dpitch + x) * 4, cf32x4{v[0], v[1], v[2], v[3]});
+                if (dst2) narrow_store_state(dst2, (long long)y * (W + 1) + x, cf32x4{v[0], v[1], v[2], v[3]}, vmax);
+            }
+        }
+        if (ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
+        if (t_next >= band1) break;
+        t_cur = t_next;
+        CRFP_CHAIN_SYNC   // buf0 and t1 are free for the next tile
+    }
+#undef CRFP_CHAIN_MFMA
+#undef CRFP_CHAIN_SYNC
+#undef CRFP_CHAIN_LOAD
+}
+
+// A -> B -> C in one launch.  C's sources: quad 0 = B's output, then (optionally) one global quad; RES: C's residual is A's output.
+int launch_narrow_chain(const NarrowArgs& a, const NarrowArgs& b, const NarrowArgs& c, bool res, const char* name, hipStream_t s) {
+    auto fast = [](const NarrowArgs& g) { return g.act != CRFP_ACT_TANH && g.act != CRFP_ACT_SIGMOID; };
+    const int kqg = c.kq - 1;
+    if (a.kq < 1 || a.kq > 3 || b.kq != 1 || kqg < 0 || kqg > 1 || (res && kqg) || a.epi != NE_PLAIN || b.epi != NE_PLAIN || c.epi != NE_PLAIN ||
+        a.resid || b.resid || c.resid || a.dst2 || b.dst2 || !fast(a) || !fast(b) || !fast(c) || a.H != b.H || a.W != b.W || a.H != c.H || a.W != c.W ||
+        (kqg && c.src[1].kind != SRC_Q4)) {
+        set_error("conv_narrow_chain %s: unsupported chain (kqA=%d kqB=%d kqC=%d res=%d)", name, a.kq, b.kq, c.kq, (int)res);
+        return CRFP_E_UNSUPPORTED;
+    }
+    double in_ch = 0;
+    for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].nch;
+    if (kqg) in_ch += c.src[1].nch;
+    const double px = (double)a.N * a.H * a.W;
+    ProfScope prof(name, s, px * (in_ch + c.cout + (c.dst2 ? 4 : 0)) * 4.0, 2.0 * px * 9.0 * (in_ch * a.cout + 4.0 * b.cout + 4.0 * c.cout));
+    const int ntl = ((a.W + KCW - 1) / KCW) * ((a.H + KCH - 1) / KCH);
+    const int share = (ntl + 256 * 3 - 1) / (256 * 3);
+    dim3 grid((ntl + share - 1) / share, 1, a.N);
+    if (res) {
+        switch (a.kq) {
+            case 1: conv3x3_narrow_chain_kernel<1, 0, true><<<grid, 256, 0, s>>>(a, b, c); break;
+            case 2: conv3x3_narrow_chain_kernel<2, 0, true><<<grid, 256, 0, s>>>(a, b, c); break;
+            default: conv3x3_narrow_chain_kernel<3, 0, true><<<grid, 256, 0, s>>>(a, b, c); break;
+        }
+    } else if (kqg) {
+        switch (a.kq) {
+            case 1: conv3x3_narrow_chain_kernel<1, 1, false><<<grid, 256, 0, s>>>(a, b, c); break;
+            case 2: conv3x3_narrow_chain_kernel<2, 1, false><<<grid, 256, 0, s>>>(a, b, c); break;
+            default: conv3x3_narrow_chain_kernel<3, 1, false><<<grid, 256, 0, s>>>(a, b, c); break;
+        }
+    } else {
+        switch (a.kq) {
+            case 1: conv3x3_narrow_chain_kernel<1, 0, false><<<grid, 256, 0, s>>>(a, b, c); break;
+            case 2: conv3x3_narrow_chain_kernel<2, 0, false><<<grid, 256, 0, s>>>(a, b, c); break;
+            default: conv3x3_narrow_chain_kernel<3, 0, false><<<grid, 256, 0, s>>>(a, b, c); break;
+        }
+    }
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+#endif
+
 int launch_narrow_pair(const NarrowArgs& a, const NarrowArgs& b, const char* name, hipStream_t s) {
     if (a.kq < 1 || a.kq > 3 || a.cout < 1 || a.cout > 4 || b.kq != 1 || b.cout < 1 || b.cout > 4 ||
         (b.epi != NE_PLAIN && b.epi != NE_OFFMASK3) || a.epi != NE_PLAIN || a.resid || a.act == CRFP_ACT_TANH ||
@@ -957,10 +1300,14 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
 #ifndef CRFP_NARROW_SEQ
 #define CRFP_NARROW_SEQ 1
 #endif
-    if (CRFP_NARROW_SEQ && !a.gate && !a.dst2 && a.epi == NE_PLAIN && a.kq >= 2 && a.act != CRFP_ACT_TANH && a.act != CRFP_ACT_SIGMOID) {
+#ifndef CRFP_NARROW_SEQ_MINKQ
+#define CRFP_NARROW_SEQ_MINKQ 1   // the one-quad plain stencils too: the form carries the interior-tile fast path (A/B builds: 2)
+#endif
+    if (CRFP_NARROW_SEQ && !a.gate && !a.dst2 && a.epi == NE_PLAIN && a.kq >= CRFP_NARROW_SEQ_MINKQ && a.act != CRFP_ACT_TANH && a.act != CRFP_ACT_SIGMOID) {
         const int share4 = (ntl + 256 * CRFP_NARROW_OCC1 - 1) / (256 * CRFP_NARROW_OCC1);
         dim3 grid4((ntl + share4 - 1) / share4, 1, a.N);
-        if (a.kq == 2) conv3x3_narrow_seq_kernel<2><<<grid4, 256, 0, s>>>(a);
+        if (a.kq == 1) conv3x3_narrow_seq_kernel<1><<<grid4, 256, 0, s>>>(a);
+        else if (a.kq == 2) conv3x3_narrow_seq_kernel<2><<<grid4, 256, 0, s>>>(a);
         else conv3x3_narrow_seq_kernel<3><<<grid4, 256, 0, s>>>(a);
         CRFP_CHECK_LAUNCH();
         return 0;

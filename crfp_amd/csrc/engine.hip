@@ -703,6 +703,31 @@ struct Runner {
         b.ovf = ovf(); b.ovf_div = ovf_div; b.ovf_add = ovf_add;
         rc = launch_narrow_pair(a, b, name, s);
     }
+    // three stencils in one pass (fp32 build; conv_narrow.hip, launch_narrow_chain): items idA -> idB -> idC, the two tensors between them never
+    // reach HBM.  gC: C's second source (its first is B's output); res: C adds A's output; dst2C: C's second destination (the new state)
+    void narrow_chain(int idA, int idB, int idC, const char* name, int H, int W, std::vector<NB> srcsA, NB gC, NB dst, bool res, NB dst2C = NB()) {
+#ifndef CRFP_ACT_BF16
+        if (rc) return;
+        NarrowArgs a = M.items[idA].nw, b = M.items[idB].nw, c = M.items[idC].nw;
+        for (size_t i = 0; i < srcsA.size(); ++i) { a.src[i].p = srcsA[i].p; a.src[i].bstride = srcsA[i].bs; a.src[i].pad = 0; }
+        if (gC.p) { c.src[1].p = gC.p; c.src[1].bstride = gC.bs; c.src[1].pad = 0; }
+        a.N = b.N = c.N = L.B; a.H = b.H = c.H = H; a.W = b.W = c.W = W;
+        a.wpk = packed + M.items[idA].off_w; a.bpk = packed + M.items[idA].off_b;
+        b.wpk = packed + M.items[idB].off_w; b.bpk = packed + M.items[idB].off_b;
+        c.wpk = packed + M.items[idC].off_w; c.bpk = packed + M.items[idC].off_b;
+        c.dst = const_cast<float*>(dst.p); c.dst_bstride = dst.bs; c.dst_pad = 0;
+        c.dst2 = const_cast<float*>(dst2C.p); c.dst2_bstride = dst2C.bs;
+        c.ovf = ovf(); c.ovf_div = ovf_div; c.ovf_add = ovf_add;
+        rc = launch_narrow_chain(a, b, c, res, name, s);
+#endif
+    }
+#ifndef CRFP_NARROW_CHAIN
+// bit 0: dcn_3's dcn_block.0 -> .2 -> conv_fuse, bit 1: forward_resblocks_3's main.0 -> conv1 -> conv2 (+ x).  Shipped: 2.  Same box, fp32 @A
+// (profiles/r06_narrow_chain_ab.txt): the residual chain 87.1 us against 41.1 + 50.8; dcn_3's chain 148.4 us against 59.5 + 28.0 + 42.2 -- its A
+// stage (three input quads on 1.33x the pixels) makes it issue-bound at three workgroups per CU, so it stays three launches.
+#define CRFP_NARROW_CHAIN 2
+#endif
+    static constexpr int chain_mask() { return kActBf16 ? 0 : CRFP_NARROW_CHAIN; }
     // which 8x-resolution conv pairs run fused (bit 0: encoder_hr.0->.2, 1: dcn_3 conv_fuse->offset/mask, 2: res3 conv1->conv2,
     // 3: dcn_3 block.0->.2).  Measured @A fp32, pair vs the two single kernels: res3 47.2 vs 57.8 us (bf16 46.7 vs 56.1);
     // encoder_hr 71.5 vs 67.6; conv_fuse->offset/mask 80 vs 76.8; dcn_3 block (3 input quads, one workgroup per CU) 126 vs 93.7.
@@ -938,6 +963,7 @@ struct Runner {
         float* prop_other = F(L.prop_b);
         float* carry = F(L.carry);
         auto nb = [&](const Ten& tn) { return NB(F(tn), tn.bs); };
+        std::vector<NB> r3_srcs;   // inputs of forward_resblocks_3.main.0
         if (!first) {
             float* flow2 = F(L.flow2[par]);
             float* flow8 = F(L.flow8[par]);
@@ -1004,6 +1030,10 @@ struct Runner {
             mfma(IT_UPP, B, H2, W2, {{prop, bs6}}, {{F(L.up), L.up.bs, 0, 1}}, H8, W8);
             mfma(IT_POFF, B, H2, W2, {{offprev, bs8}}, {{F(L.poff), L.poff.bs, 0, 1}}, H8, W8);
             const NB fl8(flow8, f8b);
+            if (chain_mask() & 1)   // dcn_block.0 -> .2 -> conv_fuse in one launch (round 6)
+                narrow_chain(IT_D3B0, IT_D3B1, IT_D3FUSE, "conv_narrow_chain:dcn3.block0_block2_fuse", H8, W8, {nb(L.up), nb(L.prevhrw), fl8}, nb(L.poff),
+                             nb(L.g2), false);
+            else {
             if (pair_mask() & 8)
                 narrow_pair(IT_D3B0, IT_D3B1, "conv_narrow_pair:dcn3.block", H8, W8, {nb(L.up), nb(L.prevhrw), fl8}, nb(L.g1));
             else {
@@ -1014,6 +1044,7 @@ struct Runner {
                 narrow_pair(IT_D3FUSE, IT_D3OM, "conv_narrow_pair:dcn3.fuse_offmask", H8, W8, {nb(L.g1), nb(L.poff)}, nb(L.om3), NB(), fl8);
             else
                 narrow(IT_D3FUSE, H8, W8, {nb(L.g1), nb(L.poff)}, nb(L.g2));
+            }
             const Item& d3 = M.items[IT_D3W];
             // dcn_3 with its offset / mask conv inside (gather.hip dcn3_kernel<true>): fp32 build 94.0 vs 73.7 + 37.3 us same-box, bit-identical;
             // the bf16 build keeps two kernels (its stand-alone conv runs on the bf16 MFMA: 84.8 vs 59.8 + 28.4 us, not worth the changed bits)
@@ -1028,9 +1059,10 @@ struct Runner {
             if (fg) {           // model/CRFP_test.py:2389
                 RUN(launch_scale_q4(F(L.up), 0, F(L.sc_up), 1, H8, W8, nullptr, fg, s));
                 RUN(launch_scale_q4(F(L.al3), 0, F(L.sc_al3), 1, H8, W8, nullptr, fg, s));
-                narrow(IT_R3_0, H8, W8, {nb(L.sc_up), nb(L.sc_al3)}, nb(L.z0));
+                r3_srcs = {nb(L.sc_up), nb(L.sc_al3)};
             } else
-                narrow(IT_R3_0, H8, W8, {nb(L.up), nb(L.al3)}, nb(L.z0));
+                r3_srcs = {nb(L.up), nb(L.al3)};
+            if (!(chain_mask() & 2)) narrow(IT_R3_0, H8, W8, r3_srcs, nb(L.z0));
         } else {
             for (int l = 0; l < 3; ++l) {
                 mfma(it_lvl(l, L_RB0F), B, H2, W2, {{prop, bs6}, {nullptr, 0}}, {{F(L.y0), bs8, 0, 8}});
@@ -1039,12 +1071,15 @@ struct Runner {
                 std::swap(prop_next, prop_other);
             }
             mfma(IT_UPP, B, H2, W2, {{prop, bs6}}, {{F(L.up), L.up.bs, 0, 1}}, H8, W8);
-            narrow(IT_R3_0F, H8, W8, {nb(L.up)}, nb(L.z0));
+            r3_srcs = {nb(L.up)};
+            if (!(chain_mask() & 2)) narrow(IT_R3_0F, H8, W8, r3_srcs, nb(L.z0));
         }
         // gated: the state is lrelu(feat) wherever the mask is clear -- written by the epilogue of forward_resblocks_3's last conv (round 6: its second
         // destination; it was a separate streaming pass over the 8x map, 21 us per frame) -- and the blend kernel rewrites the tiles with mask pixels
         const NB st2 = mask_gate_enabled() && state_from_epilogue() ? nb(L.state_hr) : NB();
-        if (pair_mask() & 4)
+        if (chain_mask() & 2)   // main.0 -> conv1 -> conv2 (+ x) in one launch (round 6)
+            narrow_chain(first ? IT_R3_0F : IT_R3_0, IT_R3_1, IT_R3_2, "conv_narrow_chain:res3.main0_conv1_conv2_add", H8, W8, r3_srcs, NB(), nb(L.feat), true, st2);
+        else if (pair_mask() & 4)
             narrow_pair(IT_R3_1, IT_R3_2, "conv_narrow_pair:res3.conv1_conv2_add", H8, W8, {nb(L.z0)}, nb(L.feat), nb(L.z0), NB(), st2);
         else {
             narrow(IT_R3_1, H8, W8, {nb(L.z0)}, nb(L.z1));
