@@ -43,7 +43,7 @@ def kernel_family(name: str) -> str:
 # hipEvent launch-site family -> rocprofv3 kernel names (for the PMC traffic lookup)
 ROCPROF_NAMES = {"conv3x3_mfma": ("conv3x3_split_kernel", "conv3x3_split8_kernel", "conv3x3_pair_kernel", "conv3x3_mfma_kernel",
                                   "conv3x3_bf16_kernel", "conv3x3_bf16x8_kernel", "conv3x3_q16_kernel"),
-                 "conv3x3_narrow": ("conv3x3_narrow_kernel", "conv3x3_narrow_pair_kernel"),
+                 "conv3x3_narrow": ("conv3x3_narrow_kernel", "conv3x3_narrow_pair_kernel", "conv3x3_narrow_seq_kernel", "conv3x3_narrow_chain_kernel"),
                  "dcnv2_g8_c32": ("dcn_g8_kernel", "dcn_g8_pipe_kernel"), "dcnv2_shared_c4": ("dcn3_kernel<false",), "dcnv2_shared_c4_fused": ("dcn3_kernel<true",),
                  "flow_warp_q4_c4": ("flow_warp_p4_kernel",), "flow_warp_q4_c32": ("flow_warp_p4_kernel",),
                  "flow_warp_q4_c24": ("flow_warp_p4_kernel",), "flow_warp_q4_c32+c24": ("flow_warp_p4_dual_kernel", "flow_warp_p4_dual_split_kernel"),
