@@ -561,6 +561,12 @@ def leg_dcn_g8_alone(c):
         # dcn_3: the compact bytes the kernel moves (credit taken) and the 9x-replicated API tensors it never materialises (labelled)
         d3 = fam.get("dcnv2_shared_c4_fused")
         ns["dcnv2_shared_c4_fused"]["frac_at_api_tensor_bytes"] = (d3["bytes"] + d3["launches"] * (8 * h) * (8 * w) * 24 * 4.0) / (d3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # `frac` prices the fused kernel's own I/O (x + the offset conv's 4-channel input + flow + out = 14 values per pixel: the head conv runs
+        # inside); SURVEY 8(d)'s compact DCNv2 bytes are (Cin + 2 + 1 + Cout) = 11 values per pixel (print both)
+        esz = 4.0 if c.storage == "f32" else 2.0
+        compact = d3["launches"] * (8.0 * h) * (8.0 * w) * c.bclips * ((4 + 4) * esz + 3 * 4.0)
+        ns["dcnv2_shared_c4_fused"]["frac_survey_compact_bytes"] = compact / (d3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        ns["dcnv2_shared_c4_fused"]["frac_is"] = "fused-kernel I/O (x, the offset conv's input, flow, out); frac_survey_compact_bytes = (Cin + 2 + 1 + Cout) H W s"
     result["north_star_per_kernel"] = {"target_frac": 0.60, "kernels": ns,
                                        "meets_target": sorted(n for n, v in ns.items() if v["frac"] >= 0.60),
                                        "below_target": sorted(n for n, v in ns.items() if v["frac"] < 0.60),
