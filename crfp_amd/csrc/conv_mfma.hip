@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = (bwork - btile * ngrp) * CT;
     const int n = blockIdx.z;                                         // destination "batch item" (ksplit: one per K slice)
-    const int n_src = a.ksplit > 0 ? n / a.ksplit : n;                // source batch item
+    const int n_src = a.ksplit > 0 ? n / a.ksplit : (a.src_bgroup > 0 ? n + n / a.src_bgroup : n);   // source batch item (ConvArgs::ksplit / src_bgroup)
     const int H = a.H, W = a.W;
 
     // per-thread staging coordinates (constant over the K loop)
@@ -694,6 +694,7 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = (bwork - btile * ngrp) * CT;
     const int n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 
     // halo pixels of this thread: clamped coordinates (every load is unconditional and in range; pixels
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
 #define CRFP_QDESC(QB, QRS, QCS, QM, QI, CH)                                                              \
     {                                                                                                     \
         const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
-        QB = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                 \
+        QB = d_.base + (long long)ns * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
     }
 #define CRFP_SPLIT_ISSUE(CH)                                                                              \
     {                                                                                                     \
@@ -931,6 +932,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * NW;
     const int T0 = bwork - btile * ngrp;
     const int n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 #ifdef CRFP_LAB
     // diagnostic timeline (CRFP_STAMP_PTR / CRFP_STAMP_NAME, tools/stamp_conv8.py): absolute s_memtime of wave 0 at kernel entry,
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #define CRFP_QDESC(QB_, QRS, QCS, QM, QI, CH)                                                             \
     {                                                                                                     \
         const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
-        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+        QB_ = d_.base + (long long)ns * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
     }
 #define CRFP_S8_ISSUE(CH)                                                                                 \
     {                                                                                                     \
@@ -1118,6 +1120,7 @@ __global__ __launch_bounds__(S8P_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const int tiles_x = (a.W + TW - 1) / TW;
     const int ngrp = a.ctiles;
     const int n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
     const int G = gridDim.x;                     // a multiple of 8: every item of a workgroup lies in its XCD's band
     int item = blockIdx.x;
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(S8P_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const float* QB_; int QRS, QCS;                                                                       \
     {                                                                                                     \
         const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
-        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+        QB_ = d_.base + (long long)ns * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
     }
 #define S8P_ISSUE(CH)                                                                                     \
     {                                                                                                     \
@@ -1310,6 +1313,7 @@ __global__ __launch_bounds__(256, RPW == 1 ? CRFP_BF16_LB : 3) void conv3x3_bf16
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = bwork - btile * ngrp;
     const int n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 
     int cgy[NIN], cgx[NIN];
@@ -1347,7 +1351,7 @@ __global__ __launch_bounds__(256, RPW == 1 ? CRFP_BF16_LB : 3) void conv3x3_bf16
 #define CRFP_QDESC(QB_, QRS, QCS, QM, QI, CH)                                                             \
     {                                                                                                     \
         const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
-        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+        QB_ = d_.base + (long long)ns * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
     }
 #define CRFP_BF16_ISSUE(CH)                                                                               \
     {                                                                                                     \
@@ -1437,6 +1441,7 @@ __global__ __launch_bounds__(B8_NT, 2) void conv3x3_bf16x8_kernel(const ConvArgs
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * B8_TH;
     const int T0 = bwork - btile * ngrp;
     const int n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 
     int cgy[B8_NIN], cgx[B8_NIN];
@@ -1477,7 +1482,7 @@ __global__ __launch_bounds__(B8_NT, 2) void conv3x3_bf16x8_kernel(const ConvArgs
             const int ch_ = min(2 * (ST) + c2, nchunks - 1);                                              \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
                 const QuadDesc d_ = a.qd[4 * ch_ + q];                                                    \
-                const float* qb_ = d_.base + (long long)n * d_.bstride;                                   \
+                const float* qb_ = d_.base + (long long)ns * d_.bstride;                                   \
                 qm[c2][q] = d_.mask;                                                                      \
                 _Pragma("unroll") for (int t = 0; t < B8_NIN; ++t)                                        \
                     rq[c2][q][t] = CRFP_LDACT(cu32x2, qb_ + cgy[t] * d_.rs + cgx[t] * d_.cs); \
@@ -1586,6 +1591,7 @@ __global__ __launch_bounds__(P2_NT, 2) void conv3x3_bf16_pair_kernel(const ConvA
     const int btile = xcd_band_tile(blockIdx.x, gridDim.x);
     const int tx0 = (btile % tiles_x) * P2_OW, ty0 = (btile / tiles_x) * 8;
     const int n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 
     int cgy[P2_NIN], cgx[P2_NIN];
@@ -1628,7 +1634,7 @@ __global__ __launch_bounds__(P2_NT, 2) void conv3x3_bf16_pair_kernel(const ConvA
 #define CRFP_QDESC(QB_, QRS, QCS, QM, QI, CH)                                                             \
     {                                                                                                     \
         const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
-        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+        QB_ = d_.base + (long long)ns * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
     }
 #define CRFP_P2_ISSUE(CH)                                                                                 \
     {                                                                                                     \
@@ -1819,7 +1825,7 @@ __device__ __forceinline__ void pipe_issue(PipeRegs& R, const ConvArgs& a, const
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi) {
         const QuadDesc d = a.qd[4 * ch + qi];
-        const float* qb = d.base + (long long)n * d.bstride;
+        const float* qb = d.base + (long long)ns * d.bstride;
         R.m[qi] = d.mask;
 #pragma unroll
         for (int t = 0; t < 2; ++t) R.q[qi][t] = *reinterpret_cast<const f32x4*>(qb + cgy[t] * d.rs + cgx[t] * d.cs);
@@ -1869,6 +1875,7 @@ __global__ __launch_bounds__(PIPE_NT, 1) void conv3x3_split_pipe_kernel(const Co
     const int j = lane & 31, h = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW, ntiles = tiles_x * ((a.H + PIPE_NW - 1) / PIPE_NW);
     const int T0 = blockIdx.y, n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int nchunks = a.kq >> 2;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nitems = my_tiles * nchunks;
@@ -1990,6 +1997,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_spli
     const int btile = xcd_band_tile(blockIdx.x, gridDim.x);   // XCD x works on a contiguous band of tiles
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
     const bf16x8* __restrict__ wp = reinterpret_cast<const bf16x8*>(NP == 3 ? a.wsplit : a.wsplit16);
     const int nsteps = a.ctiles * NCH;
@@ -2009,7 +2017,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 2 : 1) void conv3x3_spli
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) {
             const QuadDesc d = a.qd[4 * ch + qi];
-            const float* qb = d.base + (long long)n * d.bstride;
+            const float* qb = d.base + (long long)ns * d.bstride;
             msk[qi] = d.mask;
 #pragma unroll
             for (int t = 0; t < NIN; ++t) {
@@ -2126,6 +2134,7 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
     const int tiles_x = (a.W + TW - 1) / TW;
     const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * WS_TH;
     const int n = blockIdx.z;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
     const int nchunks = a.kq >> 2;
     const int T0 = IS ? 0 : blockIdx.y;
@@ -2158,10 +2167,10 @@ __global__ __launch_bounds__(WS_NT, 1) void conv3x3_split_ws_kernel(const ConvAr
         {                                                                                                 \
             const QuadDesc d0 = a.qd[4 * (CH)], d1 = a.qd[4 * (CH) + 1], d2 = a.qd[4 * (CH) + 2],         \
                            d3 = a.qd[4 * (CH) + 3];                                                       \
-            const float* b0 = d0.base + (long long)n * d0.bstride;                                        \
-            const float* b1 = d1.base + (long long)n * d1.bstride;                                        \
-            const float* b2 = d2.base + (long long)n * d2.bstride;                                        \
-            const float* b3 = d3.base + (long long)n * d3.bstride;                                        \
+            const float* b0 = d0.base + (long long)ns * d0.bstride;                                        \
+            const float* b1 = d1.base + (long long)ns * d1.bstride;                                        \
+            const float* b2 = d2.base + (long long)ns * d2.bstride;                                        \
+            const float* b3 = d3.base + (long long)ns * d3.bstride;                                        \
             M0 = d0.mask; M1 = d1.mask; M2 = d2.mask; M3 = d3.mask;                                       \
             _Pragma("unroll") for (int t = 0; t < NIN; ++t) {                                             \
                 R0[t] = *reinterpret_cast<const f32x4*>(b0 + cgy[t] * d0.rs + cgx[t] * d0.cs);            \

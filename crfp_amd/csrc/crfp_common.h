@@ -46,7 +46,7 @@ bool precision_env_strict(int family);   // CRFP_PRECISION=f32 in the environmen
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // float-tensor helpers of the fp32 build that the bf16 engine borrows for its float tensors (flow fields, masks)
 int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
-                       int OW, float sh, float sw, float mul, hipStream_t s);
+                       int OW, float sh, float sw, float mul, hipStream_t s, int out_bgroup);
 int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long ob, int N, int H, int W, int r,
                   hipStream_t s);
 int launch_fg_prep(const uint8_t* fg, float* fg2, int H8, int W8, hipStream_t s);
@@ -179,6 +179,9 @@ struct ConvArgs {
     int ovf_skip0;          // 1: items with (n + ovf_add) % ovf_div == 0 raise nothing (FNet's never-read pairs that straddle two clips)
     int strict;         // 1: plain fp32 MFMA for this launch (CRFP_DSV_STRICT_F32)
     int dst_f32;        // bf16 build, ST_Q4, one destination: store float quads (FNet's flow output stays fp32)
+    int src_bgroup;     // > 0: batch item n of the launch READS source item n + n / src_bgroup (destinations, residual, flow and status words keep n):
+                        // FNet's first conv over the B * (t - 1) frame pairs of a lock-step batch -- pair n = (clip n / (t - 1), frame n % (t - 1) + 1)
+                        // of the flattened [B * t] frame sequence, skipping the B - 1 pairs that would straddle two clips (round 6)
     int ksplit;         // fp32-MFMA kernel only: > 0 = blockIdx.z enumerates (batch item, K slice): slice z % ksplit covers K-quads
                         // [slice * kq / ksplit, ...), reads batch item z / ksplit and writes "batch item" z of the destination (partial sums,
                         // added up by the caller).  SPyNet's coarse pyramid levels: one workgroup per shifted view instead of one for all nine
@@ -400,7 +403,7 @@ int launch_dcn_generic(const float* x, const float* offset, const float* mask, c
 int launch_nchw_to_q4(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s, unsigned* ovf = nullptr, int ovf_div = 0);
 int launch_q4_to_nchw(const float* x, float* out, int N, int C, int H, int W, int pad, hipStream_t s);
 int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
-                       int OW, float sh, float sw, float mul, hipStream_t s);
+                       int OW, float sh, float sw, float mul, hipStream_t s, int out_bgroup);
 int launch_upsample_nchw(const float* x, float* out, int N, int C, int H, int W, int OH, int OW, float sh, float sw,
                          float mul, hipStream_t s);
 int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long ob, int N, int H, int W, int r,

@@ -601,10 +601,11 @@ struct Runner {
     // s3: the output goes (only, when dsts is empty) to an SRC_S3 image
     void mfma(int id, int N, int H, int W, std::vector<SrcBind> srcs, std::vector<DstBind> dsts, int dstH = 0, int dstW = 0,
               const float* resid = nullptr, long long resid_bs = 0, const float* flow = nullptr, long long flow_bs = 0,
-              float* s3 = nullptr, long long s3_bs = 0, int dst_f32 = 0) {
+              float* s3 = nullptr, long long s3_bs = 0, int dst_f32 = 0, int src_bgroup = 0) {
         if (rc) return;
         const Item& it = M.items[id];
         ConvArgs a = it.c;
+        a.src_bgroup = src_bgroup;
         for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i].p; a.src[i].bstride = srcs[i].bs; a.src[i].pad = srcs[i].pad; }
         a.ndst = (int)dsts.size();
         for (size_t i = 0; i < dsts.size(); ++i) {
@@ -766,7 +767,9 @@ struct Runner {
 
     // FNet over nb pairs (reference model/CRFP.py:797-814); cur/prev: 3-channel frames as lr_to_q4 returns them (bs: NCHW batch stride);
     // flow_out: nb consecutive fp32 flow quads [h][w][4] (component 0 = dx, 1 = dy)
-    void fnet(int nb, const float* cur, long long cur_bs, const float* prev, long long prev_bs, float* flow_out) {
+    // group > 0: pair n reads frames (and writes the flow of) item n + n / group of the cur / prev / flow_out sequences -- the B * (t - 1)
+    // pairs of a lock-step batch out of its flattened [B * t] frame sequence, without the B - 1 pairs that straddle two clips (round 6)
+    void fnet(int nb, const float* cur, long long cur_bs, const float* prev, long long prev_bs, float* flow_out, int group = 0) {
         const int h = L.h, w = L.w;
         if (!rc && nb > L.fnet_cap) { set_error("dsv: FNet pass of %d pairs exceeds the workspace's %d", nb, L.fnet_cap); rc = CRFP_E_WORKSPACE; }
         if (rc || nb < 1) return;
@@ -779,7 +782,7 @@ struct Runner {
         Q4 f0 = q(L.ff0, 16, 4 * L.h3, 4 * L.w3), f1 = q(L.ff1, 16, 4 * L.h3, 4 * L.w3), u3 = q(L.fu3, 16, 8 * L.h3, 8 * L.w3);
         Q4 g0 = q(L.fg0, 8, 8 * L.h3, 8 * L.w3), g1 = q(L.fg1, 1, 8 * L.h3, 8 * L.w3), fl = q(L.flow_lr, 1, h, w);
         fl.p = flow_out;
-        mfma(IT_F0, nb, h, w, {{cur, cur_bs}, {prev, prev_bs}}, {{a0.p, a0.bs(), 0, 8}});
+        mfma(IT_F0, nb, h, w, {{cur, cur_bs}, {prev, prev_bs}}, {{a0.p, a0.bs(), 0, 8}}, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, group);
         mfma_q(IT_F0 + 1, nb, a0, a1);
         RUN(launch_avgpool2_q4(a1.p, a1.bs(), p1.p, p1.bs(), nb, 8, h, w, s));
         mfma_q(IT_F0 + 2, nb, p1, b0);
@@ -790,18 +793,18 @@ struct Runner {
         RUN(launch_avgpool2_q4(c1.p, c1.bs(), p3.p, p3.bs(), nb, 32, L.h2, L.w2, s));
         mfma_q(IT_F0 + 6, nb, p3, d0);
         mfma_q(IT_F0 + 7, nb, d0, d1);
-        RUN(launch_upsample_q4(d1.p, d1.bs(), u1.p, u1.bs(), nb, 64, d1.H, d1.W, u1.H, u1.W, 0.5f, 0.5f, 1.0f, s));
+        RUN(launch_upsample_q4(d1.p, d1.bs(), u1.p, u1.bs(), nb, 64, d1.H, d1.W, u1.H, u1.W, 0.5f, 0.5f, 1.0f, s, 0));
         mfma_q(IT_F0 + 8, nb, u1, e0);
         mfma_q(IT_F0 + 9, nb, e0, e1);
-        RUN(launch_upsample_q4(e1.p, e1.bs(), u2.p, u2.bs(), nb, 32, e1.H, e1.W, u2.H, u2.W, 0.5f, 0.5f, 1.0f, s));
+        RUN(launch_upsample_q4(e1.p, e1.bs(), u2.p, u2.bs(), nb, 32, e1.H, e1.W, u2.H, u2.W, 0.5f, 0.5f, 1.0f, s, 0));
         mfma_q(IT_F0 + 10, nb, u2, f0);
         mfma_q(IT_F0 + 11, nb, f0, f1);
-        RUN(launch_upsample_q4(f1.p, f1.bs(), u3.p, u3.bs(), nb, 16, f1.H, f1.W, u3.H, u3.W, 0.5f, 0.5f, 1.0f, s));
+        RUN(launch_upsample_q4(f1.p, f1.bs(), u3.p, u3.bs(), nb, 16, f1.H, f1.W, u3.H, u3.W, 0.5f, 0.5f, 1.0f, s, 0));
         mfma_q(IT_F0 + 12, nb, u3, g0);
         // tanh * 256 flow and its resize to (h, w) stay float in both builds (coordinates)
         mfma(IT_F0 + 13, nb, g0.H, g0.W, {{g0.p, g0.bs()}}, {{g1.p, g1.bs(), 0, g1.nq}}, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 1);
         RUN(crfp::launch_upsample_q4(g1.p, g1.bs(), fl.p, fl.bs(), nb, 1, g1.H, g1.W, h, w, (float)g1.H / (float)h,
-                                     (float)g1.W / (float)w, 1.0f, s));
+                                     (float)g1.W / (float)w, 1.0f, s, group));
     }
 
     // zero the P4 buffers (pads must read as 0; also gives the zero initial state)
@@ -833,13 +836,14 @@ struct Runner {
         const long long lqf = lr_frame_floats(), lr_f = 3LL * L.h * L.w, fq = (long long)L.h * L.w * 4;
         const int t = L.t, B = L.B;
         struct Restore { Runner& r; int d, a, o; ~Restore() { r.ovf_div = d; r.ovf_add = a; r.ovf_off = o; r.ovf_skip0 = 0; } } restore{*this, ovf_div, ovf_add, ovf_off};
-        if (L.flat) {   // i0 == 0, i1 == t: one pass over the B * t frames / the B * t - 1 consecutive pairs (B - 1 of them straddle two clips and are never read)
-            ovf_div = t;           // item n of these launches is frame n (encoder_lr) / frame n + 1 (FNet's pair n) of the flattened sequence
+        if (L.flat) {   // i0 == 0, i1 == t: one pass over the B * t frames / the B * (t - 1) frame pairs of the clips
+            ovf_div = t;           // item n of encoder_lr's launches is frame n of the flattened sequence
             ovf_add = 0;
             if (parts & 1) encode_lr(B * t, lq, lr_f, 0);
-            ovf_add = 1;
-            ovf_skip0 = 1;         // the pair whose current frame opens a clip straddles two clips: never read, raises nothing
-            if ((parts & 2) && t > 1) fnet(B * t - 1, lq + lqf, lr_f, lq, lr_f, F(L.flow_lr) + fq);   // one-frame clips need no flow
+            // Round 6: FNet's pair n is (frame n % (t - 1) + 1, frame n % (t - 1)) of clip n / (t - 1) = items n + n / (t - 1) of the cur / prev / flow
+            // sequences: the B - 1 pairs that straddle two clips (11 % of FNet at B = 4, t = 7, 48 % at t = 2) are no longer computed
+            ovf_div = t - 1;       // ... and pair n belongs to clip n / (t - 1)
+            if ((parts & 2) && t > 1) fnet(B * (t - 1), lq + lqf, lr_f, lq, lr_f, F(L.flow_lr) + fq, t - 1);   // one-frame clips need no flow
             return;
         }
         ovf_div = 0;               // per-clip passes: every item of a launch belongs to clip b

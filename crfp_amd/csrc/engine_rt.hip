@@ -441,16 +441,16 @@ struct Runner {
         mfma_q(RI_F0 + 6, nb, F(L.fp3), 32, F(L.fd0), 64, L.h3, L.w3);
         mfma_q(RI_F0 + 7, nb, F(L.fd0), 64, F(L.fd1), 64, L.h3, L.w3);
         const int H1 = 2 * L.h3, W1 = 2 * L.w3, H2_ = 4 * L.h3, W2_ = 4 * L.w3, H3 = 8 * L.h3, W3 = 8 * L.w3;
-        RUN(launch_upsample_q4(F(L.fd1), bs(64, L.h3, L.w3), F(L.fu1), bs(64, H1, W1), nb, 64, L.h3, L.w3, H1, W1, 0.5f, 0.5f, 1.0f, s));
+        RUN(launch_upsample_q4(F(L.fd1), bs(64, L.h3, L.w3), F(L.fu1), bs(64, H1, W1), nb, 64, L.h3, L.w3, H1, W1, 0.5f, 0.5f, 1.0f, s, 0));
         mfma_q(RI_F0 + 8, nb, F(L.fu1), 64, F(L.fe0), 32, H1, W1);
         mfma_q(RI_F0 + 9, nb, F(L.fe0), 32, F(L.fe1), 32, H1, W1);
-        RUN(launch_upsample_q4(F(L.fe1), bs(32, H1, W1), F(L.fu2), bs(32, H2_, W2_), nb, 32, H1, W1, H2_, W2_, 0.5f, 0.5f, 1.0f, s));
+        RUN(launch_upsample_q4(F(L.fe1), bs(32, H1, W1), F(L.fu2), bs(32, H2_, W2_), nb, 32, H1, W1, H2_, W2_, 0.5f, 0.5f, 1.0f, s, 0));
         mfma_q(RI_F0 + 10, nb, F(L.fu2), 32, F(L.ff0), 16, H2_, W2_);
         mfma_q(RI_F0 + 11, nb, F(L.ff0), 16, F(L.ff1), 16, H2_, W2_);
-        RUN(launch_upsample_q4(F(L.ff1), bs(16, H2_, W2_), F(L.fu3), bs(16, H3, W3), nb, 16, H2_, W2_, H3, W3, 0.5f, 0.5f, 1.0f, s));
+        RUN(launch_upsample_q4(F(L.ff1), bs(16, H2_, W2_), F(L.fu3), bs(16, H3, W3), nb, 16, H2_, W2_, H3, W3, 0.5f, 0.5f, 1.0f, s, 0));
         mfma_q(RI_F0 + 12, nb, F(L.fu3), 16, F(L.fg0), 8, H3, W3);
         mfma(RI_F0 + 13, nb, H3, W3, {{F(L.fg0), bs(8, H3, W3)}}, {{F(L.fg1), bs(1, H3, W3), 0, 1}}, 0, 0, nullptr, nullptr, nullptr, 1);
-        RUN(launch_upsample_q4(F(L.fg1), bs(1, H3, W3), F(L.flow_lr), fs, nb, 1, H3, W3, h, w, (float)H3 / (float)h, (float)W3 / (float)w, 1.0f, s));
+        RUN(launch_upsample_q4(F(L.fg1), bs(1, H3, W3), F(L.flow_lr), fs, nb, 1, H3, W3, h, w, (float)H3 / (float)h, (float)W3 / (float)w, 1.0f, s, 0));
     }
 
     void zero(size_t off, size_t bytes, size_t guard = 0) {

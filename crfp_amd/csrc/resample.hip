@@ -113,8 +113,9 @@ int launch_offmask_nchw_to_q4(const float* offset, const float* mask, float* out
 #endif
 
 // bilinear resize of a Q4 tensor; out = mul * (l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11))
+// out_bgroup > 0: batch item n WRITES destination item n + n / out_bgroup (see ConvArgs::src_bgroup: FNet's per-clip pair mapping)
 __global__ void upsample_q4_kernel(const act_t* __restrict__ x, long long xb, act_t* __restrict__ out, long long ob,
-                                   int nq, int H, int W, int OH, int OW, float sh, float sw, float mul) {
+                                   int nq, int H, int W, int OH, int OW, float sh, float sw, float mul, int out_bgroup) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= OW || oy >= OH) return;
@@ -133,14 +134,15 @@ __global__ void upsample_q4_kernel(const act_t* __restrict__ x, long long xb, ac
     r.y = mul * (ly0 * (lx0 * a.y + lx1 * b.y) + ly1 * (lx0 * c.y + lx1 * d.y));
     r.z = mul * (ly0 * (lx0 * a.z + lx1 * b.z) + ly1 * (lx0 * c.z + lx1 * d.z));
     r.w = mul * (ly0 * (lx0 * a.w + lx1 * b.w) + ly1 * (lx0 * c.w + lx1 * d.w));
-    stq(out + (long long)n * ob + (((long long)q * OH + oy) * OW + ox) * 4, r);
+    const int no = out_bgroup > 0 ? n + n / out_bgroup : n;
+    stq(out + (long long)no * ob + (((long long)q * OH + oy) * OW + ox) * 4, r);
 }
 
 int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W, int OH,
-                       int OW, float sh, float sw, float mul, hipStream_t s) {
+                       int OW, float sh, float sw, float mul, hipStream_t s, int out_bgroup) {
     ProfScope prof("upsample_bilinear_q4", s, (double)N * nq * 16.0 * ((double)H * W + (double)OH * OW), 0);
     dim3 grid((OW + 63) / 64, (OH + 3) / 4, N * nq);
-    upsample_q4_kernel<<<grid, 256, 0, s>>>(as_act(x), xb, as_act(out), ob, nq, H, W, OH, OW, sh, sw, mul);
+    upsample_q4_kernel<<<grid, 256, 0, s>>>(as_act(x), xb, as_act(out), ob, nq, H, W, OH, OW, sh, sw, mul, out_bgroup);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
