@@ -1812,6 +1812,7 @@ struct PipeRegs {
 __device__ __forceinline__ void pipe_issue(PipeRegs& R, const ConvArgs& a, const bf16x8* __restrict__ wp, int n, int T0,
                                            int nchunks, int ch, int tx0, int ty0, int tid) {
     const int H = a.H, W = a.W;
+    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     int cgy[2], cgx[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {

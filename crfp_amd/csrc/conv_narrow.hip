@@ -1303,7 +1303,12 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
 #ifndef CRFP_NARROW_SEQ_MINKQ
 #define CRFP_NARROW_SEQ_MINKQ 1   // the one-quad plain stencils too: the form carries the interior-tile fast path (A/B builds: 2)
 #endif
-    if (CRFP_NARROW_SEQ && !a.gate && !a.dst2 && a.epi == NE_PLAIN && a.kq >= CRFP_NARROW_SEQ_MINKQ && a.act != CRFP_ACT_TANH && a.act != CRFP_ACT_SIGMOID) {
+#ifdef CRFP_LAB   // lab library: CRFP_NARROW_SEQ=0 at run time keeps conv3x3_narrow_kernel for the plain stencils
+    static const bool seq_on = getenv("CRFP_NARROW_SEQ") ? atoi(getenv("CRFP_NARROW_SEQ")) != 0 : CRFP_NARROW_SEQ != 0;
+#else
+    constexpr bool seq_on = CRFP_NARROW_SEQ != 0;
+#endif
+    if (seq_on && !a.gate && !a.dst2 && a.epi == NE_PLAIN && a.kq >= CRFP_NARROW_SEQ_MINKQ && a.act != CRFP_ACT_TANH && a.act != CRFP_ACT_SIGMOID) {
         const int share4 = (ntl + 256 * CRFP_NARROW_OCC1 - 1) / (256 * CRFP_NARROW_OCC1);
         dim3 grid4((ntl + share4 - 1) / share4, 1, a.N);
         if (a.kq == 1) conv3x3_narrow_seq_kernel<1><<<grid4, 256, 0, s>>>(a);

@@ -728,7 +728,14 @@ struct Runner {
 // stage (three input quads on 1.33x the pixels) makes it issue-bound at three workgroups per CU, so it stays three launches.
 #define CRFP_NARROW_CHAIN 2
 #endif
+#ifdef CRFP_LAB   // lab library: CRFP_NARROW_CHAIN=<mask> at run time (tests/test_gpu_round6.py compares the chains with the launches they replace)
+    static int chain_mask() {
+        static const int m = getenv("CRFP_NARROW_CHAIN") ? atoi(getenv("CRFP_NARROW_CHAIN")) : CRFP_NARROW_CHAIN;
+        return kActBf16 ? 0 : m;
+    }
+#else
     static constexpr int chain_mask() { return kActBf16 ? 0 : CRFP_NARROW_CHAIN; }
+#endif
     // which 8x-resolution conv pairs run fused (bit 0: encoder_hr.0->.2, 1: dcn_3 conv_fuse->offset/mask, 2: res3 conv1->conv2,
     // 3: dcn_3 block.0->.2).  Measured @A fp32, pair vs the two single kernels: res3 47.2 vs 57.8 us (bf16 46.7 vs 56.1);
     // encoder_hr 71.5 vs 67.6; conv_fuse->offset/mask 80 vs 76.8; dcn_3 block (3 input quads, one workgroup per CU) 126 vs 93.7.
@@ -740,7 +747,14 @@ struct Runner {
 #ifndef CRFP_STATE_FROM_EPILOGUE
 #define CRFP_STATE_FROM_EPILOGUE 1   // A/B builds: 0 = the separate lrelu pass
 #endif
+#ifdef CRFP_LAB   // lab library: CRFP_STATE_FROM_EPILOGUE=0 at run time keeps the separate lrelu pass
+    static bool state_from_epilogue() {
+        static const bool on = getenv("CRFP_STATE_FROM_EPILOGUE") ? atoi(getenv("CRFP_STATE_FROM_EPILOGUE")) != 0 : CRFP_STATE_FROM_EPILOGUE != 0;
+        return on;
+    }
+#else
     static constexpr bool state_from_epilogue() { return CRFP_STATE_FROM_EPILOGUE != 0; }
+#endif
 #define RUN(expr) do { if (!rc) rc = (expr); } while (0)
 
     // The fovea blend is a select under the mask (model/CRFP.py:1543-1544,1674-1675): what is computed only to be deselected -- the x8
