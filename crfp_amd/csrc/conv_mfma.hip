@@ -1591,7 +1591,6 @@ __global__ __launch_bounds__(P2_NT, 2) void conv3x3_bf16_pair_kernel(const ConvA
     const int btile = xcd_band_tile(blockIdx.x, gridDim.x);
     const int tx0 = (btile % tiles_x) * P2_OW, ty0 = (btile / tiles_x) * 8;
     const int n = blockIdx.z;
-    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 
     int cgy[P2_NIN], cgx[P2_NIN];
@@ -1634,7 +1633,7 @@ __global__ __launch_bounds__(P2_NT, 2) void conv3x3_bf16_pair_kernel(const ConvA
 #define CRFP_QDESC(QB_, QRS, QCS, QM, QI, CH)                                                             \
     {                                                                                                     \
         const QuadDesc d_ = a.qd[4 * (CH) + (QI)];                                                        \
-        QB_ = d_.base + (long long)ns * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
+        QB_ = d_.base + (long long)n * d_.bstride; QRS = d_.rs; QCS = d_.cs; QM = d_.mask;                \
     }
 #define CRFP_P2_ISSUE(CH)                                                                                 \
     {                                                                                                     \

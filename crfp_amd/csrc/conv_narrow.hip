@@ -104,7 +104,9 @@ __device__ __forceinline__ void narrow_store_state(act_t* d2, long long ppix, cf
 // tile (mask_gate_kernel, resample.hip).  Tiles without one are not computed at all.  NE_PLAIN (encoder_hr, model/CRFP.py:1545-1547): their
 // outputs only ever feed pixels the fovea blend deselects.  NE_BLEND (conv_tttf + blend, :1672-1675): there the new state is lrelu(state),
 // which a plain streaming pass has written before this launch (launch_lrelu_q4_to_p4, resample.hip).
-template <int KQ, int EPI, bool GATE = false>
+// ST2 (NE_PLAIN, round 6): the launch has a second destination (NarrowArgs::dst2); a template parameter so that every other instantiation keeps
+// the epilogue it had (as a run-time branch it cost the bf16 build's stencils ~1 us each: profiles/r06_headline_ab.txt)
+template <int KQ, int EPI, bool GATE = false, bool ST2 = false>
 __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_NARROW_OCC2 : CRFP_NARROW_OCC3)) void conv3x3_narrow_kernel(const NarrowArgs a) {
 #ifdef CRFP_ACT_BF16
     __shared__ cu32x2 tile[KQ][NLH][NLW];   // bf16 quads as they sit in HBM (8 bytes)
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
     act_t* const dsta = as_act(a.dst) + (long long)n * a.dst_bstride;   // NE_PLAIN / NE_BLEND: activation (act_t) tensors
     const int dpitch = W + a.dst_pad;                       // Q4 destination may be padded (P4)
     const act_t* const resid = a.resid ? as_act(a.resid) + (long long)n * a.resid_bstride : nullptr;
-    act_t* const dst2 = EPI == NE_PLAIN && a.dst2 ? as_act(a.dst2) + (long long)n * a.dst2_bstride : nullptr;
+    act_t* const dst2 = ST2 ? as_act(a.dst2) + (long long)n * a.dst2_bstride : nullptr;
     const uint8_t* const mask = EPI == NE_BLEND ? a.mask + (long long)n * a.mask_bstride : nullptr;
     const act_t* const basep = EPI == NE_LAST && a.base ? as_act(a.base) + (long long)n * a.base_bstride : nullptr;
     const float* const baselr = EPI == NE_LAST && !a.base ? a.base_lr + (long long)n * a.base_bstride : nullptr;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                         v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                     }
                     stq(dsta + dpix * 4, cf32x4{v[0], v[1], v[2], v[3]});
-                    if (dst2) narrow_store_state(dst2, (long long)y * (W + 1) + x, cf32x4{v[0], v[1], v[2], v[3]}, vmax);
+                    if (ST2) narrow_store_state(dst2, (long long)y * (W + 1) + x, cf32x4{v[0], v[1], v[2], v[3]}, vmax);
                 } else if (EPI == NE_BLEND) {
 #ifdef CRFP_ACT_BF16
                     const cf32x4 centre = quad_from_bits(tile[0][4 * ty + i + 1][tx + 1]);
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256, KQ == 1 ? CRFP_NARROW_OCC1 : (KQ == 2 ? CRFP_N
                 }
             }
         }
-        if ((EPI == NE_BLEND || (EPI == NE_PLAIN && dst2)) && ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
+        if ((EPI == NE_BLEND || ST2) && ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
         if (t_next >= band1) break;
         t_cur = t_next;
         // every wave is done reading the tile before it is overwritten.  LDS-only barrier: __syncthreads() would also
@@ -1323,6 +1325,12 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
         else if (a.epi == NE_PLAIN && a.kq == 2) conv3x3_narrow_kernel<2, NE_PLAIN, true><<<grid, 256, 0, s>>>(a);
         else if (a.epi == NE_BLEND && a.kq == 2) conv3x3_narrow_kernel<2, NE_BLEND, true><<<grid, 256, 0, s>>>(a);
         else { set_error("conv_narrow %s: no mask-gated form for kq=%d epi=%d", name, a.kq, a.epi); return CRFP_E_UNSUPPORTED; }
+        CRFP_CHECK_LAUNCH();
+        return 0;
+    }
+    if (a.dst2) {   // the second destination (the new state): forward_resblocks_3's last conv, one input quad
+        if (a.epi != NE_PLAIN || a.kq != 1) { set_error("conv_narrow %s: a second destination needs a plain one-quad stencil (kq=%d epi=%d)", name, a.kq, a.epi); return CRFP_E_UNSUPPORTED; }
+        conv3x3_narrow_kernel<1, NE_PLAIN, false, true><<<grid, 256, 0, s>>>(a);
         CRFP_CHECK_LAUNCH();
         return 0;
     }

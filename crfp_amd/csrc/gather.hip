@@ -717,6 +717,9 @@ __global__ __launch_bounds__(256, 3) void dcn_g8_pipe_kernel(const float* __rest
 // results are bit-identical to the two-kernel path.  LDS 81 408 B (NW = 4, two workgroups per CU) / 117 248 B (NW = 8, shipped).
 constexpr int DF_LW = 34;
 constexpr int DF_WCH = 9 * 2 * 64;                   // one (cout tile, chunk) of the fp16 pair image, 16-byte elements
+#ifndef CRFP_DF_BAND_NP
+#define CRFP_DF_BAND_NP 1   // A/B builds: 0 = the natural tile order of the one-tile form (round 5)
+#endif
 #ifndef CRFP_DF_PS_PROBE   // A/B builds, timing only (results wrong): 1 = the persistent form never requests the next tile's halo tile / weights,
 #define CRFP_DF_PS_PROBE 0 // 2 = ... never writes them to LDS
 #endif
@@ -770,6 +773,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         NN = n_; TY = y_ * NW; TX = (r_ - y_ * tiles_x) * 32;                                             \
     }
     if (PS) DF_DECODE(t_cur, tx0, ty0, n)
+#if CRFP_DF_BAND_NP   // the one-tile form walks the tile list in the XCD-banded order too (xcd_band_tile over the launch's linear workgroup id)
+    else if (DB) {
+        const int lin_ = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+        const int tb_ = xcd_band_tile(lin_, (int)(gridDim.x * gridDim.y * gridDim.z));
+        DF_DECODE(tb_, tx0, ty0, n)
+    }
+#endif
     else { tx0 = blockIdx.x * 32; ty0 = blockIdx.y * NW; n = blockIdx.z; }
 
     f32x4 rt[DF_NIN];
@@ -1331,6 +1341,15 @@ bool dcn_fused_enabled() {
 }
 
 constexpr int kFusedPersistWgs = 256;   // workgroups of the persistent form = CUs of an MI355X (one 8-wave workgroup per CU: 155 KB of LDS, 250 VGPRs)
+// launches with at least this many tiles take the persistent form (six rounds of one workgroup per CU); -DCRFP_LAB: CRFP_DF_PS_MIN_TILES overrides (tests)
+static int fused_persist_min_tiles() {
+#ifdef CRFP_LAB
+    static const int v = getenv("CRFP_DF_PS_MIN_TILES") ? atoi(getenv("CRFP_DF_PS_MIN_TILES")) : 6 * kFusedPersistWgs;
+    return v > kFusedPersistWgs ? v : kFusedPersistWgs + 1;
+#else
+    return 6 * kFusedPersistWgs;
+#endif
+}
 
 int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     if ((long long)(a.H + 1) * (a.W + 1) >= (1ll << 24)) { set_error("dcn_g8: plane of %d x %d exceeds the sampler's 2^24-element index range", a.H, a.W); return CRFP_E_UNSUPPORTED; }
@@ -1351,6 +1370,7 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     static const int nw_lab = getenv("CRFP_DCN_FUSE_NW") ? atoi(getenv("CRFP_DCN_FUSE_NW")) : 8;
     static const int fuse_v_lab = getenv("CRFP_DCN_FUSE_V") ? atoi(getenv("CRFP_DCN_FUSE_V")) : 1;
     if (nw_lab == 8 && fuse_v_lab == 2) dcn_fused2_kernel<<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), D2_NT, 0, s>>>(b);
+    else if (nw_lab == 8 && ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.N >= fused_persist_min_tiles()) dcn_fused_kernel<8, true><<<dim3(kFusedPersistWgs, 1, 1), 512, 0, s>>>(b);
     else if (nw_lab == 8) dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(b);
     else dcn_fused_kernel<4><<<dim3((a.W + 31) / 32, (a.H + 3) / 4, a.N), 256, 0, s>>>(b);
     CRFP_CHECK_LAUNCH();
@@ -1360,12 +1380,13 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     // (lab library, CRFP_DCN_FUSE_V=2: the role-specialised 16-wave form above -- bit-identical, 141.2 vs 136.6 us per launch same-box @A:
     // both forms pay the same ~53 us of per-workgroup fixed cost (116 KB of tile / weight prologue and 258 KB of streamed head
     // weights per 256 pixels, 15 barriers), and the specialised one overlaps only 17 of the 49 us its sampler role adds)
-    // Round 6: more tiles than CUs -> the persistent form (one workgroup per CU walks its XCD's band of the tile list)
+    // Round 6: both forms walk the tile list in the XCD-banded order (HBM traffic 170 -> 112-116 MB per launch @A).  Launches of six rounds of
+    // the chip and more (a lock-step batch, the 4K map) take the persistent form (-1 % there, +1.5 % at 3.5 rounds: profiles/r06_dcn_fused_persistent_ab.txt)
 #ifndef CRFP_DF_PERSIST
 #define CRFP_DF_PERSIST 1
 #endif
     const int tiles = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.N;
-    if (CRFP_DF_PERSIST && tiles > kFusedPersistWgs) dcn_fused_kernel<8, true><<<dim3(kFusedPersistWgs, 1, 1), 512, 0, s>>>(a);
+    if (CRFP_DF_PERSIST && tiles >= fused_persist_min_tiles()) dcn_fused_kernel<8, true><<<dim3(kFusedPersistWgs, 1, 1), 512, 0, s>>>(a);
     else dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
     CRFP_CHECK_LAUNCH();
     return 0;
@@ -1380,6 +1401,9 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
 // workgroups per CU.
 constexpr int DF_LW = 34;
 constexpr int DF_WST = 2 * 9 * 64;                   // one cout tile of the bf16 image, 16-byte elements
+#ifndef CRFP_DF_BAND_NP
+#define CRFP_DF_BAND_NP 1
+#endif
 #ifndef CRFP_DF_PS_PROBE   // A/B builds, timing only (results wrong): see the fp32 kernel
 #define CRFP_DF_PS_PROBE 0
 #endif
@@ -1424,6 +1448,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(con
         NN = n_; TY = y_ * NW; TX = (r_ - y_ * tiles_x) * 32;                                             \
     }
     if (PS) DF_DECODE(t_cur, tx0, ty0, n)
+#if CRFP_DF_BAND_NP   // the one-tile form walks the tile list in the XCD-banded order too (xcd_band_tile over the launch's linear workgroup id)
+    else if (DB) {
+        const int lin_ = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+        const int tb_ = xcd_band_tile(lin_, (int)(gridDim.x * gridDim.y * gridDim.z));
+        DF_DECODE(tb_, tx0, ty0, n)
+    }
+#endif
     else { tx0 = blockIdx.x * 32; ty0 = blockIdx.y * NW; n = blockIdx.z; }
 
     int ltid = tid0;   // the thread id as the tile loop sees it (opaquely re-defined per tile: see the fp32 kernel)
@@ -1684,6 +1715,14 @@ bool dcn_fused_enabled() {
 }
 
 constexpr int kFusedPersistWgs = 256;   // workgroups of the persistent form = CUs of an MI355X (one 8-wave workgroup per CU)
+static int fused_persist_min_tiles() {     // see the fp32 launcher
+#ifdef CRFP_LAB
+    static const int v = getenv("CRFP_DF_PS_MIN_TILES") ? atoi(getenv("CRFP_DF_PS_MIN_TILES")) : 6 * kFusedPersistWgs;
+    return v > kFusedPersistWgs ? v : kFusedPersistWgs + 1;
+#else
+    return 6 * kFusedPersistWgs;
+#endif
+}
 
 int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     if ((long long)(a.H + 1) * (a.W + 1) >= (1ll << 24)) { set_error("dcn_g8: plane of %d x %d exceeds the sampler's 2^24-element index range", a.H, a.W); return CRFP_E_UNSUPPORTED; }
@@ -1698,12 +1737,12 @@ int launch_dcn_fused(const DcnFuseArgs& a, hipStream_t s) {
     else
 #endif
     {
-        // Round 6: more tiles than CUs -> the persistent form (one workgroup per CU walks its XCD's band of the tile list)
+        // Round 6: see the fp32 launcher
 #ifndef CRFP_DF_PERSIST
 #define CRFP_DF_PERSIST 1
 #endif
         const int tiles = ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.N;
-        if (CRFP_DF_PERSIST && tiles > kFusedPersistWgs) dcn_fused_kernel<8, true><<<dim3(kFusedPersistWgs, 1, 1), 512, 0, s>>>(a);
+        if (CRFP_DF_PERSIST && tiles >= fused_persist_min_tiles()) dcn_fused_kernel<8, true><<<dim3(kFusedPersistWgs, 1, 1), 512, 0, s>>>(a);
         else dcn_fused_kernel<8><<<dim3((a.W + 31) / 32, (a.H + 7) / 8, a.N), 512, 0, s>>>(a);
     }
     CRFP_CHECK_LAUNCH();

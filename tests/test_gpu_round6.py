@@ -9,15 +9,19 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("storage", ["f32", "bf16"])
 def test_persistent_fused_dcn_is_bit_identical_to_the_two_kernel_path(storage):
-    """A 101 x 170 clip is 202 x 340 at 2x resolution = 26 x 11 = 286 tiles of 8 x 32 pixels (ragged in x and y) > 256, so dcn_fused_kernel
-    runs in its persistent form: one workgroup per CU walks its XCD band of the tile list, the next tile's halo tile and weight stage 0
-    requested in the current tile's tail.  Same arithmetic in the same order as conv3x3 + dcn_g8_pipe (CRFP_DCN_FUSED=0): not one bit
+    """A 101 x 170 clip is 202 x 340 at 2x resolution = 26 x 11 = 286 tiles of 8 x 32 pixels (ragged in x and y) > 256 workgroups: the persistent
+    form of dcn_fused_kernel (one workgroup per CU walks its XCD band of the tile list, the next tile's halo tile and weight stage 0
+    requested in the current tile's tail) gives every workgroup of XCDs 0-5 a second tile.  Same arithmetic in the same order as conv3x3 + dcn_g8_pipe (CRFP_DCN_FUSED=0): not one bit
     of the clip may differ.  (The lock-step batch at 4 x 180 x 320 -- tile ids that run across batch items -- is
     test_gpu_round5.py::test_config4_lockstep_batch_at_the_real_shape.)"""
     env = {"CRFP_CHECK_GEOM": "101,170,3"}
     if storage == "bf16":
         env["CRFP_CHECK_STORAGE"] = "bf16"
-    assert _golden_check(env, want="DIGEST") == _golden_check(dict(env, CRFP_DCN_FUSED="0"), want="DIGEST")
+    two_kernel = _golden_check(dict(env, CRFP_DCN_FUSED="0"), want="DIGEST")
+    # the product takes the XCD-banded one-tile form here (the persistent form starts at six rounds of the chip) ...
+    assert _golden_check(env, want="DIGEST") == two_kernel
+    # ... and the lab library is told to take the persistent form for every launch with more tiles than workgroups
+    assert _golden_check(dict(env, CRFP_DF_PS_MIN_TILES="257"), lab=True, want="DIGEST") == two_kernel
 
 
 @pytest.mark.parametrize("env", [{"CRFP_NARROW_CHAIN": "0"}, {"CRFP_NARROW_CHAIN": "3"}, {"CRFP_NARROW_SEQ": "0", "CRFP_NARROW_CHAIN": "0"},
