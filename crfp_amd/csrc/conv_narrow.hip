@@ -1319,6 +1319,220 @@ int launch_narrow_chain(const NarrowArgs& a, const NarrowArgs& b, const NarrowAr
 }
 #endif
 
+#ifdef CRFP_ACT_BF16
+// ---------------------------------------------------------------- three stencils in one pass (A -> B -> C), bf16 storage (round 6)
+// forward_resblocks_3's main.0 -> conv1 -> conv2 + x (+ the new state) as ONE launch, the twin of the fp32 build's conv3x3_narrow_chain_kernel: the
+// same 16 x 60 output tile, A on 20 x 64 and B on 18 x 62 (lane = column, five / four rows per wave), global quads through LDS one at a time; the
+// tensors between the convs are the bf16 quads the three-launch path would have stored (rounded at the same points), the channel mixing runs on
+// the block-diagonal v_mfma_f32_16x16x32_bf16 of conv3x3_narrow_kernel in its order (quad outer, then the five tap pairs): bit-identical.
+// LDS 21.8 KB + the A fragments of the (KQA + 2) quads (5 KB each: 64 lanes x 16 B x 5 tap pairs), read once per tap pair and stage.
+constexpr int KCW = 60, KCH = 16;
+constexpr int KAW = KCW + 4, KAH = KCH + 4;
+constexpr int KBW = KCW + 2, KBH = KCH + 2;
+constexpr int KIW = KCW + 6, KIH = KCH + 6;
+constexpr int KST = (KIH * KIW + 255) / 256;
+
+template <int KQA>
+__global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const NarrowArgs a, const NarrowArgs b, const NarrowArgs c) {
+    __shared__ cu32x2 buf0[KIH][KIW];   // one global quad of A (22 x 66); later B's output (rows < 18, columns < 62)
+    __shared__ cu32x2 t1[KAH][KAW];     // A's output (20 x 64): B's input and C's residual
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + KCW - 1) / KCW, ntiles = tiles_x * ((H + KCH - 1) / KCH);
+    const char* qbase[KQA];
+    int qpitch[KQA];
+    bool qflow[KQA];
+#pragma unroll
+    for (int k = 0; k < KQA; ++k) {
+        int kql = k, s = 0;
+        while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
+        const ConvSrc src = a.src[s];
+        qflow[k] = src.kind == SRC_FLOW2;
+        qpitch[k] = W + src.pad;
+        qbase[k] = qflow[k] ? reinterpret_cast<const char*>(src.p + (long long)n * src.bstride)
+                            : reinterpret_cast<const char*>(as_act(src.p) + (long long)n * src.bstride + (long long)kql * (H + src.pad) * qpitch[k] * 4);
+    }
+    typedef __bf16 nb16x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 nb16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
+    // block-diagonal A fragments (conv3x3_narrow_kernel) of A's quads, B and C: built once per workgroup into LDS ([quad][tap pair][lane])
+    __shared__ nb16x8 awl[(KQA + 2) * 5][64];
+    if (tid < 64) {
+        const int cc_ = lane & 3;
+        const bool diag = (lane >> 4) == ((lane & 15) >> 2);
+#define CRFP_CHAIN_FRAG(QI, WPK, KQT, K_, FLOW_)                                                          \
+    _Pragma("unroll") for (int st = 0; st < 5; ++st) {                                                    \
+        nu32x4 wds;                                                                                       \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                \
+            const int tap = 2 * st + hf;                                                                  \
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                                        \
+            if (tap < 9) {                                                                                \
+                _Pragma("unroll") for (int comp = 0; comp < 4; ++comp) {                                  \
+                    const int cc = (FLOW_) ? (comp & 1) : comp;                                           \
+                    const float wv = (WPK)[((tap * (KQT) + (K_)) * 4 + cc) * 4 + cc_];                    \
+                    v[comp] = diag ? wv : 0.0f;                                                           \
+                }                                                                                         \
+            }                                                                                             \
+            wds[2 * hf] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v[0], v[1]}, nb16x2)); \
+            wds[2 * hf + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v[2], v[3]}, nb16x2)); \
+        }                                                                                                 \
+        awl[(QI) * 5 + st][lane] = __builtin_bit_cast(nb16x8, wds);                                       \
+    }
+#pragma unroll
+        for (int k = 0; k < KQA; ++k) CRFP_CHAIN_FRAG(k, a.wpk, KQA, k, qflow[k])
+        CRFP_CHAIN_FRAG(KQA, b.wpk, 1, 0, false)
+        CRFP_CHAIN_FRAG(KQA + 1, c.wpk, 1, 0, false)
+#undef CRFP_CHAIN_FRAG
+    }
+    const float4 biasA = *reinterpret_cast<const float4*>(a.bpk), biasB = *reinterpret_cast<const float4*>(b.bpk),
+                 biasC = *reinterpret_cast<const float4*>(c.bpk);
+    const float slopeA = a.act == CRFP_ACT_RELU ? 0.0f : (a.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const float slopeB = b.act == CRFP_ACT_RELU ? 0.0f : (b.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    const float slopeC = c.act == CRFP_ACT_RELU ? 0.0f : (c.act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    act_t* const dst = as_act(c.dst) + (long long)n * c.dst_bstride;
+    const int dpitch = W + c.dst_pad;
+    act_t* const dst2 = c.dst2 ? as_act(c.dst2) + (long long)n * c.dst2_bstride : nullptr;
+    unsigned* const ovfw = dst2 ? ovf_word(c.ovf, c.ovf_div, c.ovf_add, n) : nullptr;
+    float vmax = 0.0f;
+
+    cu32x2 r[KST];
+    bool okr[KST];
+#define CRFP_CHAIN_LOAD(T, Q_)                                                                            \
+    {                                                                                                     \
+        const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * KCW, y0_ = ty_ * KCH;                \
+        _Pragma("unroll") for (int t = 0; t < KST; ++t) {                                                 \
+            const int idx = min(tid + 256 * t, KIW * KIH - 1);                                            \
+            const int rr = idx / KIW, cc = idx - rr * KIW;                                                \
+            const int gy = y0_ + rr - 3, gx = x0_ + cc - 3;                                               \
+            okr[t] = tid + 256 * t < KIW * KIH && gy >= 0 && gy < H && gx >= 0 && gx < W;                 \
+            const int cgy = min(max(gy, 0), H - 1), cgx = min(max(gx, 0), W - 1);                         \
+            if (qflow[Q_]) r[t] = raw_flow(qbase[Q_] + ((long long)cgy * W + cgx) * 8);                   \
+            else r[t] = *reinterpret_cast<const cu32x2*>(qbase[Q_] + ((long long)cgy * qpitch[Q_] + cgx) * 8); \
+        }                                                                                                 \
+    }
+#define CRFP_CHAIN_SYNC asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // NR rows of one input quad out of LDS tile SRC into acc[0 .. NR - 1]: rows R0 + i, column C0 of the stage's region
+    // (tap pair outer, rows inner: every accumulator still sees its tap pairs in order)
+#define CRFP_CHAIN_MFMA(SRC, QI, NR, R0, C0)                                                              \
+    _Pragma("unroll") for (int st = 0; st < 5; ++st) {                                                    \
+        const nb16x8 af_ = awl[(QI) * 5 + st][lane];                                                      \
+        _Pragma("unroll") for (int i = 0; i < (NR); ++i) {                                                \
+            const int t0 = 2 * st, t1_ = 2 * st + 1;                                                      \
+            const cu32x2 q0 = (SRC)[(R0) + i + t0 / 3][(C0) + t0 % 3];                                    \
+            const cu32x2 q1 = t1_ < 9 ? (SRC)[(R0) + i + t1_ / 3][(C0) + t1_ % 3] : cu32x2{0u, 0u};       \
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af_, __builtin_bit_cast(nb16x8, nu32x4{q0.x, q0.y, q1.x, q1.y}), acc[i], 0, 0, 0); \
+        }                                                                                                 \
+    }
+    const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+    const int band0 = xcd * xq + min(xcd, xr), band1 = band0 + xq + (xcd < xr ? 1 : 0);
+    const int t_step = ((int)gridDim.x - xcd + 7) >> 3;
+    int t_cur = band0 + (blockIdx.x >> 3);
+    if (t_cur >= band1) return;
+    CRFP_CHAIN_LOAD(t_cur, 0)
+    const int rB0 = min(5 * wave, KBH - 5), cB = min(lane, KBW - 1), cC = min(lane, KCW - 1);
+    for (;;) {
+        const int tyi = t_cur / tiles_x, x0 = (t_cur - tyi * tiles_x) * KCW, y0 = tyi * KCH;
+        const int t_next = t_cur + t_step;
+        f32x4 acc[5];
+        // ---- conv A: its global quads one after the other through buf0
+#pragma unroll
+        for (int k = 0; k < KQA; ++k) {
+#pragma unroll
+            for (int t = 0; t < KST; ++t) {
+                const int idx = tid + 256 * t;
+                if (idx < KIH * KIW) (&buf0[0][0])[idx] = okr[t] ? (qflow[k] ? flow_words(r[t]) : r[t]) : cu32x2{0u, 0u};
+            }
+            CRFP_CHAIN_SYNC
+            if (k + 1 < KQA) CRFP_CHAIN_LOAD(t_cur, k + 1)
+            else if (t_next < band1) CRFP_CHAIN_LOAD(t_next, 0)
+            if (k == 0) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[i] = f32x4{biasA.x, biasA.y, biasA.z, biasA.w};
+            }
+            CRFP_CHAIN_MFMA(buf0, k, 5, 5 * wave, lane)
+            CRFP_CHAIN_SYNC   // every wave is done reading buf0
+        }
+        // A's activated output -> t1 as the bf16 quads the three-launch path stores, zero outside the image
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int gy = y0 - 2 + 5 * wave + i, gx = x0 - 2 + lane;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            cf32x4 v;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) v[o] = (in && o < a.cout) ? fmaxf(acc[i][o], slopeA * acc[i][o]) * a.post_scale : 0.0f;
+            t1[5 * wave + i][lane] = quad_to_bits(v);
+        }
+        CRFP_CHAIN_SYNC
+        // ---- conv B out of t1 on the 18 x 62 region -> buf0
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = f32x4{biasB.x, biasB.y, biasB.z, biasB.w};
+        CRFP_CHAIN_MFMA(t1, KQA, 5, rB0, cB)
+        if (5 * wave < KBH && lane < KBW) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int row = rB0 + i;
+                if (row < 5 * wave) continue;
+                const int gy = y0 - 1 + row, gx = x0 - 1 + lane;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                cf32x4 v;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) v[o] = (in && o < b.cout) ? fmaxf(acc[i][o], slopeB * acc[i][o]) * b.post_scale : 0.0f;
+                buf0[row][lane] = quad_to_bits(v);
+            }
+        }
+        CRFP_CHAIN_SYNC
+        // ---- conv C on the 16 x 60 tile out of buf0, + A's output of the pixel (the residual block's x), + the new state
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{biasC.x, biasC.y, biasC.z, biasC.w};
+        CRFP_CHAIN_MFMA(buf0, KQA + 1, 4, 4 * wave, cC)
+        const int x = x0 + lane;
+        if (lane < KCW && x < W) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = y0 + 4 * wave + i;
+                if (y >= H) break;
+                float v[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) v[o] = o < c.cout ? fmaxf(acc[i][o], slopeC * acc[i][o]) * c.post_scale : 0.0f;
+                const cf32x4 rv = quad_from_bits(t1[4 * wave + i + 2][lane + 2]);
+                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                stq(dst + ((long long)y * dpitch + x) * 4, cf32x4{v[0], v[1], v[2], v[3]});
+                if (dst2) narrow_store_state(dst2, (long long)y * (W + 1) + x, cf32x4{v[0], v[1], v[2], v[3]}, vmax);
+            }
+        }
+        if (ovfw && !(vmax < 65504.0f)) { atomicOr(ovfw, 1u); vmax = 0.0f; }
+        if (t_next >= band1) break;
+        t_cur = t_next;
+        CRFP_CHAIN_SYNC   // buf0 and t1 are free for the next tile
+    }
+#undef CRFP_CHAIN_MFMA
+#undef CRFP_CHAIN_SYNC
+#undef CRFP_CHAIN_LOAD
+}
+
+// A -> B -> C in one launch (bf16 build: the residual chain only: C's one source is B's output, its residual A's output)
+int launch_narrow_chain(const NarrowArgs& a, const NarrowArgs& b, const NarrowArgs& c, bool res, const char* name, hipStream_t s) {
+    auto fast = [](const NarrowArgs& g) { return g.act != CRFP_ACT_TANH && g.act != CRFP_ACT_SIGMOID; };
+    if (!res || a.kq < 1 || a.kq > 2 || b.kq != 1 || c.kq != 1 || a.epi != NE_PLAIN || b.epi != NE_PLAIN || c.epi != NE_PLAIN || a.resid || b.resid ||
+        c.resid || a.dst2 || b.dst2 || !fast(a) || !fast(b) || !fast(c) || a.H != b.H || a.W != b.W || a.H != c.H || a.W != c.W) {
+        set_error("conv_narrow_chain %s: unsupported chain (kqA=%d kqB=%d kqC=%d res=%d)", name, a.kq, b.kq, c.kq, (int)res);
+        return CRFP_E_UNSUPPORTED;
+    }
+    double in_ch = 0;
+    for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].nch;
+    const double px = (double)a.N * a.H * a.W;
+    ProfScope prof(name, s, px * (in_ch + c.cout + (c.dst2 ? 4 : 0)) * (double)sizeof(act_t), 2.0 * px * 9.0 * (in_ch * a.cout + 4.0 * b.cout + 4.0 * c.cout));
+    const int ntl = ((a.W + KCW - 1) / KCW) * ((a.H + KCH - 1) / KCH);
+    const int share = (ntl + 256 * 3 - 1) / (256 * 3);
+    dim3 grid((ntl + share - 1) / share, 1, a.N);
+    if (a.kq == 1) conv3x3_narrow_chain_kernel<1><<<grid, 256, 0, s>>>(a, b, c);
+    else conv3x3_narrow_chain_kernel<2><<<grid, 256, 0, s>>>(a, b, c);
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+#endif
+
 int launch_narrow_pair(const NarrowArgs& a, const NarrowArgs& b, const char* name, hipStream_t s) {
     if (a.kq < 1 || a.kq > 3 || a.cout < 1 || a.cout > 4 || b.kq != 1 || b.cout < 1 || b.cout > 4 ||
         (b.epi != NE_PLAIN && b.epi != NE_OFFMASK3) || a.epi != NE_PLAIN || a.resid || a.act == CRFP_ACT_TANH ||

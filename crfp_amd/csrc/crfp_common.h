@@ -352,10 +352,8 @@ int launch_narrow_pack(const NarrowArgs& a, const float* w_oihw, const float* bi
 int launch_narrow(const NarrowArgs& a, const char* name, hipStream_t s);
 // a (NE_PLAIN, no residual) feeding b (one input quad = a's output; NE_PLAIN [+ residual] or NE_OFFMASK3) in one pass
 int launch_narrow_pair(const NarrowArgs& a, const NarrowArgs& b, const char* name, hipStream_t s);
-#ifndef CRFP_ACT_BF16
-// three stencils in one pass, fp32 build (conv_narrow.hip): a -> b -> c; res: c adds a's output (residual block)
+// three stencils in one pass (conv_narrow.hip): a -> b -> c; res: c adds a's output (residual block; the only form of the bf16 build)
 int launch_narrow_chain(const NarrowArgs& a, const NarrowArgs& b, const NarrowArgs& c, bool res, const char* name, hipStream_t s);
-#endif
 // gather.hip
 // src_pad = 1: x is P4 (padded planes, zero pads): validity logic replaced by clamping + hardware range check
 // N > 1: batch strides in elements of each tensor's own type (activations: act_t, flow: float)

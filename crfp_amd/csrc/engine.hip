@@ -707,7 +707,6 @@ struct Runner {
     // three stencils in one pass (fp32 build; conv_narrow.hip, launch_narrow_chain): items idA -> idB -> idC, the two tensors between them never
     // reach HBM.  gC: C's second source (its first is B's output); res: C adds A's output; dst2C: C's second destination (the new state)
     void narrow_chain(int idA, int idB, int idC, const char* name, int H, int W, std::vector<NB> srcsA, NB gC, NB dst, bool res, NB dst2C = NB()) {
-#ifndef CRFP_ACT_BF16
         if (rc) return;
         NarrowArgs a = M.items[idA].nw, b = M.items[idB].nw, c = M.items[idC].nw;
         for (size_t i = 0; i < srcsA.size(); ++i) { a.src[i].p = srcsA[i].p; a.src[i].bstride = srcsA[i].bs; a.src[i].pad = 0; }
@@ -720,7 +719,6 @@ struct Runner {
         c.dst2 = const_cast<float*>(dst2C.p); c.dst2_bstride = dst2C.bs;
         c.ovf = ovf(); c.ovf_div = ovf_div; c.ovf_add = ovf_add;
         rc = launch_narrow_chain(a, b, c, res, name, s);
-#endif
     }
 #ifndef CRFP_NARROW_CHAIN
 // bit 0: dcn_3's dcn_block.0 -> .2 -> conv_fuse, bit 1: forward_resblocks_3's main.0 -> conv1 -> conv2 (+ x).  Shipped: 2.  Same box, fp32 @A
@@ -731,10 +729,10 @@ struct Runner {
 #ifdef CRFP_LAB   // lab library: CRFP_NARROW_CHAIN=<mask> at run time (tests/test_gpu_round6.py compares the chains with the launches they replace)
     static int chain_mask() {
         static const int m = getenv("CRFP_NARROW_CHAIN") ? atoi(getenv("CRFP_NARROW_CHAIN")) : CRFP_NARROW_CHAIN;
-        return kActBf16 ? 0 : m;
+        return kActBf16 ? (m & 2) : m;   // (the bf16 build has the residual chain only)
     }
 #else
-    static constexpr int chain_mask() { return kActBf16 ? 0 : CRFP_NARROW_CHAIN; }
+    static constexpr int chain_mask() { return kActBf16 ? (CRFP_NARROW_CHAIN & 2) : CRFP_NARROW_CHAIN; }   // (the bf16 build has the residual chain only)
 #endif
     // which 8x-resolution conv pairs run fused (bit 0: encoder_hr.0->.2, 1: dcn_3 conv_fuse->offset/mask, 2: res3 conv1->conv2,
     // 3: dcn_3 block.0->.2).  Measured @A fp32, pair vs the two single kernels: res3 47.2 vs 57.8 us (bf16 46.7 vs 56.1);
