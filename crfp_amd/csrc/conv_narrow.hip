@@ -1332,22 +1332,24 @@ constexpr int KBW = KCW + 2, KBH = KCH + 2;
 constexpr int KIW = KCW + 6, KIH = KCH + 6;
 constexpr int KST = (KIH * KIW + 255) / 256;
 
-template <int KQA>
+template <int KQA, int KQG, bool RES>   // KQG: global quads of C behind its LDS quad (0 / 1); RES: C adds A's output (+ the second destination)
 __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const NarrowArgs a, const NarrowArgs b, const NarrowArgs c) {
+    static_assert(!(RES && KQG), "the residual chain has no global quad in C");
     __shared__ cu32x2 buf0[KIH][KIW];   // one global quad of A (22 x 66); later B's output (rows < 18, columns < 62)
-    __shared__ cu32x2 t1[KAH][KAW];     // A's output (20 x 64): B's input and C's residual
+    __shared__ cu32x2 t1[KAH][KAW];     // A's output (20 x 64): B's input; RES: C's residual; KQG: later C's global quad (rows < 18, columns < 62)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.z;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + KCW - 1) / KCW, ntiles = tiles_x * ((H + KCH - 1) / KCH);
-    const char* qbase[KQA];
-    int qpitch[KQA];
-    bool qflow[KQA];
+    const char* qbase[KQA + KQG];
+    int qpitch[KQA + KQG];
+    bool qflow[KQA + KQG];
 #pragma unroll
-    for (int k = 0; k < KQA; ++k) {
-        int kql = k, s = 0;
-        while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
-        const ConvSrc src = a.src[s];
+    for (int k = 0; k < KQA + KQG; ++k) {
+        const NarrowArgs& g = k < KQA ? a : c;
+        int kql = k < KQA ? k : 1, s = 0;
+        while (s < g.nsrc - 1 && kql >= g.src[s].nq) { kql -= g.src[s].nq; ++s; }
+        const ConvSrc src = g.src[s];
         qflow[k] = src.kind == SRC_FLOW2;
         qpitch[k] = W + src.pad;
         qbase[k] = qflow[k] ? reinterpret_cast<const char*>(src.p + (long long)n * src.bstride)
@@ -1357,7 +1359,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
     typedef __bf16 nb16x2 __attribute__((ext_vector_type(2)));
     typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
     // block-diagonal A fragments (conv3x3_narrow_kernel) of A's quads, B and C: built once per workgroup into LDS ([quad][tap pair][lane])
-    __shared__ nb16x8 awl[(KQA + 2) * 5][64];
+    __shared__ nb16x8 awl[(KQA + 2 + KQG) * 5][64];
     if (tid < 64) {
         const int cc_ = lane & 3;
         const bool diag = (lane >> 4) == ((lane & 15) >> 2);
@@ -1382,7 +1384,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
 #pragma unroll
         for (int k = 0; k < KQA; ++k) CRFP_CHAIN_FRAG(k, a.wpk, KQA, k, qflow[k])
         CRFP_CHAIN_FRAG(KQA, b.wpk, 1, 0, false)
-        CRFP_CHAIN_FRAG(KQA + 1, c.wpk, 1, 0, false)
+        CRFP_CHAIN_FRAG(KQA + 1, c.wpk, 1 + KQG, 0, false)
+        if (KQG) CRFP_CHAIN_FRAG(KQA + 2, c.wpk, 1 + KQG, 1, qflow[KQA + KQG - 1])
 #undef CRFP_CHAIN_FRAG
     }
     const float4 biasA = *reinterpret_cast<const float4*>(a.bpk), biasB = *reinterpret_cast<const float4*>(b.bpk),
@@ -1398,14 +1401,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
 
     cu32x2 r[KST];
     bool okr[KST];
-#define CRFP_CHAIN_LOAD(T, Q_)                                                                            \
+#define CRFP_CHAIN_LOAD(T, Q_, RW, RH, OFF)                                                               \
     {                                                                                                     \
         const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * KCW, y0_ = ty_ * KCH;                \
         _Pragma("unroll") for (int t = 0; t < KST; ++t) {                                                 \
-            const int idx = min(tid + 256 * t, KIW * KIH - 1);                                            \
-            const int rr = idx / KIW, cc = idx - rr * KIW;                                                \
-            const int gy = y0_ + rr - 3, gx = x0_ + cc - 3;                                               \
-            okr[t] = tid + 256 * t < KIW * KIH && gy >= 0 && gy < H && gx >= 0 && gx < W;                 \
+            const int idx = min(tid + 256 * t, (RW) * (RH) - 1);                                          \
+            const int rr = idx / (RW), cc = idx - rr * (RW);                                              \
+            const int gy = y0_ + rr - (OFF), gx = x0_ + cc - (OFF);                                       \
+            okr[t] = tid + 256 * t < (RW) * (RH) && gy >= 0 && gy < H && gx >= 0 && gx < W;               \
             const int cgy = min(max(gy, 0), H - 1), cgx = min(max(gx, 0), W - 1);                         \
             if (qflow[Q_]) r[t] = raw_flow(qbase[Q_] + ((long long)cgy * W + cgx) * 8);                   \
             else r[t] = *reinterpret_cast<const cu32x2*>(qbase[Q_] + ((long long)cgy * qpitch[Q_] + cgx) * 8); \
@@ -1429,7 +1432,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
     const int t_step = ((int)gridDim.x - xcd + 7) >> 3;
     int t_cur = band0 + (blockIdx.x >> 3);
     if (t_cur >= band1) return;
-    CRFP_CHAIN_LOAD(t_cur, 0)
+    CRFP_CHAIN_LOAD(t_cur, 0, KIW, KIH, 3)
     const int rB0 = min(5 * wave, KBH - 5), cB = min(lane, KBW - 1), cC = min(lane, KCW - 1);
     for (;;) {
         const int tyi = t_cur / tiles_x, x0 = (t_cur - tyi * tiles_x) * KCW, y0 = tyi * KCH;
@@ -1444,8 +1447,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
                 if (idx < KIH * KIW) (&buf0[0][0])[idx] = okr[t] ? (qflow[k] ? flow_words(r[t]) : r[t]) : cu32x2{0u, 0u};
             }
             CRFP_CHAIN_SYNC
-            if (k + 1 < KQA) CRFP_CHAIN_LOAD(t_cur, k + 1)
-            else if (t_next < band1) CRFP_CHAIN_LOAD(t_next, 0)
+            if (k + 1 < KQA) CRFP_CHAIN_LOAD(t_cur, k + 1, KIW, KIH, 3)
+            else if (KQG) CRFP_CHAIN_LOAD(t_cur, KQA, KBW, KBH, 1)
+            else if (t_next < band1) CRFP_CHAIN_LOAD(t_next, 0, KIW, KIH, 3)
             if (k == 0) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) acc[i] = f32x4{biasA.x, biasA.y, biasA.z, biasA.w};
@@ -1468,6 +1472,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
 #pragma unroll
         for (int i = 0; i < 5; ++i) acc[i] = f32x4{biasB.x, biasB.y, biasB.z, biasB.w};
         CRFP_CHAIN_MFMA(t1, KQA, 5, rB0, cB)
+        if (KQG) CRFP_CHAIN_SYNC   // t1 is about to receive C's global quad: every wave is done reading A's output
         if (5 * wave < KBH && lane < KBW) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -1481,11 +1486,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
                 buf0[row][lane] = quad_to_bits(v);
             }
         }
+        if (KQG) {
+#pragma unroll
+            for (int t = 0; t < KST; ++t) {
+                const int idx = tid + 256 * t, rr = idx / KBW, cc = idx - rr * KBW;
+                if (idx < KBH * KBW) t1[rr][cc] = okr[t] ? (qflow[KQA] ? flow_words(r[t]) : r[t]) : cu32x2{0u, 0u};
+            }
+            if (t_next < band1) CRFP_CHAIN_LOAD(t_next, 0, KIW, KIH, 3)
+        }
         CRFP_CHAIN_SYNC
         // ---- conv C on the 16 x 60 tile out of buf0, + A's output of the pixel (the residual block's x), + the new state
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{biasC.x, biasC.y, biasC.z, biasC.w};
         CRFP_CHAIN_MFMA(buf0, KQA + 1, 4, 4 * wave, cC)
+        if (KQG) CRFP_CHAIN_MFMA(t1, KQA + 2, 4, 4 * wave, cC)
         const int x = x0 + lane;
         if (lane < KCW && x < W) {
 #pragma unroll
@@ -1495,8 +1509,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
                 float v[4];
 #pragma unroll
                 for (int o = 0; o < 4; ++o) v[o] = o < c.cout ? fmaxf(acc[i][o], slopeC * acc[i][o]) * c.post_scale : 0.0f;
-                const cf32x4 rv = quad_from_bits(t1[4 * wave + i + 2][lane + 2]);
-                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                if (RES) {
+                    const cf32x4 rv = quad_from_bits(t1[4 * wave + i + 2][lane + 2]);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
                 stq(dst + ((long long)y * dpitch + x) * 4, cf32x4{v[0], v[1], v[2], v[3]});
                 if (dst2) narrow_store_state(dst2, (long long)y * (W + 1) + x, cf32x4{v[0], v[1], v[2], v[3]}, vmax);
             }
@@ -1511,23 +1527,34 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_chain_kernel(const Narr
 #undef CRFP_CHAIN_LOAD
 }
 
-// A -> B -> C in one launch (bf16 build: the residual chain only: C's one source is B's output, its residual A's output)
+// A -> B -> C in one launch.  C's sources: quad 0 = B's output, then (optionally) one global quad; res: C's residual is A's output.
 int launch_narrow_chain(const NarrowArgs& a, const NarrowArgs& b, const NarrowArgs& c, bool res, const char* name, hipStream_t s) {
     auto fast = [](const NarrowArgs& g) { return g.act != CRFP_ACT_TANH && g.act != CRFP_ACT_SIGMOID; };
-    if (!res || a.kq < 1 || a.kq > 2 || b.kq != 1 || c.kq != 1 || a.epi != NE_PLAIN || b.epi != NE_PLAIN || c.epi != NE_PLAIN || a.resid || b.resid ||
-        c.resid || a.dst2 || b.dst2 || !fast(a) || !fast(b) || !fast(c) || a.H != b.H || a.W != b.W || a.H != c.H || a.W != c.W) {
+    const int kqg = c.kq - 1;
+    if (a.kq < 1 || a.kq > 3 || b.kq != 1 || kqg < 0 || kqg > 1 || (res && kqg) || (res && a.kq > 2) || (!res && !kqg) || a.epi != NE_PLAIN || b.epi != NE_PLAIN ||
+        c.epi != NE_PLAIN || a.resid || b.resid || c.resid || a.dst2 || b.dst2 || !fast(a) || !fast(b) || !fast(c) || a.H != b.H || a.W != b.W || a.H != c.H ||
+        a.W != c.W || (kqg && c.src[1].kind != SRC_Q4)) {
         set_error("conv_narrow_chain %s: unsupported chain (kqA=%d kqB=%d kqC=%d res=%d)", name, a.kq, b.kq, c.kq, (int)res);
         return CRFP_E_UNSUPPORTED;
     }
     double in_ch = 0;
     for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].nch;
+    if (kqg) in_ch += c.src[1].nch;
     const double px = (double)a.N * a.H * a.W;
     ProfScope prof(name, s, px * (in_ch + c.cout + (c.dst2 ? 4 : 0)) * (double)sizeof(act_t), 2.0 * px * 9.0 * (in_ch * a.cout + 4.0 * b.cout + 4.0 * c.cout));
     const int ntl = ((a.W + KCW - 1) / KCW) * ((a.H + KCH - 1) / KCH);
     const int share = (ntl + 256 * 3 - 1) / (256 * 3);
     dim3 grid((ntl + share - 1) / share, 1, a.N);
-    if (a.kq == 1) conv3x3_narrow_chain_kernel<1><<<grid, 256, 0, s>>>(a, b, c);
-    else conv3x3_narrow_chain_kernel<2><<<grid, 256, 0, s>>>(a, b, c);
+    if (res) {
+        if (a.kq == 1) conv3x3_narrow_chain_kernel<1, 0, true><<<grid, 256, 0, s>>>(a, b, c);
+        else conv3x3_narrow_chain_kernel<2, 0, true><<<grid, 256, 0, s>>>(a, b, c);
+    } else {
+        switch (a.kq) {
+            case 1: conv3x3_narrow_chain_kernel<1, 1, false><<<grid, 256, 0, s>>>(a, b, c); break;
+            case 2: conv3x3_narrow_chain_kernel<2, 1, false><<<grid, 256, 0, s>>>(a, b, c); break;
+            default: conv3x3_narrow_chain_kernel<3, 1, false><<<grid, 256, 0, s>>>(a, b, c); break;
+        }
+    }
     CRFP_CHECK_LAUNCH();
     return 0;
 }

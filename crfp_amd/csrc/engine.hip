@@ -726,13 +726,16 @@ struct Runner {
 // stage (three input quads on 1.33x the pixels) makes it issue-bound at three workgroups per CU, so it stays three launches.
 #define CRFP_NARROW_CHAIN 2
 #endif
+#ifndef CRFP_NARROW_CHAIN_BF16
+#define CRFP_NARROW_CHAIN_BF16 3   // bf16 build: both chains (its block-diagonal MFMA makes the stages' extra pixels cheap: profiles/r06_narrow_chain_ab.txt)
+#endif
 #ifdef CRFP_LAB   // lab library: CRFP_NARROW_CHAIN=<mask> at run time (tests/test_gpu_round6.py compares the chains with the launches they replace)
     static int chain_mask() {
-        static const int m = getenv("CRFP_NARROW_CHAIN") ? atoi(getenv("CRFP_NARROW_CHAIN")) : CRFP_NARROW_CHAIN;
-        return kActBf16 ? (m & 2) : m;   // (the bf16 build has the residual chain only)
+        static const int m = getenv("CRFP_NARROW_CHAIN") ? atoi(getenv("CRFP_NARROW_CHAIN")) : (kActBf16 ? CRFP_NARROW_CHAIN_BF16 : CRFP_NARROW_CHAIN);
+        return m;
     }
 #else
-    static constexpr int chain_mask() { return kActBf16 ? (CRFP_NARROW_CHAIN & 2) : CRFP_NARROW_CHAIN; }   // (the bf16 build has the residual chain only)
+    static constexpr int chain_mask() { return kActBf16 ? CRFP_NARROW_CHAIN_BF16 : CRFP_NARROW_CHAIN; }
 #endif
     // which 8x-resolution conv pairs run fused (bit 0: encoder_hr.0->.2, 1: dcn_3 conv_fuse->offset/mask, 2: res3 conv1->conv2,
     // 3: dcn_3 block.0->.2).  Measured @A fp32, pair vs the two single kernels: res3 47.2 vs 57.8 us (bf16 46.7 vs 56.1);

@@ -27,11 +27,14 @@ def test_persistent_fused_dcn_is_bit_identical_to_the_two_kernel_path(storage):
 @pytest.mark.parametrize("env", [{"CRFP_NARROW_CHAIN": "0"}, {"CRFP_NARROW_CHAIN": "3"}, {"CRFP_NARROW_SEQ": "0", "CRFP_NARROW_CHAIN": "0"},
                                  {"CRFP_STATE_FROM_EPILOGUE": "0"}])
 @pytest.mark.parametrize("geom", [None, "33,47,3"])
-def test_round6_stencil_forms_are_bit_identical_to_the_launches_they_replace(env, geom):
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_round6_stencil_forms_are_bit_identical_to_the_launches_they_replace(env, geom, storage):
     """The 8x stencils of round 6 -- the quad-sequential kernels, forward_resblocks_3 (and, lab only, dcn_3's conv chain) as one launch, the new
     state written by the last conv's epilogue -- apply each conv's arithmetic in its single kernel's order: switching any of them off in the lab
     library (the product compiles the choice in) must not change one bit of the clip.  Geometries: the 20 x 36 golden clip (160 x 288 at 8x:
     ragged 60- and 64-pixel tiles, every tile touches a border) and 33 x 47 (264 x 376: interior tiles take the fast paths)."""
     base = {"CRFP_CHECK_GEOM": geom} if geom else {}
+    if storage == "bf16":   # the bf16 build ships both chains and the quad-sequential form of the multi-quad stencils
+        base["CRFP_CHECK_STORAGE"] = "bf16"
     assert _golden_check(base, lab=True, want="DIGEST") == _golden_check(dict(base, **env), lab=True, want="DIGEST")
     assert _golden_check(base, want="DIGEST") == _golden_check(base, lab=True, want="DIGEST")   # and the product computes the same clip
