@@ -503,145 +503,6 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_direct_kernel(const Narrow
 }
 #endif
 
-#ifdef CRFP_ACT_BF16
-// ---------------------------------------------------------------- quad-sequential form of the multi-quad stencils, bf16 storage (round 6)
-// The fp32 build's reasoning (below) holds here too: conv3x3_narrow_kernel<3> stages 28.5 KB of LDS and 157-168 VGPRs (two workgroups per CU by
-// its launch bound), <2> three.  Unit of work = (tile, input quad): ONE quad's halo in LDS (9.5 KB) and in the prefetch registers (10 VGPRs), the
-// A fragments of all quads resident (20 VGPRs each), the accumulators carried over the quads of a tile; the quad loop is unrolled, so the
-// fragments are indexed at compile time.  Per output row the block-diagonal MFMAs run in conv3x3_narrow_kernel's order (quad outer, then the five
-// tap pairs): bit-identical.
-template <int KQ>
-__global__ __launch_bounds__(256, KQ == 3 ? 3 : 4) void conv3x3_narrow_seq_kernel(const NarrowArgs a) {
-    __shared__ cu32x2 tile[NLH][NLW];
-    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    const int n = blockIdx.z;
-    const int H = a.H, W = a.W;
-    const int tiles_x = (W + NTW - 1) / NTW, ntiles = tiles_x * ((H + NTH - 1) / NTH);
-    const char* qbase[KQ];
-    int qpitch[KQ];
-    bool qflow[KQ];
-#pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-        int kql = k, s = 0;
-        while (s < a.nsrc - 1 && kql >= a.src[s].nq) { kql -= a.src[s].nq; ++s; }
-        const ConvSrc src = a.src[s];
-        qflow[k] = src.kind == SRC_FLOW2;
-        qpitch[k] = W + src.pad;
-        qbase[k] = qflow[k] ? reinterpret_cast<const char*>(src.p + (long long)n * src.bstride)
-                            : reinterpret_cast<const char*>(as_act(src.p) + (long long)n * src.bstride + (long long)kql * (H + src.pad) * qpitch[k] * 4);
-    }
-    typedef __bf16 nb16x8 __attribute__((ext_vector_type(8)));
-    typedef __bf16 nb16x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
-    nb16x8 aw[KQ][5];   // the block-diagonal A fragments (see conv3x3_narrow_kernel)
-    {
-        const int lane = tid & 63, c = lane & 3;
-        const bool diag = (lane >> 4) == ((lane & 15) >> 2);
-#pragma unroll
-        for (int k = 0; k < KQ; ++k)
-#pragma unroll
-            for (int st = 0; st < 5; ++st) {
-                nu32x4 wds;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int tap = 2 * st + hf;
-                    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (tap < 9) {
-#pragma unroll
-                        for (int comp = 0; comp < 4; ++comp) {
-                            const int cc = qflow[k] ? (comp & 1) : comp;
-                            const float wv = a.wpk[((tap * KQ + k) * 4 + cc) * 4 + c];
-                            v[comp] = diag ? wv : 0.0f;
-                        }
-                    }
-                    wds[2 * hf] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v[0], v[1]}, nb16x2));
-                    wds[2 * hf + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v[2], v[3]}, nb16x2));
-                }
-                aw[k][st] = __builtin_bit_cast(nb16x8, wds);
-            }
-    }
-    const float4 bias = *reinterpret_cast<const float4*>(a.bpk);
-    const int cout = a.cout, act = a.act;
-    const float slope = act == CRFP_ACT_RELU ? 0.0f : (act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
-    const float post = a.post_scale;
-    act_t* const dsta = as_act(a.dst) + (long long)n * a.dst_bstride;
-    const int dpitch = W + a.dst_pad;
-    const act_t* const resid = a.resid ? as_act(a.resid) + (long long)n * a.resid_bstride : nullptr;
-
-    cu32x2 r[NST];
-    bool okr[NST];
-#define CRFP_SEQ_LOAD(T, K_)                                                                              \
-    {                                                                                                     \
-        const int ty_ = (T) / tiles_x, x0_ = ((T) - ty_ * tiles_x) * NTW, y0_ = ty_ * NTH;                \
-        _Pragma("unroll") for (int t = 0; t < NST; ++t) {                                                 \
-            const int idx = min(tid + 256 * t, NLH * NLW - 1);                                            \
-            const int rr = idx / NLW, c = idx - rr * NLW;                                                 \
-            const int gy = y0_ + rr - 1, gx = x0_ + c - 1;                                                \
-            okr[t] = tid + 256 * t < NLH * NLW && gy >= 0 && gy < H && gx >= 0 && gx < W;                 \
-            const int cgy = min(max(gy, 0), H - 1), cgx = min(max(gx, 0), W - 1);                         \
-            if (qflow[K_]) r[t] = raw_flow(qbase[K_] + ((long long)cgy * W + cgx) * 8);                   \
-            else r[t] = *reinterpret_cast<const cu32x2*>(qbase[K_] + ((long long)cgy * qpitch[K_] + cgx) * 8); \
-        }                                                                                                 \
-    }
-    const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
-    const int band0 = xcd * xq + min(xcd, xr), band1 = band0 + xq + (xcd < xr ? 1 : 0);
-    const int t_step = ((int)gridDim.x - xcd + 7) >> 3;   // workgroups on this XCD
-    int t_cur = band0 + (blockIdx.x >> 3);
-    if (t_cur >= band1) return;
-    CRFP_SEQ_LOAD(t_cur, 0)
-    for (;;) {
-        const int t_next = t_cur + t_step;
-        f32x4 acc[4];
-#pragma unroll
-        for (int k = 0; k < KQ; ++k) {
-#pragma unroll
-            for (int t = 0; t < NST; ++t) {
-                const int idx = tid + 256 * t;
-                if (idx < NLH * NLW) (&tile[0][0])[idx] = okr[t] ? (qflow[k] ? flow_words(r[t]) : r[t]) : cu32x2{0u, 0u};
-            }
-            __syncthreads();
-            // the next unit flies during the MFMAs (and stores) below: the next quad of this tile, or quad 0 of the workgroup's next tile
-            if (k + 1 < KQ) CRFP_SEQ_LOAD(t_cur, k + 1)
-            else if (t_next < band1) CRFP_SEQ_LOAD(t_next, 0)
-            if (k == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = f32x4{bias.x, bias.y, bias.z, bias.w};
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int st = 0; st < 5; ++st) {
-                    const int t0 = 2 * st, t1 = 2 * st + 1;
-                    const cu32x2 q0 = tile[4 * ty + i + t0 / 3][tx + t0 % 3];
-                    const cu32x2 q1 = t1 < 9 ? tile[4 * ty + i + t1 / 3][tx + t1 % 3] : cu32x2{0u, 0u};
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[k][st], __builtin_bit_cast(nb16x8, nu32x4{q0.x, q0.y, q1.x, q1.y}), acc[i], 0, 0, 0);
-                }
-            if (k + 1 < KQ) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading this quad's tile
-        }
-        const int tyi = t_cur / tiles_x, x = (t_cur - tyi * tiles_x) * NTW + tx, y0 = tyi * NTH;
-        if (x < W) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int y = y0 + 4 * ty + i;
-                if (y >= H) break;
-                float v[4];
-#pragma unroll
-                for (int o = 0; o < 4; ++o) v[o] = o < cout ? fmaxf(acc[i][o], slope * acc[i][o]) * post : 0.0f;
-                if (resid) {
-                    const cf32x4 rv = ldq(resid + ((long long)y * W + x) * 4);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                }
-                stq(dsta + ((long long)y * dpitch + x) * 4, cf32x4{v[0], v[1], v[2], v[3]});
-            }
-        }
-        if (t_next >= band1) break;
-        t_cur = t_next;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-#undef CRFP_SEQ_LOAD
-}
-#endif
-
 #ifndef CRFP_ACT_BF16
 #ifndef CRFP_SEQ_FAST
 #define CRFP_SEQ_FAST 1   // A/B builds: 0 = the general loader / epilogue for every tile (quad-sequential and chain kernels)
@@ -1677,17 +1538,16 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     const int per_cu = per_cu_env > 0 ? per_cu_env : (a.kq == 1 ? CRFP_NARROW_OCC1 : (a.kq == 2 ? CRFP_NARROW_OCC2 : CRFP_NARROW_OCC3));
     const int share = (ntl + 256 * per_cu - 1) / (256 * per_cu);
     dim3 grid((ntl + share - 1) / share, 1, a.N);
+#ifndef CRFP_ACT_BF16
     {
-    // Round 6: the multi-quad plain stencils (dcn_3.dcn_block.0, dcn_3.conv_fuse, forward_resblocks_3.main.0) in the quad-sequential form
+    // Round 6: the plain stencils (dcn_3.dcn_block.0 / .2, dcn_3.conv_fuse; forward_resblocks_3 when its chain is off) in the quad-sequential form.
+    // (The bf16 build runs both 8x conv chains as one launch each -- conv3x3_narrow_chain_kernel -- and keeps conv3x3_narrow_kernel for the rest;
+    // a bf16 twin of this form measured dcn3.block0 42.1 -> 37.0 us before the chains superseded it: profiles/r06_narrow_seq_ab.txt.)
 #ifndef CRFP_NARROW_SEQ
 #define CRFP_NARROW_SEQ 1
 #endif
 #ifndef CRFP_NARROW_SEQ_MINKQ
-#ifdef CRFP_ACT_BF16
-#define CRFP_NARROW_SEQ_MINKQ 2   // bf16 build: the one-quad stencils keep conv3x3_narrow_kernel<1> (the same resources)
-#else
 #define CRFP_NARROW_SEQ_MINKQ 1   // the one-quad plain stencils too: the form carries the interior-tile fast path (A/B builds: 2)
-#endif
 #endif
 #ifdef CRFP_LAB   // lab library: CRFP_NARROW_SEQ=0 at run time keeps conv3x3_narrow_kernel for the plain stencils
     static const bool seq_on = getenv("CRFP_NARROW_SEQ") ? atoi(getenv("CRFP_NARROW_SEQ")) != 0 : CRFP_NARROW_SEQ != 0;
@@ -1695,12 +1555,7 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
     constexpr bool seq_on = CRFP_NARROW_SEQ != 0;
 #endif
     if (seq_on && !a.gate && !a.dst2 && a.epi == NE_PLAIN && a.kq >= CRFP_NARROW_SEQ_MINKQ && a.act != CRFP_ACT_TANH && a.act != CRFP_ACT_SIGMOID) {
-#ifdef CRFP_ACT_BF16
-        const int seq_occ = a.kq == 3 ? 3 : 4;   // workgroups per CU of conv3x3_narrow_seq_kernel<KQ> (its launch bound)
-#else
-        const int seq_occ = CRFP_NARROW_OCC1;
-#endif
-        const int share4 = (ntl + 256 * seq_occ - 1) / (256 * seq_occ);
+        const int share4 = (ntl + 256 * CRFP_NARROW_OCC1 - 1) / (256 * CRFP_NARROW_OCC1);
         dim3 grid4((ntl + share4 - 1) / share4, 1, a.N);
         if (a.kq == 1) conv3x3_narrow_seq_kernel<1><<<grid4, 256, 0, s>>>(a);
         else if (a.kq == 2) conv3x3_narrow_seq_kernel<2><<<grid4, 256, 0, s>>>(a);
@@ -1709,6 +1564,7 @@ int launch_narrow(const NarrowArgs& a_in, const char* name, hipStream_t s) {
         return 0;
     }
     }
+#endif
     if (a.gate) {   // mask-gated forms (engine.hip: encoder_hr and the fovea blend)
         if (a.epi == NE_PLAIN && a.kq == 1) conv3x3_narrow_kernel<1, NE_PLAIN, true><<<grid, 256, 0, s>>>(a);
         else if (a.epi == NE_PLAIN && a.kq == 2) conv3x3_narrow_kernel<2, NE_PLAIN, true><<<grid, 256, 0, s>>>(a);
