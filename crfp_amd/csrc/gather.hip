@@ -731,9 +731,11 @@ __device__ __forceinline__ void df_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // per CU, the weight stage double-buffered (one barrier per stage, half the L2 -> LDS weight and DCN-image traffic per pixel).
 // PS (round 6): the PERSISTENT form.  gridDim.x workgroups (one per CU) walk the tile list of the whole launch (all batch items), XCD x
 // taking the contiguous band x of it (xcd_band_tile's split).  The DCN weight image, the bias table and the kernel's registers are set up
-// once per workgroup instead of once per tile; the NEXT tile's halo tile and weight stage 0 are requested in the middle of the current
-// tile's last cout tile (their registers -- rt, rws -- are dead there) and go to LDS behind one barrier at the tile boundary, so only the
-// first tile of a workgroup pays the 80 KB prologue in front of its first MFMA.  Same per-pixel operations in the same order: bit-identical.
+// once per workgroup instead of once per tile; the NEXT tile's halo tile and weight stage 0 are requested in the schedule's tail behind the
+// last gather issue (their registers -- rt, rws -- are dead there; nothing queues behind them in the in-order vmcnt) and go to LDS behind one
+// barrier behind the last DCN MFMA, so only the first tile of a workgroup pays the 116 KB prologue in front of its first MFMA.  Same per-pixel
+// operations in the same order: bit-identical.  Used for launches of >= 6 rounds of the chip (launch_dcn_fused); below that the one-tile form
+// (PS = false, the same XCD-banded tile order) is 1-1.5 % faster (profiles/r06_dcn_fused_persistent_ab.txt).
 template <int NW, bool PS = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void dcn_fused_kernel(const DcnFuseArgs a) {
     constexpr int NT = 64 * NW, DF_NEL = (NW + 2) * DF_LW;   // halo tile of an NW x 32-pixel workgroup
