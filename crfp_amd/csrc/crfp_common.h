@@ -176,7 +176,8 @@ struct ConvArgs {
     // NaN when the word is set (sticky per clip / stream).  Null: not tracked (per-op API, strict fp32).
     unsigned* ovf;
     int ovf_div, ovf_add;   // which status word batch item n of the launch raises: ovf[(n + ovf_add) / ovf_div]; ovf_div == 0: ovf[0] (ovf_word())
-    int ovf_skip0;          // 1: items with (n + ovf_add) % ovf_div == 0 raise nothing (FNet's never-read pairs that straddle two clips)
+    int ovf_skip0;          // 1: items with (n + ovf_add) % ovf_div == 0 raise nothing (rounds 4-5: FNet's never-read pairs that straddled two clips; the engine
+                            // no longer launches those pairs -- src_bgroup below -- and leaves this 0)
     int strict;         // 1: plain fp32 MFMA for this launch (CRFP_DSV_STRICT_F32)
     int dst_f32;        // bf16 build, ST_Q4, one destination: store float quads (FNet's flow output stays fp32)
     int src_bgroup;     // > 0: batch item n of the launch READS source item n + n / src_bgroup (destinations, residual, flow and status words keep n):
