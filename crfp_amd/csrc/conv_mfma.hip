@@ -671,8 +671,10 @@ __device__ __forceinline__ void load_quad_batch_v(f32x4 (&r)[NIN], const ConvSrc
     }
 }
 
+// The kernel's body: workgroup wg_x of wg_nx (the launch's work items: (tile, cout-tile group)) of batch item n of plan a.  A function so that
+// conv3x3_split_dual_kernel (below) can run TWO plans in one launch.
 template <int CT, int RPW, int NP>
-__global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void conv3x3_split_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv3x3_split_body(const ConvArgs& a, const int wg_x, const int wg_nx, const int n) {
 #ifdef CRFP_LAB
     const long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -689,11 +691,10 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
     // 1-D grid over (tile, cout-tile group) with the groups of a tile adjacent, dealt to the XCDs in contiguous bands:
     // neighbouring tiles share their halo lines and the cout-tile groups of one tile re-read the same input in one L2
     const int ngrp = a.ctiles / CT;
-    const int bwork = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int bwork = xcd_band_tile(wg_x, wg_nx);
     const int btile = bwork / ngrp;
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = (bwork - btile * ngrp) * CT;
-    const int n = blockIdx.z;
     const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 
@@ -898,6 +899,25 @@ __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void c
     }
 #endif
 }
+
+template <int CT, int RPW, int NP>
+__global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void conv3x3_split_kernel(const ConvArgs a) {
+    conv3x3_split_body<CT, RPW, NP>(a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+}
+
+#ifndef CRFP_ACT_BF16
+// Round 6: TWO independent convs of the same shape in ONE launch (workgroups [0, w0) run plan a0, the rest plan a1; w0 is a multiple of 8, so a
+// workgroup keeps its XCD).  The engine's two 32 -> 64 pixel-shuffle convs behind level 2 (the x4 upsample of the propagated features, dcn_3's
+// pre-offset conv) are 1 800 four-wave workgroups each on the chip's 768 slots: 2.34 rounds paid as 3, twice; together 4.69 paid as 5
+// (a lock-step batch of 4 clips shows the same arithmetic: 41.0 -> 34.7 us per clip).  Two streams cost more in fork / join than they save
+// (profiles/r06_aux_stream_ab.txt).  Each plan's arithmetic is untouched: bit-identical.
+template <int CT, int RPW, int NP>
+__global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void conv3x3_split_dual_kernel(const ConvArgs a0, const ConvArgs a1, const int w0) {
+    const bool second = (int)blockIdx.x >= w0;   // workgroup-uniform
+    if (second) conv3x3_split_body<CT, RPW, NP>(a1, (int)blockIdx.x - w0, (int)gridDim.x - w0, (int)blockIdx.z);
+    else conv3x3_split_body<CT, RPW, NP>(a0, (int)blockIdx.x, w0, (int)blockIdx.z);
+}
+#endif
 
 // ---------------------------------------------------------------- f16x3, 8 waves, ONE accumulator ("f16x3s")
 // The 4-wave kernel above needs 164 VGPRs (two fp32 accumulators per pixel tile, hi and lo) = 3 waves per SIMD = 768 workgroup
@@ -2740,6 +2760,54 @@ int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s) {
     return 0;
 }
 
+
+// Two convs of the same shape in one launch (fp32 build: conv3x3_split_dual_kernel); anything it does not cover runs as two launches.
+int launch_conv_mfma_dual(const ConvArgs& a0, const char* name0, const ConvArgs& a1, const char* name1, const char* name_both, hipStream_t s) {
+#ifndef CRFP_ACT_BF16
+#ifndef CRFP_CONV_DUAL
+#define CRFP_CONV_DUAL 1   // A/B builds: 0 = always two launches
+#endif
+    auto plain_split = [](const ConvArgs& a) {
+        bool q4 = true;
+        for (int i = 0; i < a.nsrc; ++i) q4 = q4 && (a.src[i].kind == SRC_Q4 || a.src[i].kind == SRC_S3 || a.src[i].kind == SRC_ZERO);
+        return a.wsplit && !a.strict && !precision_env_strict(0) && (a.kq & 3) == 0 && a.kq <= CRFP_MAX_KQ && a.ctiles > 1 && q4 && a.ksplit == 0 && !a.s3_dst &&
+               (a.store != ST_PS || ((a.ps_r == 2 || a.ps_r == 4) && a.act != CRFP_ACT_TANH && a.act != CRFP_ACT_SIGMOID));
+    };
+    bool lab = false;
+#ifdef CRFP_LAB
+    lab = true;   // the lab library keeps its kernel-selection knobs: two launches
+#endif
+    if (CRFP_CONV_DUAL && !lab && plain_split(a0) && plain_split(a1) && a0.N == a1.N && a0.H == a1.H && a0.W == a1.W && a0.ctiles == a1.ctiles &&
+        conv_s3_supported()) {
+        const int tiles = ((a0.W + TW - 1) / TW) * ((a0.H + 3) / 4), w0 = tiles * a0.ctiles;
+        if ((w0 & 7) == 0) {
+            double bytes = 0, flops = 0;
+            for (const ConvArgs* a : {&a0, &a1}) {
+                double in_ch = 0;
+                for (int i = 0; i < a->nsrc; ++i) in_ch += a->src[i].kind == SRC_ZERO ? 0 : a->src[i].nch;
+                const double px = (double)a->N * a->H * a->W;
+                bytes += px * (in_ch + a->cout) * (double)sizeof(act_t) + (double)a->cout * in_ch * 9 * 4.0;
+                flops += 2.0 * px * a->cout * in_ch * 9.0;
+            }
+            ProfScope prof(name_both, s, bytes, flops);
+            ConvArgs* am[2] = {&const_cast<ConvArgs&>(a0), &const_cast<ConvArgs&>(a1)};   // callers pass private, mutable plan copies
+            const char* nm[2] = {name0, name1};
+            for (int k = 0; k < 2; ++k) {
+                am[k]->stamps = nullptr;
+                am[k]->wsplit16 = (const char*)am[k]->wsplit + conv_split16_offset_bytes(*am[k]);
+                am[k]->wsplit_sa = (const char*)am[k]->wsplit + conv_split_sa_offset_bytes(*am[k]);
+                const int rc = build_quad_descs(*am[k], nm[k]);
+                if (rc) return rc;
+            }
+            conv3x3_split_dual_kernel<1, 1, 2><<<dim3(2 * w0, 1, a0.N), 256, 0, s>>>(*am[0], *am[1], w0);
+            CRFP_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+#endif
+    const int rc = launch_conv_mfma(a0, name0, s);
+    return rc ? rc : launch_conv_mfma(a1, name1, s);
+}
 
 #ifdef CRFP_ACT_BF16
 // conv A -> conv B in one launch (conv3x3_bf16_pair_kernel); both plans as launch_conv_mfma takes them.  Conv A's output tensor is

@@ -338,6 +338,8 @@ size_t conv_packed_weight_floats(const ConvArgs& a);
 int launch_conv_pack(const ConvArgs& a, const float* w_oihw, const float* bias, const float* w2, const float* bias2,
                      int cout_split, float* wpk, float* bpk, hipStream_t s);
 int launch_conv_mfma(const ConvArgs& a, const char* name, hipStream_t s);
+// two convs of the same shape (N, H, W, cout tiles) in one launch where the build has the kernel for it (fp32: conv3x3_split_dual_kernel), else two launches
+int launch_conv_mfma_dual(const ConvArgs& a0, const char* name0, const ConvArgs& a1, const char* name1, const char* name_both, hipStream_t s);
 #ifdef CRFP_ACT_BF16
 // bf16 build: conv a (32 couts, no other reader of its output) feeding conv b (32 -> 32) in ONE launch, the tensor between them in LDS
 int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, const char* name, hipStream_t s);

@@ -622,6 +622,29 @@ struct Runner {
         a.strict = strict;
         rc = launch_conv_mfma(a, it.name, s);
     }
+    // the launch-time plan of item id as mfma() builds it
+    ConvArgs plan(int id, int N, int H, int W, const std::vector<SrcBind>& srcs, const std::vector<DstBind>& dsts, int dstH, int dstW) const {
+        const Item& it = M.items[id];
+        ConvArgs a = it.c;
+        for (size_t i = 0; i < srcs.size(); ++i) { a.src[i].p = srcs[i].p; a.src[i].bstride = srcs[i].bs; a.src[i].pad = srcs[i].pad; }
+        a.ndst = (int)dsts.size();
+        for (size_t i = 0; i < dsts.size(); ++i) {
+            a.dst[i].p = dsts[i].p; a.dst[i].bstride = dsts[i].bs; a.dst[i].q0 = dsts[i].q0; a.dst[i].q1 = dsts[i].q1;
+            a.dst[i].pad = dsts[i].pad;
+        }
+        a.N = N; a.H = H; a.W = W; a.dstH = dstH; a.dstW = dstW;
+        a.wpk = packed + it.off_w; a.bpk = packed + it.off_b; a.wsplit = packed + it.off_s;
+        a.ovf = ovf(); a.ovf_div = ovf_div; a.ovf_add = ovf_add; a.ovf_skip0 = ovf_skip0;
+        a.strict = strict;
+        return a;
+    }
+    // two independent convs of the same shape as ONE launch where the build can (conv_mfma.hip, launch_conv_mfma_dual)
+    void mfma_dual(int idA, std::vector<SrcBind> srcsA, std::vector<DstBind> dstsA, int idB, std::vector<SrcBind> srcsB, std::vector<DstBind> dstsB,
+                   int N, int H, int W, int dstH, int dstW, const char* name_both) {
+        if (rc) return;
+        ConvArgs a = plan(idA, N, H, W, srcsA, dstsA, dstH, dstW), b = plan(idB, N, H, W, srcsB, dstsB, dstH, dstW);
+        rc = launch_conv_mfma_dual(a, M.items[idA].name, b, M.items[idB].name, name_both, s);
+    }
     // fills the per-launch fields of a packed MFMA item's plan (what mfma() passes to launch_conv_mfma)
     ConvArgs bind(int id, int N, int H, int W, const std::vector<SrcBind>& srcs, const std::vector<DstBind>& dsts, const float* resid = nullptr,
                   long long resid_bs = 0) const {
@@ -1046,8 +1069,9 @@ struct Runner {
                 std::swap(prop_next, prop_other);
                 offprev = f;
             }
-            mfma(IT_UPP, B, H2, W2, {{prop, bs6}}, {{F(L.up), L.up.bs, 0, 1}}, H8, W8);
-            mfma(IT_POFF, B, H2, W2, {{offprev, bs8}}, {{F(L.poff), L.poff.bs, 0, 1}}, H8, W8);
+            // the two 32 -> 64 pixel-shuffle convs behind level 2 are independent: one launch (round 6; fp32 build)
+            mfma_dual(IT_UPP, {{prop, bs6}}, {{F(L.up), L.up.bs, 0, 1}}, IT_POFF, {{offprev, bs8}}, {{F(L.poff), L.poff.bs, 0, 1}}, B, H2, W2, H8, W8,
+                      "conv_mfma:upsample_post_ps4+dcn3.preoffset_ps4");
             const NB fl8(flow8, f8b);
             if (chain_mask() & 1)   // dcn_block.0 -> .2 -> conv_fuse in one launch (round 6)
                 narrow_chain(IT_D3B0, IT_D3B1, IT_D3FUSE, "conv_narrow_chain:dcn3.block0_block2_fuse", H8, W8, {nb(L.up), nb(L.prevhrw), fl8}, nb(L.poff),
