@@ -90,6 +90,12 @@ for _n in ("param_name", "param_numel", "packed_weight_bytes", "pack_weights", "
     SIGNATURES["crfp_cra_" + _n] = SIGNATURES["crfp_dsv_" + _n]
 for _n in ("packed_weight_bytes", "pack_weights", "batch_workspace_bytes", "batch_status_offset", "forward_batch"):
     SIGNATURES["crfp_cra_" + _n + "_bf16"] = SIGNATURES["crfp_dsv_" + _n]
+# the CRFP_simple / CRFP wirings (round 6): CRFP_DSV's parameter names, their own shapes / packed weights / workspace, the same forward call
+for _w in ("simple", "dense"):
+    for _n in ("param_numel", "packed_weight_bytes", "pack_weights", "batch_workspace_bytes", "batch_status_offset", "forward_batch"):
+        SIGNATURES[f"crfp_{_w}_{_n}"] = SIGNATURES["crfp_dsv_" + _n]
+        if _n != "param_numel":
+            SIGNATURES[f"crfp_{_w}_{_n}_bf16"] = SIGNATURES["crfp_dsv_" + _n]
 # bf16-storage twins of the engine entry points (same argument lists)
 for _n in ("crfp_dsv_packed_weight_bytes", "crfp_dsv_pack_weights", "crfp_dsv_workspace_bytes", "crfp_dsv_status_offset",
            "crfp_dsv_forward_clip", "crfp_dsv_stream_frame", "crfp_fnet_forward", "crfp_dsv_debug_fetch",

@@ -77,7 +77,24 @@ static inline int ci_dcn(int lvl, int which) {  // which: 0 fuse, 1 block.0, 2 b
 }
 static inline int ci_rb(int lvl, int which) { return 43 + 3 * lvl + which; }
 
-static int conv_cout(int ci, int y_only) { return (ci == CI_LAST && y_only) ? 1 : kConvs[ci].cout; }
+// Wirings of the recurrent chain one engine schedule exists for.  W_SIMPLE / W_DENSE: the reference's ablation models in front of CRFP_DSV --
+// CRFP_simple ("v13", model/CRFP.py:816-1099) and CRFP ("v15", :1101-1385) with mid_channels = 32, hr_dcn and offset_prop on: the same 59
+// convs under the same state_dict keys, four of them with other channel counts (`upsample` keeps all 32 features, nothing is carried
+// beside a level; the dense variant hands every residual block the warped previous state as a third input).
+enum Wiring { W_DSV = 0, W_CRA = 1, W_SIMPLE = 2, W_DENSE = 3 };
+static int conv_cin(int ci, int wiring = W_DSV) {
+    if (wiring >= W_SIMPLE) {
+        if (ci == CI_UPP) return 32;                                               // upsample_post reads all mid_channels (:877)
+        if (wiring == W_DENSE && (ci == 43 || ci == 46 || ci == 49)) return 96;   // forward_resblocks_k.main.0: mid_channels * 3 (:1138-1142)
+        if (wiring == W_DENSE && ci == CI_RB3) return 12;                         // forward_resblocks_3.main.0: last_channels * 3 (:1148)
+    }
+    return kConvs[ci].cin;
+}
+static int conv_cout(int ci, int y_only, int wiring = W_DSV) {
+    if (ci == CI_LAST && y_only) return 1;
+    if (wiring >= W_SIMPLE && ci == CI_UPS) return 128;                           // upsample: PixelShufflePack(mid, mid, 2) (:875)
+    return kConvs[ci].cout;
+}
 
 // ------------------------------------------------------------------ packed items
 enum ItemType { T_MFMA = 0, T_NARROW = 1, T_DCN8 = 2, T_RAW = 3 };
@@ -107,7 +124,7 @@ static inline int it_lvl(int lvl, int which) { return IT_LVL0 + 10 * lvl + which
 
 struct SrcSpec { int kind, nch; };
 
-static ConvArgs make_mfma(int y_only, int ci, int ci2, std::vector<SrcSpec> srcs, int store, int ps_r, int act,
+static ConvArgs make_mfma(int y_only, int wiring, int ci, int ci2, std::vector<SrcSpec> srcs, int store, int ps_r, int act,
                           float post_scale, int cbase_override = -1) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -132,8 +149,8 @@ static ConvArgs make_mfma(int y_only, int ci, int ci2, std::vector<SrcSpec> srcs
         kq += d.nq;
     }
     a.kq = kq;
-    a.cin_total = kConvs[ci].cin;
-    a.cout = conv_cout(ci, y_only) + (ci2 >= 0 ? conv_cout(ci2, y_only) : 0);
+    a.cin_total = conv_cin(ci, wiring);
+    a.cout = conv_cout(ci, y_only, wiring) + (ci2 >= 0 ? conv_cout(ci2, y_only, wiring) : 0);
     a.store = store;
     a.ps_r = ps_r;
     a.act = act;
@@ -142,7 +159,7 @@ static ConvArgs make_mfma(int y_only, int ci, int ci2, std::vector<SrcSpec> srcs
     return a;
 }
 
-static NarrowArgs make_narrow(int y_only, int ci, int ci2, std::vector<SrcSpec> srcs, int act, int epi) {
+static NarrowArgs make_narrow(int y_only, int wiring, int ci, int ci2, std::vector<SrcSpec> srcs, int act, int epi) {
     NarrowArgs a;
     memset(&a, 0, sizeof(a));
     int kq = 0, cbase = 0;
@@ -156,8 +173,8 @@ static NarrowArgs make_narrow(int y_only, int ci, int ci2, std::vector<SrcSpec> 
         kq += d.nq;
     }
     a.kq = kq;
-    a.cin_total = kConvs[ci].cin;
-    a.cout = conv_cout(ci, y_only) + (ci2 >= 0 ? conv_cout(ci2, y_only) : 0);
+    a.cin_total = conv_cin(ci, wiring);
+    a.cout = conv_cout(ci, y_only, wiring) + (ci2 >= 0 ? conv_cout(ci2, y_only, wiring) : 0);
     a.act = act;
     a.epi = epi;
     a.y_only = y_only;
@@ -171,6 +188,9 @@ struct Model {
     int y_only = 0;
     bool use_s3 = false;   // producer-split SRC_S3 edges (default precision only); packed weights are identical either way
     bool cra = false;      // the CRFP_DSV_CRA wiring: 13 more convs behind the CRFP_DSV ones
+    int wiring = W_DSV;
+    bool abl() const { return wiring >= W_SIMPLE; }     // CRFP_simple / CRFP: all 32 features travel through the levels, no carried ones
+    bool dense() const { return wiring == W_DENSE; }
 
     void add_mfma(int id, const char* name, int ci, int ci2, std::vector<SrcSpec> srcs, int store, int ps_r, int act,
                   float post_scale = 1.0f) {
@@ -179,7 +199,7 @@ struct Model {
         it.name = name;
         it.w1 = ci;
         it.w2 = ci2;
-        it.c = make_mfma(y_only, ci, ci2, srcs, store, ps_r, act, post_scale);
+        it.c = make_mfma(y_only, wiring, ci, ci2, srcs, store, ps_r, act, post_scale);
         it.n_w = conv_packed_weight_floats(it.c);
         it.n_b = (size_t)it.c.ctiles * 32;
         it.n_s = conv_split_weight_bytes(it.c) / sizeof(float);
@@ -190,13 +210,14 @@ struct Model {
         it.name = name;
         it.w1 = ci;
         it.w2 = ci2;
-        it.nw = make_narrow(y_only, ci, ci2, srcs, act, epi);
+        it.nw = make_narrow(y_only, wiring, ci, ci2, srcs, act, epi);
         it.n_w = narrow_packed_weight_floats(it.nw);
         it.n_b = 4;
     }
 
-    Model(int y_only_, bool use_s3_, bool cra_ = false) : y_only(y_only_), use_s3(use_s3_), cra(cra_) {
+    Model(int y_only_, bool use_s3_, int wiring_ = W_DSV) : y_only(y_only_), use_s3(use_s3_), cra(wiring_ == W_CRA), wiring(wiring_) {
         const int Q = SRC_Q4;
+        typedef std::vector<SrcSpec> Srcs;
         static const char* fn[14] = {"conv_mfma:fnet.enc1a", "conv_mfma:fnet.enc1b", "conv_mfma:fnet.enc2a",
                                      "conv_mfma:fnet.enc2b", "conv_mfma:fnet.enc3a", "conv_mfma:fnet.enc3b",
                                      "conv_mfma:fnet.dec1a", "conv_mfma:fnet.dec1b", "conv_mfma:fnet.dec2a",
@@ -222,8 +243,9 @@ struct Model {
                 add_mfma(it_lvl(l, L_FUSE), "conv_mfma:dcn.conv_fuse", ci_dcn(l, 0), -1, {{Q, 32}, {FS, 32}}, ST_Q4, 0,
                          CRFP_ACT_LRELU01);
             // dcn_block.0 input = [cur = prop(24) | carry(8)] | warped prev(32) | flow(2)   (:331,1586)
+            // CRFP_simple / CRFP: cur(32) | warped prev(32) | flow(2)   (:1029)
             add_mfma(it_lvl(l, L_DB0), "conv_mfma:dcn.block0", ci_dcn(l, 1), -1,
-                     {{Q, 24}, {Q, 8}, {Q, 32}, {SRC_FLOW2, 2}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+                     abl() ? Srcs{{Q, 32}, {Q, 32}, {SRC_FLOW2, 2}} : Srcs{{Q, 24}, {Q, 8}, {Q, 32}, {SRC_FLOW2, 2}}, ST_Q4, 0, CRFP_ACT_LRELU01);
             add_mfma(it_lvl(l, L_DB1), "conv_mfma:dcn.block2", ci_dcn(l, 2), -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_LRELU01);
             add_mfma(it_lvl(l, L_OM), "conv_mfma:dcn.offset_mask", ci_dcn(l, 3), ci_dcn(l, 4), {{FS, 32}}, ST_OFFMASK, 0,
                      CRFP_ACT_NONE);
@@ -238,14 +260,15 @@ struct Model {
             dw.n_w = 2 * 36 * 2 * 32 * 4;   // fp32 MFMA image (strict), then the split-fp16 image (default), 36 KB each
             dw.n_b = 32;
             // resblocks input = [prop(24) | carry(8)] | aligned(32)   (:1589); first frame: prop only (:1637)
-            add_mfma(it_lvl(l, L_RB0), "conv_mfma:res.main0", ci_rb(l, 0), -1, {{Q, 24}, {Q, 8}, {Q, 32}}, ST_Q4, 0,
-                     CRFP_ACT_LRELU01);
-            add_mfma(it_lvl(l, L_RB0F), "conv_mfma:res.main0_first", ci_rb(l, 0), -1, {{Q, 24}}, ST_Q4, 0,
+            // CRFP_simple: cur(32) | aligned(32) (:1034); CRFP: + the warped previous state (32) (:1311); first frame: cur only (:967, zeros behind it)
+            add_mfma(it_lvl(l, L_RB0), "conv_mfma:res.main0", ci_rb(l, 0), -1,
+                     dense() ? Srcs{{Q, 32}, {Q, 32}, {Q, 32}} : abl() ? Srcs{{Q, 32}, {Q, 32}} : Srcs{{Q, 24}, {Q, 8}, {Q, 32}}, ST_Q4, 0, CRFP_ACT_LRELU01);
+            add_mfma(it_lvl(l, L_RB0F), "conv_mfma:res.main0_first", ci_rb(l, 0), -1, abl() ? Srcs{{Q, 32}} : Srcs{{Q, 24}}, ST_Q4, 0,
                      CRFP_ACT_LRELU01);
             add_mfma(it_lvl(l, L_RB1), "conv_mfma:res.conv1", ci_rb(l, 1), -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_RELU);
             add_mfma(it_lvl(l, L_RB2), "conv_mfma:res.conv2_add", ci_rb(l, 2), -1, {{Q, 32}}, ST_Q4, 0, CRFP_ACT_NONE);
         }
-        add_mfma(IT_UPP, "conv_mfma:upsample_post_ps4", CI_UPP, -1, {{Q, 24}}, ST_PS, 4, CRFP_ACT_LRELU01);
+        add_mfma(IT_UPP, "conv_mfma:upsample_post_ps4", CI_UPP, -1, abl() ? Srcs{{Q, 32}} : Srcs{{Q, 24}}, ST_PS, 4, CRFP_ACT_LRELU01);
         add_mfma(IT_POFF, "conv_mfma:dcn3.preoffset_ps4", CI_D3_UPS, -1, {{FS, 32}}, ST_PS, 4, CRFP_ACT_NONE, 2.0f);
         add_narrow(IT_EH0, "conv_narrow:enc_hr0", CI_ENC_HR0, -1, {{Q, 3}, {Q, 3}}, CRFP_ACT_LRELU01, NE_PLAIN);
         add_narrow(IT_EH1, "conv_narrow:enc_hr1", CI_ENC_HR1, -1, {{Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
@@ -260,7 +283,7 @@ struct Model {
         d3.w1 = CI_D3_DCN;
         d3.n_w = 4 * 4 * 9;
         d3.n_b = 4;
-        add_narrow(IT_R3_0, "conv_narrow:res3.main0", CI_RB3, -1, {{Q, 4}, {Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
+        add_narrow(IT_R3_0, "conv_narrow:res3.main0", CI_RB3, -1, dense() ? Srcs{{Q, 4}, {Q, 4}, {Q, 4}} : Srcs{{Q, 4}, {Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
         add_narrow(IT_R3_0F, "conv_narrow:res3.main0_first", CI_RB3, -1, {{Q, 4}}, CRFP_ACT_LRELU01, NE_PLAIN);
         add_narrow(IT_R3_1, "conv_narrow:res3.conv1", CI_RB3 + 1, -1, {{Q, 4}}, CRFP_ACT_RELU, NE_PLAIN);
         add_narrow(IT_R3_2, "conv_narrow:res3.conv2_add", CI_RB3 + 2, -1, {{Q, 4}}, CRFP_ACT_NONE, NE_PLAIN);
@@ -295,15 +318,19 @@ struct Model {
 };
 
 // strict: the fp32-MFMA wiring (no SRC_S3 edges); same packed-weight layout as the default wiring
-static const Model& model_for(int y_only, bool strict = false, bool cra = false) {
-    if (cra) {
-        static const Model m0(0, false, true), m1(1, false, true), s0(0, true, true), s1(1, true, true);
-        if (strict || !conv_s3_supported()) return y_only ? m1 : m0;
-        return y_only ? s1 : s0;
-    }
-    static const Model m0(0, false), m1(1, false), s0(0, true), s1(1, true);
+template <int WIRING>
+static const Model& model_of(int y_only, bool strict) {
+    static const Model m0(0, false, WIRING), m1(1, false, WIRING), s0(0, true, WIRING), s1(1, true, WIRING);
     if (strict || !conv_s3_supported()) return y_only ? m1 : m0;
     return y_only ? s1 : s0;
+}
+static const Model& model_for(int y_only, bool strict = false, int wiring = W_DSV) {
+    switch (wiring) {
+        case W_CRA: return model_of<W_CRA>(y_only, strict);
+        case W_SIMPLE: return model_of<W_SIMPLE>(y_only, strict);
+        case W_DENSE: return model_of<W_DENSE>(y_only, strict);
+        default: return model_of<W_DSV>(y_only, strict);
+    }
 }
 
 // ------------------------------------------------------------------ workspace arena
@@ -370,13 +397,14 @@ struct Layout {
     // CRFP_DSV_CRA: slice1's output, the 2x chain's two temporaries, the three fovea levels per buffer set, a level's features and their fused twin
     Ten c_s1, c_a, c_b, c_lv[2][3], c_y, c_f;
     bool cra;
+    int pq;   // quads of the features a level passes on: 6 (CRFP_DSV: 24 + 8 carried beside the level) or 8 (CRFP_simple / CRFP)
     // mask gate of each buffer set: 4 flag bytes per 64 x 16 tile of the 8x map and clip (launch_mask_gate); gate_b = bytes per clip
     Ten gate[2];
     long long gate_b;
     int h1, w1, h2, w2, h3, w3;
     int fnet_cap;   // pairs one FNet pass can hold
 
-    Layout(int B_, int t_, int h_, int w_, bool cra_ = false) : B(B_), t(t_), h(h_), w(w_), cra(cra_) {
+    Layout(int B_, int t_, int h_, int w_, int wiring = W_DSV) : B(B_), t(t_), h(h_), w(w_), cra(wiring == W_CRA), pq(wiring >= W_SIMPLE ? 8 : 6) {
         flat = (long long)B * t <= kFlatFrames;
         TC = flat ? t : kChunkFrames;
         // pairs one FNet pass holds: all of a flat job's (the B - 1 straddling ones included); one per sequence for the one-frame-per-call layout
@@ -421,15 +449,15 @@ struct Layout {
             xin8[p] = A.take(p ? "xin8.1" : "xin8", B, 2, H8, W8);
             eh[p] = A.take(p ? "enc_hr0.1" : "enc_hr0", B, 1, H8, W8);
             x_hr[p] = A.take(p ? "x_hr.1" : "x_hr", B, 1, H8, W8);
-            prop0[p] = A.take(p ? "prop0.1" : "prop0", B, 6, H2, W2);
+            prop0[p] = A.take(p ? "prop0.1" : "prop0", B, pq, H2, W2);
             flow2[p] = A.take(p ? "flow2.1" : "flow2", B, 0, H2, W2, 1);
             flow8[p] = A.take(p ? "flow8.1" : "flow8", B, 0, H8, W8, 1);
             const int gtiles = ((W8 + 63) / 64) * ((H8 + 15) / 16);
             gate_b = ((long long)gtiles * 4 + 7) / 8 * 8;
             gate[p] = A.take(p ? "gate.1" : "gate", B, 0, 1, (int)(gate_b / 8), 1);
         }
-        prop_a = A.take("prop_a", B, 6, H2, W2);
-        prop_b = A.take("prop_b", B, 6, H2, W2);
+        prop_a = A.take("prop_a", B, pq, H2, W2);
+        prop_b = A.take("prop_b", B, pq, H2, W2);
         prev2 = A.take("prev2", B, 8, H2, W2, 0, 1);
         prev2w = A.take("prev2w", B, 8, H2, W2);
         prevhrw = A.take("prevhrw", B, 1, H8, W8);
@@ -904,6 +932,7 @@ struct Runner {
         const long long P2q = (long long)H2 * W2 * 4, P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;
         std::vector<DstBind> dsts = {{prop_next, 6 * P2q, 0, 6}, {carry_l, 6 * P2qp, 6, 8, 1}};
         if (M.cra) dsts = {{F(L.c_y), L.c_y.bs, 0, 8}};
+        if (M.abl()) dsts = {{prop_next, 8 * P2q, 0, 8}};   // CRFP_simple / CRFP: all 32 channels are the next level's features
 #ifdef CRFP_ACT_BF16
         if (pair_convs())
             mfma_pair(it_lvl(l, L_RB1), it_lvl(l, L_RB2), "conv_mfma_pair:res.conv1_conv2_add", B, H2, W2, {{F(L.y0), L.y0.bs}}, dsts, F(L.y0), L.y0.bs);
@@ -981,7 +1010,7 @@ struct Runner {
                 mfma_q(IT_C_LV0, B, b, lv(0));
             }
             if (before_ups && !rc && hipStreamWaitEvent(s, before_ups, 0) != hipSuccess) { set_error("dsv: hipStreamWaitEvent failed"); rc = 1; }
-            mfma(IT_UPS, B, h, w, {{io.x_lr, io.x_b}}, {{F(L.prop0[par]), L.prop0[par].bs, 0, 6}}, H2, W2);
+            mfma(IT_UPS, B, h, w, {{io.x_lr, io.x_b}}, {{F(L.prop0[par]), L.prop0[par].bs, 0, L.pq}}, H2, W2);
         }
         if (!first && (parts & 2)) {
             RUN(crfp::launch_upflow(io.flow_lr, io.flow_b, F(L.flow2[par]), L.flow2[par].bs, B, h, w, 2, s));
@@ -999,37 +1028,48 @@ struct Runner {
         const int h = L.h, w = L.w, H2 = 2 * h, W2 = 2 * w, H8 = 8 * h, W8 = 8 * w, B = L.B;
         const long long P2q = (long long)H2 * W2 * 4;
         const long long P2qp = (long long)(H2 + 1) * (W2 + 1) * 4;   // padded (P4) plane at 2x resolution
-        const long long bs6 = 6 * P2q, bs8 = 8 * P2q;
+        const long long bs8 = 8 * P2q;
+        const long long bs6 = L.pq * P2q;   // batch stride of the features a level passes on (prop*): 6 quads, CRFP_simple / CRFP 8
+        const bool abl = M.abl(), dense = M.dense();
         float* prop = F(L.prop0[par]);
         float* prop_next = F(L.prop_a);
         float* prop_other = F(L.prop_b);
         float* carry = F(L.carry);
         auto nb = [&](const Ten& tn) { return NB(F(tn), tn.bs); };
         std::vector<NB> r3_srcs;   // inputs of forward_resblocks_3.main.0
+        // forward_resblocks_3 as one launch; the bf16 chain kernel takes at most two input quads (CRFP's three: three launches there)
+        const bool r3_chain = (chain_mask() & 2) && !(kActBf16 && dense && !first);
         if (!first) {
             float* flow2 = F(L.flow2[par]);
             float* flow8 = F(L.flow8[par]);
             const long long f2b = L.flow2[par].bs, f8b = L.flow8[par].bs;
             if (!down_done) downsample_state();
+            if (abl) {
+                // CRFP_simple / CRFP (model/CRFP.py:1021-1026): the state is warped at 8x FIRST and both versions are brought to 2x by `downsample`
+                RUN(launch_flow_warp_q4(F(L.state_hr), L.state_hr.bs, flow8, f8b, F(L.prevhrw), L.prevhrw.bs, B, 1, H8, W8, 0, 1, s));
+                mfma(IT_DOWN, B, H2, W2, {{F(L.prevhrw), L.prevhrw.bs, 0}}, {{F(L.prev2w), L.prev2w.bs, 0, 8}});
+            } else {
             WarpDualStrides wb;
             wb.xa = L.prev2.bs; wb.xb = L.carry.bs; wb.flow = f2b; wb.outa = L.prev2w.bs; wb.outb = L.carryw.bs;
             RUN(launch_flow_warp_p4_dual_8_6(F(L.prev2), carry, flow2, F(L.prev2w), F(L.carryw), H2, W2, s, B, wb));
             RUN(launch_flow_warp_q4(F(L.state_hr), L.state_hr.bs, flow8, f8b, F(L.prevhrw), L.prevhrw.bs, B, 1, H8, W8, 0, 1, s));
+            }
             const float* offprev = nullptr;
             if (fg) RUN(crfp::launch_fg_prep(fg, F(L.fg2), H8, W8, s));
             for (int l = 0; l < 3; ++l) {
                 const float* cw = adv(F(L.carryw), 2 * l * P2q);
                 float* f = F(L.offfeat[l]);
                 const bool s3 = M.use_s3;   // f holds the SRC_S3 image (same size) instead of fp32 Q4
+                // dcn_block.0's inputs: [features | carried] | warped previous state | flow; CRFP_simple / CRFP: features (32) | warped | flow
+                const std::vector<SrcBind> db0 = abl ? std::vector<SrcBind>{{prop, bs6}, {F(L.prev2w), bs8}, {flow2, f2b}, {nullptr, 0}}
+                                                     : std::vector<SrcBind>{{prop, bs6}, {cw, bs6}, {F(L.prev2w), bs8}, {flow2, f2b}, {nullptr, 0}};
 #ifdef CRFP_ACT_BF16
                 if (pair_convs())   // dcn_block.0 -> .2 in one launch, the 32-channel tensor between them stays in LDS
-                    mfma_pair(it_lvl(l, L_DB0), it_lvl(l, L_DB1), "conv_mfma_pair:dcn.block0_block2", B, H2, W2,
-                              {{prop, bs6}, {cw, bs6}, {F(L.prev2w), bs8}, {flow2, f2b}, {nullptr, 0}}, {{l == 0 ? f : F(L.fb), bs8, 0, 8}});
+                    mfma_pair(it_lvl(l, L_DB0), it_lvl(l, L_DB1), "conv_mfma_pair:dcn.block0_block2", B, H2, W2, db0, {{l == 0 ? f : F(L.fb), bs8, 0, 8}});
                 else
 #endif
                 {
-                mfma(it_lvl(l, L_DB0), B, H2, W2, {{prop, bs6}, {cw, bs6}, {F(L.prev2w), bs8}, {flow2, f2b}, {nullptr, 0}},
-                     {{F(L.fa), bs8, 0, 8}});
+                mfma(it_lvl(l, L_DB0), B, H2, W2, db0, {{F(L.fa), bs8, 0, 8}});
                 if (l == 0) {
                     if (s3) mfma(it_lvl(l, L_DB1), B, H2, W2, {{F(L.fa), bs8}}, {}, 0, 0, nullptr, 0, nullptr, 0, f, bs8);
                     else mfma(it_lvl(l, L_DB1), B, H2, W2, {{F(L.fa), bs8}}, {{f, bs8, 0, 8}});
@@ -1062,6 +1102,10 @@ struct Runner {
                     RUN(launch_scale_q4(cw, 0, F(L.sc_cw), 2, H2, W2, F(L.fg2), nullptr, s));
                     RUN(launch_scale_q4(F(L.aligned), 0, F(L.sc_al), 8, H2, W2, F(L.fg2), nullptr, s));
                     mfma(it_lvl(l, L_RB0), 1, H2, W2, {{F(L.sc_prop), 0}, {F(L.sc_cw), 0}, {F(L.sc_al), 0}}, {{F(L.y0), 0, 0, 8}});
+                } else if (abl) {   // cat(cur, aligned) (:1034); CRFP: + the warped previous state (:1311)
+                    std::vector<SrcBind> rb = {{prop, bs6}, {F(L.aligned), bs8}};
+                    if (dense) rb.push_back({F(L.prev2w), bs8});
+                    mfma(it_lvl(l, L_RB0), B, H2, W2, rb, {{F(L.y0), bs8, 0, 8}});
                 } else
                     mfma(it_lvl(l, L_RB0), B, H2, W2, {{prop, bs6}, {cw, bs6}, {F(L.aligned), bs8}}, {{F(L.y0), bs8, 0, 8}});
                 res_block(l, prop_next, adv(carry, 2 * l * P2qp), H2, W2, par, io.mk, io.mk_b);
@@ -1105,7 +1149,8 @@ struct Runner {
                 r3_srcs = {nb(L.sc_up), nb(L.sc_al3)};
             } else
                 r3_srcs = {nb(L.up), nb(L.al3)};
-            if (!(chain_mask() & 2)) narrow(IT_R3_0, H8, W8, r3_srcs, nb(L.z0));
+            if (dense) r3_srcs.push_back(nb(L.prevhrw));   // CRFP (:1316): + the warped previous state
+            if (!r3_chain) narrow(IT_R3_0, H8, W8, r3_srcs, nb(L.z0));
         } else {
             for (int l = 0; l < 3; ++l) {
                 mfma(it_lvl(l, L_RB0F), B, H2, W2, {{prop, bs6}, {nullptr, 0}}, {{F(L.y0), bs8, 0, 8}});
@@ -1115,12 +1160,12 @@ struct Runner {
             }
             mfma(IT_UPP, B, H2, W2, {{prop, bs6}}, {{F(L.up), L.up.bs, 0, 1}}, H8, W8);
             r3_srcs = {nb(L.up)};
-            if (!(chain_mask() & 2)) narrow(IT_R3_0F, H8, W8, r3_srcs, nb(L.z0));
+            if (!r3_chain) narrow(IT_R3_0F, H8, W8, r3_srcs, nb(L.z0));
         }
         // gated: the state is lrelu(feat) wherever the mask is clear -- written by the epilogue of forward_resblocks_3's last conv (round 6: its second
         // destination; it was a separate streaming pass over the 8x map, 21 us per frame) -- and the blend kernel rewrites the tiles with mask pixels
         const NB st2 = mask_gate_enabled() && state_from_epilogue() ? nb(L.state_hr) : NB();
-        if (chain_mask() & 2)   // main.0 -> conv1 -> conv2 (+ x) in one launch (round 6)
+        if (r3_chain)   // main.0 -> conv1 -> conv2 (+ x) in one launch (round 6)
             narrow_chain(first ? IT_R3_0F : IT_R3_0, IT_R3_1, IT_R3_2, "conv_narrow_chain:res3.main0_conv1_conv2_add", H8, W8, r3_srcs, NB(), nb(L.feat), true, st2);
         else if (pair_mask() & 4)
             narrow_pair(IT_R3_1, IT_R3_2, "conv_narrow_pair:res3.conv1_conv2_add", H8, W8, {nb(L.z0)}, nb(L.feat), nb(L.z0), NB(), st2);
@@ -1182,6 +1227,15 @@ int crfp_cra_param_numel(int index, int y_only) {
     return index % 2 ? co : co * kConvs[ci].cin * 9;
 }
 
+// CRFP_simple / CRFP: the state_dict keys and their order are CRFP_DSV's (crfp_dsv_param_name); four weights have other shapes
+static int abl_param_numel(int wiring, int index, int y_only) {
+    if (index < 0 || index >= CRFP_DSV_NUM_PARAMS) return CRFP_E_BADARG;
+    const int ci = index / 2, co = conv_cout(ci, y_only, wiring);
+    return index % 2 ? co : co * conv_cin(ci, wiring) * 9;
+}
+int crfp_simple_param_numel(int index, int y_only) { return abl_param_numel(W_SIMPLE, index, y_only); }
+int crfp_dense_param_numel(int index, int y_only) { return abl_param_numel(W_DENSE, index, y_only); }
+
 #endif  // parameter tables: exported once
 
 }  // extern "C"
@@ -1198,7 +1252,7 @@ static int pack_weights_impl(const Model& M, const float* const* params, int y_o
         const float* b = params[2 * it.w1 + 1];
         const float* w2 = it.w2 >= 0 ? params[2 * it.w2] : nullptr;
         const float* b2 = it.w2 >= 0 ? params[2 * it.w2 + 1] : nullptr;
-        const int split = conv_cout(it.w1, y_only);
+        const int split = conv_cout(it.w1, y_only, M.wiring);
         int rc = 0;
         switch (it.type) {
             case T_MFMA:
@@ -1228,7 +1282,9 @@ static int pack_weights_impl(const Model& M, const float* const* params, int y_o
 extern "C" {
 
 size_t CRFP_API(crfp_dsv_packed_weight_bytes)(int y_only) { return model_for(y_only).total_floats * sizeof(float); }
-size_t CRFP_API(crfp_cra_packed_weight_bytes)(int y_only) { return model_for(y_only, false, true).total_floats * sizeof(float); }
+size_t CRFP_API(crfp_cra_packed_weight_bytes)(int y_only) { return model_for(y_only, false, W_CRA).total_floats * sizeof(float); }
+size_t CRFP_API(crfp_simple_packed_weight_bytes)(int y_only) { return model_for(y_only, false, W_SIMPLE).total_floats * sizeof(float); }
+size_t CRFP_API(crfp_dense_packed_weight_bytes)(int y_only) { return model_for(y_only, false, W_DENSE).total_floats * sizeof(float); }
 
 int CRFP_API(crfp_dsv_pack_weights)(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
     if (!params || !packed) { set_error("pack_weights: null argument"); return CRFP_E_BADARG; }
@@ -1246,7 +1302,21 @@ int CRFP_API(crfp_cra_pack_weights)(const float* const* params, int y_only, void
             if (!params[2 * j + k]) { set_error("pack_weights: parameter %d (%s) is null", 2 * j + k, crfp_cra_param_name(2 * j + k)); return CRFP_E_BADARG; }
             eng[2 * kCraOrder[j] + k] = params[2 * j + k];
         }
-    return pack_weights_impl(model_for(y_only, false, true), eng, y_only, packed, packed_bytes, stream);
+    return pack_weights_impl(model_for(y_only, false, W_CRA), eng, y_only, packed, packed_bytes, stream);
+}
+
+// params: CRFP_DSV_NUM_PARAMS device pointers in the order of the reference's CRFP_simple / CRFP state_dict (= crfp_dsv_param_name)
+static int abl_pack_weights(int wiring, const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
+    if (!params || !packed) { set_error("pack_weights: null argument"); return CRFP_E_BADARG; }
+    for (int i = 0; i < CRFP_DSV_NUM_PARAMS; ++i)
+        if (!params[i]) { set_error("pack_weights: parameter %d (%s) is null", i, crfp_dsv_param_name(i)); return CRFP_E_BADARG; }
+    return pack_weights_impl(model_for(y_only, false, wiring), params, y_only, packed, packed_bytes, stream);
+}
+int CRFP_API(crfp_simple_pack_weights)(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
+    return abl_pack_weights(W_SIMPLE, params, y_only, packed, packed_bytes, stream);
+}
+int CRFP_API(crfp_dense_pack_weights)(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream) {
+    return abl_pack_weights(W_DENSE, params, y_only, packed, packed_bytes, stream);
 }
 
 static bool dims_ok(int n, int t, int h, int w) { return n >= 1 && t >= 1 && h >= 8 && w >= 8 && (long long)n * t <= (1 << 20); }
@@ -1258,8 +1328,10 @@ size_t CRFP_API(crfp_dsv_batch_workspace_bytes)(int n, int t, int h, int w) {
 size_t CRFP_API(crfp_dsv_workspace_bytes)(int t, int h, int w) { return CRFP_API(crfp_dsv_batch_workspace_bytes)(1, t, h, w); }
 size_t CRFP_API(crfp_cra_batch_workspace_bytes)(int n, int t, int h, int w) {
     if (!dims_ok(n, t, h, w)) return 0;
-    return Layout(n, t, h, w, true).bytes();
+    return Layout(n, t, h, w, W_CRA).bytes();
 }
+size_t CRFP_API(crfp_simple_batch_workspace_bytes)(int n, int t, int h, int w) { return dims_ok(n, t, h, w) ? Layout(n, t, h, w, W_SIMPLE).bytes() : 0; }
+size_t CRFP_API(crfp_dense_batch_workspace_bytes)(int n, int t, int h, int w) { return dims_ok(n, t, h, w) ? Layout(n, t, h, w, W_DENSE).bytes() : 0; }
 
 static int check_common(const void* packed, int n, int t, int h, int w, void* ws, size_t ws_bytes, const Layout& L) {
     if (!packed || !ws) { set_error("dsv: null packed weights or workspace"); return CRFP_E_BADARG; }
@@ -1275,24 +1347,26 @@ size_t CRFP_API(crfp_dsv_batch_status_offset)(int n, int t, int h, int w) {
 size_t CRFP_API(crfp_dsv_status_offset)(int t, int h, int w) { return CRFP_API(crfp_dsv_batch_status_offset)(1, t, h, w); }
 size_t CRFP_API(crfp_cra_batch_status_offset)(int n, int t, int h, int w) {
     if (!dims_ok(n, t, h, w)) return 0;
-    return Layout(n, t, h, w, true).status;
+    return Layout(n, t, h, w, W_CRA).status;
 }
+size_t CRFP_API(crfp_simple_batch_status_offset)(int n, int t, int h, int w) { return dims_ok(n, t, h, w) ? (size_t)Layout(n, t, h, w, W_SIMPLE).status : 0; }
+size_t CRFP_API(crfp_dense_batch_status_offset)(int n, int t, int h, int w) { return dims_ok(n, t, h, w) ? (size_t)Layout(n, t, h, w, W_DENSE).status : 0; }
 
 }  // extern "C"
 
 // n clips in lock-step through the recurrent chain (reference model/CRFP.py:1510-1535: every op of forward() carries the batch
 // axis n): ONE launch per layer and frame step over all n clips, so a 360 x 640 map that is a single round of workgroups for one
 // clip becomes n rounds whose load / MFMA / store phases overlap.  Per clip the arithmetic is that of a one-clip call, bit for bit.
-static int forward_batch_impl(bool cra, const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+static int forward_batch_impl(int wiring, const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                               float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
     const int y_only = flags & CRFP_DSV_Y_ONLY;
     if (kActBf16 && (flags & CRFP_DSV_STRICT_F32)) { set_error("dsv (bf16 storage): CRFP_DSV_STRICT_F32 belongs to the fp32 entry points"); return CRFP_E_UNSUPPORTED; }
     if (!dims_ok(n, t, h, w)) { set_error("dsv: need n,t>=1, h,w>=8 (got %d,%d,%d,%d)", n, t, h, w); return CRFP_E_BADARG; }
-    Layout L(n, t, h, w, cra);
+    Layout L(n, t, h, w, wiring);
     int rc = check_common(packed, n, t, h, w, workspace, workspace_bytes, L);
     if (rc) return rc;
     if (!lrs || !fvs || !mks || !out) { set_error("dsv_forward_clip: null tensor"); return CRFP_E_BADARG; }
-    Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32, cra), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
+    Runner R{model_for(y_only, flags & CRFP_DSV_STRICT_F32, wiring), (const float*)packed, (char*)workspace, L, (hipStream_t)stream};
     R.strict = (flags & CRFP_DSV_STRICT_F32) ? 1 : 0;
     const int TC = L.TC;
     SideStream* ssp = side_stream_enabled() && !prof_enabled() && !(flags & CRFP_DSV_SINGLE_STREAM) ? side_stream() : nullptr;
@@ -1365,7 +1439,7 @@ extern "C" {
 
 int CRFP_API(crfp_dsv_forward_batch)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                            float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
-    return forward_batch_impl(false, packed, flags, lrs, fvs, mks, out, n, t, h, w, workspace, workspace_bytes, stream);
+    return forward_batch_impl(W_DSV, packed, flags, lrs, fvs, mks, out, n, t, h, w, workspace, workspace_bytes, stream);
 }
 
 // The same call for the reference's CRFP_DSV_CRA wiring (model/CRFP.py:2314-2664): packed = crfp_cra_pack_weights' buffer, workspace sized by
@@ -1373,7 +1447,19 @@ int CRFP_API(crfp_dsv_forward_batch)(const void* packed, int flags, const float*
 // state-independent and runs with the rest of a frame's pre-work on the side stream.
 int CRFP_API(crfp_cra_forward_batch)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                            float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
-    return forward_batch_impl(true, packed, flags, lrs, fvs, mks, out, n, t, h, w, workspace, workspace_bytes, stream);
+    return forward_batch_impl(W_CRA, packed, flags, lrs, fvs, mks, out, n, t, h, w, workspace, workspace_bytes, stream);
+}
+
+// The same call for the reference's ablation wirings CRFP_simple (model/CRFP.py:816-1099) and CRFP (:1101-1385) at mid_channels = 32 with
+// hr_dcn and offset_prop on: packed = crfp_simple_pack_weights' / crfp_dense_pack_weights' buffer, workspace sized by the wiring's own query.
+// Schedule, flags and status words as crfp_dsv_forward_batch.
+int CRFP_API(crfp_simple_forward_batch)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                           float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_batch_impl(W_SIMPLE, packed, flags, lrs, fvs, mks, out, n, t, h, w, workspace, workspace_bytes, stream);
+}
+int CRFP_API(crfp_dense_forward_batch)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                           float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_batch_impl(W_DENSE, packed, flags, lrs, fvs, mks, out, n, t, h, w, workspace, workspace_bytes, stream);
 }
 
 int CRFP_API(crfp_dsv_forward_clip)(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,

@@ -57,7 +57,8 @@ class DSVEngine:
         self._stream_hw = None
         self.pack(state_dict)
 
-    WIRING = "dsv"   # which parameter table / entry-point family this handle drives (CRAEngine: "cra")
+    WIRING = "dsv"   # which parameter table / entry-point family this handle drives (CRAEngine: "cra", SimpleEngine: "simple", DenseEngine: "dense")
+    MODEL_NAME = "CRFP_DSV"
 
     def _fn(self, name):
         return getattr(_lib.lib(), name + self._sfx)
@@ -67,10 +68,10 @@ class DSVEngine:
         names = param_names(self.WIRING)
         missing = [k for k in names if k not in state_dict]
         if missing:
-            raise KeyError(f"state_dict lacks {'CRFP_DSV_CRA' if self.WIRING == 'cra' else 'CRFP_DSV'} parameters: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+            raise KeyError(f"state_dict lacks {self.MODEL_NAME} parameters: {missing[:4]}{'...' if len(missing) > 4 else ''}")
         keep = []
         ptrs = (C.c_void_p * len(names))()
-        numel = L.crfp_cra_param_numel if self.WIRING == "cra" else L.crfp_dsv_param_numel
+        numel = getattr(L, f"crfp_{self.WIRING}_param_numel")
         for i, k in enumerate(names):
             t = state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
             want = numel(i, self.y_only)
@@ -367,23 +368,40 @@ class CRAEngine(DSVEngine):
     workspace.  Clip forward only: the reference's one-frame-per-call model (model/CRFP_test.py) is the plain CRFP_DSV."""
 
     WIRING = "cra"
-    _MAP = {"crfp_dsv_packed_weight_bytes": "crfp_cra_packed_weight_bytes", "crfp_dsv_pack_weights": "crfp_cra_pack_weights",
-            "crfp_dsv_batch_workspace_bytes": "crfp_cra_batch_workspace_bytes", "crfp_dsv_batch_status_offset": "crfp_cra_batch_status_offset",
-            "crfp_dsv_forward_batch": "crfp_cra_forward_batch"}
+    MODEL_NAME = "CRFP_DSV_CRA"
+    _CALLS = ("packed_weight_bytes", "pack_weights", "batch_workspace_bytes", "batch_status_offset", "forward_batch")
 
     def _fn(self, name):
+        fam = f"crfp_{self.WIRING}_"
         if name == "crfp_dsv_forward_clip":   # batch_mode "loop": the n = 1 form of the batch call
-            f = getattr(_lib.lib(), "crfp_cra_forward_batch" + self._sfx)
+            f = getattr(_lib.lib(), fam + "forward_batch" + self._sfx)
             return lambda packed, flags, lrs, fvs, mks, out, t, h, w, ws, nb, stream: f(packed, flags, lrs, fvs, mks, out, 1, t, h, w, ws, nb, stream)
-        if name not in self._MAP:
-            raise NotImplementedError(f"crfp_amd: {name} has no CRFP_DSV_CRA counterpart (clip forward only)")
-        return getattr(_lib.lib(), self._MAP[name] + self._sfx)
+        if not name.startswith("crfp_dsv_") or name[len("crfp_dsv_"):] not in self._CALLS:
+            raise NotImplementedError(f"crfp_amd: {name} has no {self.MODEL_NAME} counterpart (clip forward only)")
+        return getattr(_lib.lib(), fam + name[len("crfp_dsv_"):] + self._sfx)
 
     def stream_frame(self, *a, **k):
         raise NotImplementedError("crfp_amd: the one-frame-per-call schedule exists for the plain CRFP_DSV wiring only")
 
     def compute_flow(self, cur, prev):
-        raise NotImplementedError("crfp_amd: use the model's flow network modules (CRFP_DSV_CRA.compute_flow)")
+        raise NotImplementedError(f"crfp_amd: use the model's flow network modules ({self.MODEL_NAME}.compute_flow)")
 
     def debug_fetch(self, name, t, h, w):
         raise NotImplementedError("crfp_amd: debug_fetch reads the CRFP_DSV workspace layout")
+
+
+class SimpleEngine(CRAEngine):
+    """Handle on the one-call schedule of the reference's CRFP_simple wiring ("v13", model/CRFP.py:816-1099) at mid_channels = 32 with hr_dcn and
+    offset_prop on (crfp_simple_* entry points, include/crfp_hip.h): CRFP_DSV's state_dict keys, clip / lock-step batch forward, flags, status
+    words and overflow policies; its own packed weights and workspace."""
+
+    WIRING = "simple"
+    MODEL_NAME = "CRFP_simple"
+
+
+class DenseEngine(SimpleEngine):
+    """The same for the reference's class CRFP ("v15", model/CRFP.py:1101-1385; crfp_dense_* entry points): CRFP_simple with the warped previous
+    state as a third input of every residual block."""
+
+    WIRING = "dense"
+    MODEL_NAME = "CRFP"

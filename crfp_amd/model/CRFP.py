@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from crfp_amd import ops
 from crfp_amd.dcn_v2 import DCNv2
-from crfp_amd.engine import CRAEngine, DSVEngine
+from crfp_amd.engine import CRAEngine, DenseEngine, DSVEngine, SimpleEngine
 from . import LTE
 
 
@@ -536,10 +536,13 @@ class CRFP_simple(nn.Module):
     mid_channels, the previous state is warped at 8x FIRST and then brought to 2x (:1023-1026), and both constructor flags are live:
     ``hr_dcn=False`` runs dcn_3 / forward_resblocks_3 at 2x resolution in mid_channels and up-samples afterwards (:1066-1078),
     ``offset_prop=False`` drops the offset hand-down (:1032-1033).  The dense variant feeds each residual block the warped previous
-    state as a third input (:1311,1316,1321).  Same constructor and state_dict table as the reference (tests/golden/dsv_flags.npz);
-    forward is a composition of per-operator HIP calls."""
+    state as a third input (:1311,1316,1321).  Same constructor and state_dict table as the reference (tests/golden/dsv_flags.npz).
+    mid_channels = 32 with both flags on runs the one-call engine schedule of the wiring (``crfp_simple_forward_batch`` /
+    ``crfp_dense_forward_batch``, crfp_amd.engine.SimpleEngine / DenseEngine: clip forward, lock-step batches, both storage types);
+    every other constructor combination runs ``forward_composed`` (per-operator HIP calls)."""
 
     dense = False
+    _engine_class = SimpleEngine
 
     def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, spynet_pretrained=None):
         super().__init__()
@@ -570,6 +573,9 @@ class CRFP_simple(nn.Module):
         self.upsample_post = PixelShufflePack(m, l, 4, upsample_kernel=3)
         self.conv_last = nn.Conv2d(l, 1 if y_only else 3, 3, 1, 1)
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+        self._engine = self._engine_sig = self._engine_sum = None
+        # numerics policy of the HIP engine, as on CRFP_DSV (not part of the reference's interface)
+        self.precision, self.on_overflow, self.storage, self.inputs_resident = "split", "poison", "f32", False
 
     def compute_flow(self, lrs):
         n, t, c, h, w = lrs.shape
@@ -577,9 +583,19 @@ class CRFP_simple(nn.Module):
         return self.spynet(cur.contiguous(), prev.contiguous()).view(n, t - 1, 2, h, w), None
 
     init_weights = CRFP_DSV.init_weights
+    # engine management: CRFP_DSV's (repack whenever a parameter was modified or moved)
+    _signature, _checksum, invalidate_packed = CRFP_DSV._signature, CRFP_DSV._checksum, CRFP_DSV.invalidate_packed
+    has_engine, engine = CRFP_DSV.has_engine, CRFP_DSV.engine
 
     @torch.no_grad()
     def forward(self, lrs, fvs, mks):
+        if not self.has_engine():
+            return self.forward_composed(lrs, fvs, mks)
+        return self.engine().forward(lrs, fvs, mks)
+
+    @torch.no_grad()
+    def forward_composed(self, lrs, fvs, mks):
+        """The recurrence of model/CRFP.py:938-1079 (dense: :1223-1365) as a composition of per-operator HIP calls: every flag combination."""
         if lrs.dim() != 5 or not lrs.is_cuda:
             raise RuntimeError("crfp_amd: needs CUDA/HIP tensors lrs[n,t,3,h,w], fvs[n,t,3,8h,8w], mks[n,t,1,8h,8w]")
         n, t, _, h, w = lrs.shape
@@ -648,6 +664,7 @@ class CRFP(CRFP_simple):
     """The reference's CRFP ("v15", model/CRFP.py:1101-1385): see CRFP_simple."""
 
     dense = True
+    _engine_class = DenseEngine
 
 
 class MRCF_simple_v18(CRFP_DSV):

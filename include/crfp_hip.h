@@ -257,6 +257,30 @@ size_t crfp_cra_batch_status_offset(int n, int t, int h, int w);
 int crfp_cra_forward_batch(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                            float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- CRFP_simple / CRFP engines: the reference's two ablation wirings in front of CRFP_DSV -- CRFP_simple ("v13", model/CRFP.py:816-1099)
+ * and CRFP ("v15", :1101-1385) -- as one-call schedules, for mid_channels = 32 with hr_dcn = offset_prop = True (round 6; every other
+ * constructor combination stays a per-operator composition in the Python mirror).  Against CRFP_DSV: `upsample` keeps all 32 features
+ * (:875) and nothing is carried beside a level; the previous state is warped at 8x FIRST and both versions are brought to 2x by
+ * `downsample` (:1021-1026); `crfp_dense_*` (the reference's class CRFP) additionally feeds every residual block the warped previous state
+ * as a third input (:1311,1316).  Parameters: CRFP_DSV_NUM_PARAMS device pointers under CRFP_DSV's state_dict keys, in its order
+ * (crfp_dsv_param_name); `upsample`, `upsample_post` and -- dense -- the four `forward_resblocks_k.main.0` weights have other shapes
+ * (crfp_simple_param_numel / crfp_dense_param_numel).  The forward calls take the tensors, flags, status words and workspace rules of
+ * crfp_dsv_forward_batch; packed weights and workspaces are each wiring's own. */
+int crfp_simple_param_numel(int index, int y_only);
+size_t crfp_simple_packed_weight_bytes(int y_only);
+int crfp_simple_pack_weights(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+size_t crfp_simple_batch_workspace_bytes(int n, int t, int h, int w);
+size_t crfp_simple_batch_status_offset(int n, int t, int h, int w);
+int crfp_simple_forward_batch(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                              float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+int crfp_dense_param_numel(int index, int y_only);
+size_t crfp_dense_packed_weight_bytes(int y_only);
+int crfp_dense_pack_weights(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+size_t crfp_dense_batch_workspace_bytes(int n, int t, int h, int w);
+size_t crfp_dense_batch_status_offset(int n, int t, int h, int w);
+int crfp_dense_forward_batch(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                             float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- bf16 storage (BASELINE configs 3-5): the same engine with every activation tensor and the recurrent state held
  * as bf16 in HBM (half the traffic of the HBM-bound kernels, one bf16 MFMA per product instead of three fp16 ones).
  * What stays fp32: the API tensors (lrs, fvs, out), all accumulators and interpolation arithmetic, biases, and everything
@@ -286,6 +310,18 @@ size_t crfp_cra_batch_workspace_bytes_bf16(int n, int t, int h, int w);
 size_t crfp_cra_batch_status_offset_bf16(int n, int t, int h, int w);
 int crfp_cra_forward_batch_bf16(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
                                 float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+size_t crfp_simple_packed_weight_bytes_bf16(int y_only);
+int crfp_simple_pack_weights_bf16(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+size_t crfp_simple_batch_workspace_bytes_bf16(int n, int t, int h, int w);
+size_t crfp_simple_batch_status_offset_bf16(int n, int t, int h, int w);
+int crfp_simple_forward_batch_bf16(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                                   float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+size_t crfp_dense_packed_weight_bytes_bf16(int y_only);
+int crfp_dense_pack_weights_bf16(const float* const* params, int y_only, void* packed, size_t packed_bytes, void* stream);
+size_t crfp_dense_batch_workspace_bytes_bf16(int n, int t, int h, int w);
+size_t crfp_dense_batch_status_offset_bf16(int n, int t, int h, int w);
+int crfp_dense_forward_batch_bf16(const void* packed, int flags, const float* lrs, const float* fvs, const uint8_t* mks,
+                                  float* out, int n, int t, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
 int crfp_fnet_forward_bf16(const void* packed, const float* cur, const float* prev, float* flow, int n, int h, int w,
                            void* workspace, size_t workspace_bytes, void* stream);
 int crfp_dsv_debug_fetch_bf16(const char* name, int t, int h, int w, const void* workspace, float* out_nchw,

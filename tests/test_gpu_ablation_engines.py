@@ -1,0 +1,143 @@
+"""The one-call engine schedules of the reference's ablation wirings CRFP_simple ("v13", model/CRFP.py:816-1099; crfp_simple_forward_batch)
+and CRFP ("v15", :1101-1385; crfp_dense_forward_batch) against the reference's own outputs (tests/golden/dsv_flags.npz, cases
+simple_mid32 / dense_mid32), against the per-operator composition of the same model, and against themselves across the schedules
+that must not change a bit (lock-step batch vs one clip per call, one stream vs two)."""
+import pytest
+import torch
+
+from test_flags import T, _model, flags  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("simple_mid32", "CRFP_simple"), ("dense_mid32", "CRFP")]
+
+
+def _clip(seed, n, t, h, w, fv=None):
+    from crfp_amd import synth
+    return tuple(T(a).cuda() for a in synth.make_clip(seed, n, t, h, w, fv_size=fv or 8 * min(h, w) // 2))
+
+
+@pytest.mark.parametrize("case,cls", CASES)
+def test_ablation_engine_matches_the_reference_golden(flags, case, cls):
+    from crfp_amd import synth
+    dev = torch.device("cuda:0")
+    m = _model(flags, case, dev)
+    assert type(m).__name__ == cls and m.has_engine()
+    h, w, fv = int(flags["h"]), int(flags["w"]), int(flags["fv"])
+    lrs, fvs, mks = (T(a).to(dev) for a in synth.make_clip(int(flags[f"{case}.clip_seed"]), 1, int(flags[f"{case}.t"]), h, w, fv_size=fv))
+    ref = T(flags[f"{case}.out"])
+    with torch.no_grad():
+        got = m(lrs=lrs, fvs=fvs, mks=mks).cpu()
+        comp = m.forward_composed(lrs, fvs, mks).cpu()
+        m.precision = "f32"
+        strict = m(lrs=lrs, fvs=fvs, mks=mks).cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 2e-4
+    assert float((comp - ref).abs().max()) < 2e-4
+    assert float((strict - ref).abs().max()) < 2e-4
+    assert not m.engine().overflowed()
+
+
+@pytest.mark.parametrize("cls", ["CRFP_simple", "CRFP"])
+@pytest.mark.parametrize("y_only", [False, True])
+def test_ablation_engine_equals_its_composed_twin_and_is_schedule_invariant(cls, y_only):
+    """Random weights, a 3-clip batch of 4 frames at 24 x 40: engine within 2e-4 of the per-operator composition; lock-step == one clip
+    per call and one stream == two streams, bit for bit; the three wirings give three different pictures from the weights they share."""
+    from crfp_amd.model import CRFP
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    m = getattr(CRFP, cls)(dev, mid_channels=32, y_only=y_only).to(dev).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.5)      # default init is small: make the recurrent inputs matter
+    lrs, fvs, mks = _clip(81, 3, 4, 24, 40, 96)
+    with torch.no_grad():
+        out = m(lrs, fvs, mks)
+        comp = m.forward_composed(lrs, fvs, mks)
+        eng = m.engine()
+        assert type(eng).__name__ == ("DenseEngine" if cls == "CRFP" else "SimpleEngine")
+        eng.batch_mode = "loop"
+        loop = m(lrs, fvs, mks).clone()
+        eng.batch_mode = "lockstep"
+        eng.single_stream = True
+        single = m(lrs, fvs, mks).clone()
+        eng.single_stream = False
+    assert out.shape == (3, 4, 1 if y_only else 3, 192, 320)
+    assert float((out - comp).abs().max()) < 2e-4 * max(1.0, float(comp.abs().max()))
+    assert torch.equal(out, loop) and torch.equal(out, single)
+    # frames after the first depend on the state (a schedule that dropped the recurrence would repeat the first-frame arithmetic)
+    assert float((out[:, 1:] - comp[:, :1]).abs().max()) > 1e-3
+
+
+def test_dense_wiring_is_not_the_simple_one():
+    """CRFP's extra inputs are live: zeroing the weights that read the warped previous state turns CRFP into CRFP_simple, bit for bit in
+    the engine's arithmetic order (the three-input convs then add exact zeros)."""
+    from crfp_amd.model import CRFP
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    dense = CRFP.CRFP(dev, mid_channels=32).to(dev).eval()
+    simple = CRFP.CRFP_simple(dev, mid_channels=32).to(dev).eval()
+    lrs, fvs, mks = _clip(82, 1, 3, 24, 40, 96)
+    with torch.no_grad():
+        full = dense(lrs, fvs, mks).clone()
+        sd = {k: v.clone() for k, v in dense.state_dict().items()}
+        for k in range(3):
+            sd[f"forward_resblocks_{k}.main.0.weight"][:, 64:] = 0
+        sd["forward_resblocks_3.main.0.weight"][:, 8:] = 0
+        dense.load_state_dict(sd)
+        cut = dense(lrs, fvs, mks).clone()
+        ssd = {k: (v[:, :64] if k in [f"forward_resblocks_{j}.main.0.weight" for j in range(3)] else
+                   v[:, :8] if k == "forward_resblocks_3.main.0.weight" else v).contiguous() for k, v in sd.items()}
+        simple.load_state_dict(ssd, strict=True)
+        plain = simple(lrs, fvs, mks)
+    assert float((full - cut).abs().max()) > 1e-4
+    assert float((cut - plain).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("case", ["simple_mid32", "dense_mid32"])
+def test_ablation_engine_bf16_storage_and_long_clips(flags, case):
+    """bf16 storage: lock-step == loop bit for bit, and within bf16 noise of the fp32-storage result; a clip longer than the flat limit
+    (chunked clip-level stages) equals the same frames run as a flat job."""
+    dev = torch.device("cuda:0")
+    m = _model(flags, case, dev)
+    lrs, fvs, mks = _clip(83, 2, 5, 24, 40, 96)
+    with torch.no_grad():
+        ref = m(lrs, fvs, mks).clone()
+        m.storage = "bf16"
+        out = m(lrs, fvs, mks).clone()
+        m.engine().batch_mode = "loop"
+        loop = m(lrs, fvs, mks).clone()
+    assert torch.equal(out, loop)
+    assert float((out - ref).abs().max()) < 0.06 and float((out - ref).abs().mean()) < 4e-3
+    m.storage = "f32"
+    lrs, fvs, mks = _clip(84, 1, 35, 16, 24, 64)      # 35 frames > 32: chunks of 8
+    with torch.no_grad():
+        long = m(lrs, fvs, mks)
+        head = m(lrs[:, :20].contiguous(), fvs[:, :20].contiguous(), mks[:, :20].contiguous())
+    assert torch.equal(long[:, :20], head)
+
+
+def test_ablation_engines_at_the_benchmark_geometry_and_what_they_refuse():
+    """7 x 180 x 320 (BASELINE configs[1]'s shape): the chain / dual-launch / persistent kernel forms of the full-size maps against the composition;
+    the other flag combinations keep the composed path; the entry points check the parameter shapes of their own wiring."""
+    from crfp_amd import engine
+    from crfp_amd.model import CRFP
+    dev = torch.device("cuda:0")
+    for cls in ("CRFP_simple", "CRFP"):
+        torch.manual_seed(8)
+        m = getattr(CRFP, cls)(dev, mid_channels=32).to(dev).eval()
+        lrs, fvs, mks = _clip(85, 1, 3, 180, 320, 96)
+        with torch.no_grad():
+            out = m(lrs, fvs, mks)
+            comp = m.forward_composed(lrs, fvs, mks)
+        assert float((out - comp).abs().max()) < 2e-4 * max(1.0, float(comp.abs().max()))
+        del out, comp
+    assert not CRFP.CRFP_simple(dev, mid_channels=16).has_engine()
+    assert not CRFP.CRFP(dev, mid_channels=32, hr_dcn=False).has_engine()
+    assert not CRFP.CRFP_simple(dev, mid_channels=32, offset_prop=False).has_engine()
+    with pytest.raises(ValueError):      # a CRFP_DSV table: `upsample` has 96 output channels there
+        engine.SimpleEngine(CRFP.CRFP_DSV(dev, mid_channels=32).state_dict(), dev)
+    with pytest.raises(ValueError):      # CRFP_simple's residual blocks take 64 input channels, CRFP's 96
+        engine.DenseEngine(CRFP.CRFP_simple(dev, mid_channels=32).state_dict(), dev)
+    with pytest.raises(NotImplementedError):
+        engine.SimpleEngine(CRFP.CRFP_simple(dev, mid_channels=32).state_dict(), dev).stream_frame(None, None, None)
