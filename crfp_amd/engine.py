@@ -18,6 +18,90 @@ def param_names(wiring: str = "dsv"):
     return [L.crfp_dsv_param_name(i).decode() for i in range(_lib.NUM_PARAMS)]
 
 
+def embed_mid32(state_dict, mid: int, wiring: str = "dsv", y_only: bool = False):
+    """A CRFP_DSV / CRFP_simple / CRFP state_dict of ``mid_channels = mid`` (16: the reference's constructor default, model/CRFP.py:1388,
+    and the only width below 32 its `downsample` assertion admits, :206-222) -> the state_dict of the SAME function at mid_channels = 32, which the one-call engine schedules run: every
+    tensor of the narrow model sits at fixed channel positions of its 32- (8x maps: 4-) channel twin, the other channels are exact
+    zeros (zero weight rows and biases; lrelu / relu / the residual adds keep them zero), and zero weight columns ignore them.  The
+    positions: identity, except (a) a residual block's output keeps its [features | carried] split -- the 3 mid / 4 features in
+    channels [0, 24), the mid / 4 carried ones from 24 on (model/CRFP.py:1590-1591), and (b) `downsample`'s output, the tensor DCNv2
+    samples with 8 deformable groups, puts group g's mid / 8 channels at [4 g, 4 g + mid / 8) -- the engine's one-quad-per-group
+    layout.  Pixel-(un)shuffle channel indices c * r^2 + s survive as they are.  Products with the padding are exact zeros, so the
+    results equal the narrow model's up to fp32 summation order (tests: the reference's own mid16 goldens)."""
+    import torch as _t
+    if mid != 16 or wiring not in ("dsv", "simple", "dense"):
+        raise ValueError(f"embed_mid32: mid_channels {mid} / wiring {wiring!r}")
+    m, l = mid, mid // 8
+    abl = wiring != "dsv"
+    p = m if abl else 3 * m // 4                     # features a level passes on
+    ident = lambda n, base=0: [base + j for j in range(n)]   # noqa: E731
+    feat = ident(m)
+    cur = ident(m) if abl else ident(p) + ident(m - p, 24)
+    grp = [4 * (j // l) + j % l for j in range(m)]
+    lq = ident(l)
+    off = lambda e, base: [base + j for j in e]      # noqa: E731
+    ups_rows = [c * 4 + s_ for c in (ident(m) if abl else ident(p)) for s_ in range(4)]
+    third2 = off(grp, 64) if wiring == "dense" else []          # CRFP: + the warped previous state (in `downsample`'s layout)
+    third8 = off(lq, 8) if wiring == "dense" else []
+    # conv stem -> (rows, cols, full cout, full cin)
+    table = {}
+    for k in range(3):
+        d = f"dcn_{k}."
+        table[d + "dcn_block.0"] = (feat, cur + off(grp, 32) + [64, 65], 32, 66)
+        table[d + "dcn_block.2"] = (feat, feat, 32, 32)
+        if k:
+            table[d + "conv_fuse"] = (feat, feat + off(feat, 32), 32, 64)
+        table[d + "dcn_offset"] = (ident(144), feat, 144, 32)
+        table[d + "dcn_mask"] = (ident(72), feat, 72, 32)
+        table[d + "dcn"] = (feat, grp, 32, 32)
+        r = f"forward_resblocks_{k}."
+        table[r + "main.0"] = (cur, cur + off(feat, 32) + third2, 32, 96 if wiring == "dense" else 64)
+        table[r + "main.2.0.conv1"] = (feat, cur, 32, 32)
+        table[r + "main.2.0.conv2"] = (cur, feat, 32, 32)
+    table["dcn_3.upsample.upsample_conv"] = (ident(16 * l), feat, 64, 32)
+    table["dcn_3.conv_fuse"] = (lq, lq + off(lq, 4), 4, 8)
+    table["dcn_3.dcn_block.0"] = (lq, lq + off(lq, 4) + [8, 9], 4, 10)
+    table["dcn_3.dcn_block.2"] = (lq, lq, 4, 4)
+    table["dcn_3.dcn_offset"] = ([0, 1], lq, 2, 4)
+    table["dcn_3.dcn_mask"] = ([0], lq, 1, 4)
+    table["dcn_3.dcn"] = (lq, lq, 4, 4)
+    table["encoder_lr.slice1.0"] = (feat, [0, 1, 2], 32, 3)
+    table["encoder_lr.slice1.2"] = (feat, feat, 32, 32)
+    table["encoder_hr.slice1.0"] = (lq, ident(6), 4, 6)
+    table["encoder_hr.slice1.2"] = (lq, lq, 4, 4)
+    table["conv_tttf"] = (lq, lq + off(lq, 4), 4, 8)
+    table["forward_resblocks_3.main.0"] = (lq, lq + off(lq, 4) + third8, 4, 12 if wiring == "dense" else 8)
+    table["forward_resblocks_3.main.2.0.conv1"] = (lq, lq, 4, 4)
+    table["forward_resblocks_3.main.2.0.conv2"] = (lq, lq, 4, 4)
+    table["downsample.downsample_conv"] = (grp, ident(16 * l), 32, 64)
+    table["upsample.upsample_conv"] = (ups_rows, feat, 128 if abl else 96, 32)
+    table["upsample_post.upsample_conv"] = (ident(16 * l), ident(p), 64, 32 if abl else 24)
+    co_last = 1 if y_only else 3
+    table["conv_last"] = (ident(co_last), lq, co_last, 4)
+    out = {}
+    for key, v in state_dict.items():
+        stem, _, kind = key.rpartition(".")
+        if stem not in table or kind not in ("weight", "bias"):
+            out[key] = v            # the flow network has no mid_channels in it
+            continue
+        rows, cols, co, ci = table[stem]
+        v = v.detach().to(_t.float32)
+        if kind == "bias":
+            if v.numel() != len(rows):
+                raise ValueError(f"parameter {key}: {v.numel()} elements, expected {len(rows)} at mid_channels = {mid}")
+            b = v.new_zeros(co)
+            b[_t.tensor(rows, device=v.device)] = v
+            out[key] = b
+            continue
+        if tuple(v.shape) != (len(rows), len(cols), 3, 3):
+            raise ValueError(f"parameter {key}: shape {tuple(v.shape)}, expected {(len(rows), len(cols), 3, 3)} at mid_channels = {mid}")
+        w = v.new_zeros(co, ci, 3, 3)
+        ri, cj = _t.tensor(rows, device=v.device), _t.tensor(cols, device=v.device)
+        w[ri[:, None], cj[None, :]] = v
+        out[key] = w
+    return out
+
+
 class DSVEngine:
     """precision: "split" (default: split-fp16 MFMA scheme, fp32-grade, operands must stay below 65504) or "f32" (strict
     fp32 MFMA, CRFP_DSV_STRICT_F32).  on_overflow: what a clip / streamed frame does when the split scheme's range guard
@@ -25,8 +109,9 @@ class DSVEngine:
     (synchronise, rerun the call in strict fp32) or "raise" (FloatingPointError)."""
 
     def __init__(self, state_dict, device, y_only: bool = False, precision: str = "split", on_overflow: str = "poison",
-                 storage: str = "f32"):
+                 storage: str = "f32", mid_channels: int = 32):
         """state_dict: mapping with the reference's CRFP_DSV keys -> tensors (any device).
+        mid_channels: 32, or 16 -- the narrower model runs embedded in the 32-channel schedule (``embed_mid32``).
         storage: "f32" (default) or "bf16" -- activations and recurrent state held as bf16 in HBM (crfp_dsv_*_bf16 entry
         points, BASELINE configs 3-5); API tensors, accumulators, flow / offsets / masks stay fp32."""
         if precision not in ("split", "f32") or on_overflow not in ("poison", "fallback", "raise") or storage not in ("f32", "bf16"):
@@ -55,6 +140,11 @@ class DSVEngine:
         self._stream_prev_buf = None
         self._stream_resident = False
         self._stream_hw = None
+        self.mid_channels = int(mid_channels)
+        if self.mid_channels != 32:
+            if self.WIRING == "cra":
+                raise NotImplementedError("crfp_amd: the CRFP_DSV_CRA engine schedule exists for mid_channels = 32")
+            state_dict = embed_mid32(state_dict, self.mid_channels, self.WIRING, bool(y_only))
         self.pack(state_dict)
 
     WIRING = "dsv"   # which parameter table / entry-point family this handle drives (CRAEngine: "cra", SimpleEngine: "simple", DenseEngine: "dense")

@@ -340,11 +340,14 @@ class CRFP_DSV(nn.Module):
         self._engine_sig = None
 
     _engine_class = DSVEngine
+    _engine_mids = (16, 32)   # mid_channels = 16 runs embedded in the 32-channel schedule (crfp_amd.engine.embed_mid32)
 
     def has_engine(self) -> bool:
         """The one-call C++ schedule (csrc/engine.hip) exists for the configuration the reference ships and evaluates (main.py:34 with
-        eval.sh's flags: mid_channels=32, hr_dcn, offset_prop); every other flag combination runs ``forward_composed``."""
-        return self.mid_channels == 32 and bool(self.hr_dcn) and bool(self.offset_prop)
+        eval.sh's flags: mid_channels=32, hr_dcn, offset_prop) and -- round 6 -- for mid_channels = 16 (the constructor default,
+        model/CRFP.py:1388), which runs as the same function embedded in the 32-channel schedule; every other flag combination
+        (hr_dcn / offset_prop off, mid_channels > 32) runs ``forward_composed``."""
+        return self.mid_channels in self._engine_mids and bool(self.hr_dcn) and bool(self.offset_prop)
 
     def engine(self) -> DSVEngine:
         if not self.has_engine():
@@ -355,7 +358,7 @@ class CRFP_DSV(nn.Module):
         check = os.environ.get("CRFP_CHECK_PACKED") == "1"
         if (self._engine is None or self._engine_sig != sig or self._engine.device != dev
                 or self._engine.storage != self.storage):
-            self._engine = self._engine_class(self.state_dict(), dev, self.y_only, storage=self.storage)
+            self._engine = self._engine_class(self.state_dict(), dev, self.y_only, storage=self.storage, mid_channels=self.mid_channels)
             self._engine_sig = sig
             self._engine_sum = self._checksum() if check else None
         elif check and self._engine_sum is not None and not torch.equal(self._engine_sum, self._checksum()):
@@ -494,6 +497,7 @@ class CRFP_DSV_CRA(CRFP_DSV):
     types); every other constructor combination runs ``forward_composed`` (per-operator HIP calls), as in CRFP_DSV."""
 
     _engine_class = CRAEngine
+    _engine_mids = (32,)
 
     def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, spynet_pretrained=None):
         super().__init__(device, mid_channels, y_only, hr_dcn, offset_prop, spynet_pretrained)
@@ -585,7 +589,7 @@ class CRFP_simple(nn.Module):
     init_weights = CRFP_DSV.init_weights
     # engine management: CRFP_DSV's (repack whenever a parameter was modified or moved)
     _signature, _checksum, invalidate_packed = CRFP_DSV._signature, CRFP_DSV._checksum, CRFP_DSV.invalidate_packed
-    has_engine, engine = CRFP_DSV.has_engine, CRFP_DSV.engine
+    has_engine, engine, _engine_mids = CRFP_DSV.has_engine, CRFP_DSV.engine, CRFP_DSV._engine_mids
 
     @torch.no_grad()
     def forward(self, lrs, fvs, mks):

@@ -59,7 +59,8 @@ def test_state_dict_tables_match_the_reference_for_every_flag_combination(flags)
         assert list(mine) == list(ref), name
         assert mine == ref, name
         if hasattr(m, "has_engine"):
-            assert m.has_engine() == (kw.get("mid_channels", 16) == 32 and kw.get("hr_dcn", True) and kw.get("offset_prop", True))
+            mids = (32,) if name.startswith("cra") else (16, 32)   # mid_channels = 16 runs embedded in the 32-channel schedule
+            assert m.has_engine() == (kw.get("mid_channels", 16) in mids and kw.get("hr_dcn", True) and kw.get("offset_prop", True))
 
 
 @pytest.mark.gpu
@@ -74,8 +75,8 @@ def test_flag_combinations_behave_like_the_reference(flags):
         if f"{name}.ctor_error" in flags:
             continue
         m = _model(flags, name, dev)
-        # the one case with a one-call engine schedule of its own (CRFP_DSV_CRA as shipped): the engine here, its composed twin in test_gpu_cra.py
-        assert getattr(m, "has_engine", lambda: False)() == (name == "cra_mid32")
+        # the cases with a one-call engine schedule run it here (their composed twins: test_gpu_cra.py, test_gpu_ablation_engines.py)
+        assert getattr(m, "has_engine", lambda: False)() == (name in ("cra_mid32", "simple_mid32", "dense_mid32", "mid16_default", "mid16_yonly"))
         lrs, fvs, mks = (T(a).to(dev) for a in synth.make_clip(int(flags[f"{name}.clip_seed"]), 1, int(flags[f"{name}.t"]), h, w, fv_size=fv))
         if f"{name}.forward_error" in flags:
             cls = {"RuntimeError": RuntimeError, "AttributeError": AttributeError}[str(flags[f"{name}.forward_error"])]
@@ -140,3 +141,22 @@ def test_runtime_mirror_routes_what_the_engine_does_not_take(rt_flags):
         clamped = m2(lrs, fvs, warp_size=(128, 192)).cpu()   # the one-call engine on the window the reference's slicing ends up with
     assert float((got - T(g["oversize.out"])).abs().max()) < 2e-4
     assert float((clamped - T(g["oversize.out"])).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("cls,wiring", [("CRFP_DSV", "dsv"), ("CRFP_simple", "simple"), ("CRFP", "dense")])
+@pytest.mark.parametrize("y_only", [False, True])
+def test_embedded_narrow_tables_have_the_32_channel_shapes_and_keep_every_weight(cls, wiring, y_only, mid=16):
+    """No GPU: crfp_amd.engine.embed_mid32 places a narrow model's parameters inside the 32-channel table the engine packs -- same keys,
+    the 32-channel shapes, every value kept exactly once, everything else zero."""
+    from crfp_amd import engine
+    from crfp_amd.model import CRFP
+    torch.manual_seed(mid)
+    narrow = getattr(CRFP, cls)(torch.device("cpu"), mid_channels=mid, y_only=y_only).state_dict()
+    wide = getattr(CRFP, cls)(torch.device("cpu"), mid_channels=32, y_only=y_only).state_dict()
+    emb = engine.embed_mid32(narrow, mid, wiring, y_only=y_only)
+    assert list(emb) == list(wide)
+    for k, v in emb.items():
+        assert tuple(v.shape) == tuple(wide[k].shape), k
+        a, b = narrow[k].flatten(), v.flatten()
+        assert int((b != 0).sum()) == int((a != 0).sum()), k
+        assert torch.equal(torch.sort(b[b != 0])[0], torch.sort(a[a != 0])[0]), k

@@ -132,7 +132,7 @@ def test_ablation_engines_at_the_benchmark_geometry_and_what_they_refuse():
             comp = m.forward_composed(lrs, fvs, mks)
         assert float((out - comp).abs().max()) < 2e-4 * max(1.0, float(comp.abs().max()))
         del out, comp
-    assert not CRFP.CRFP_simple(dev, mid_channels=16).has_engine()
+    assert not CRFP.CRFP_simple(dev, mid_channels=64).has_engine()
     assert not CRFP.CRFP(dev, mid_channels=32, hr_dcn=False).has_engine()
     assert not CRFP.CRFP_simple(dev, mid_channels=32, offset_prop=False).has_engine()
     with pytest.raises(ValueError):      # a CRFP_DSV table: `upsample` has 96 output channels there
@@ -141,3 +141,65 @@ def test_ablation_engines_at_the_benchmark_geometry_and_what_they_refuse():
         engine.DenseEngine(CRFP.CRFP_simple(dev, mid_channels=32).state_dict(), dev)
     with pytest.raises(NotImplementedError):
         engine.SimpleEngine(CRFP.CRFP_simple(dev, mid_channels=32).state_dict(), dev).stream_frame(None, None, None)
+
+
+@pytest.mark.parametrize("case", ["mid16_default", "mid16_yonly"])
+def test_mid16_runs_the_engine_and_matches_the_reference_golden(flags, case):
+    """mid_channels = 16 (the reference's constructor default, model/CRFP.py:1388) through the one-call schedule -- the same function embedded in
+    the 32-channel engine (crfp_amd.engine.embed_mid32) -- against the reference's own output and the per-operator composition."""
+    from crfp_amd import synth
+    dev = torch.device("cuda:0")
+    m = _model(flags, case, dev)
+    assert m.mid_channels == 16 and m.has_engine()
+    h, w, fv = int(flags["h"]), int(flags["w"]), int(flags["fv"])
+    lrs, fvs, mks = (T(a).to(dev) for a in synth.make_clip(int(flags[f"{case}.clip_seed"]), 1, int(flags[f"{case}.t"]), h, w, fv_size=fv))
+    ref = T(flags[f"{case}.out"])
+    with torch.no_grad():
+        got = m(lrs=lrs, fvs=fvs, mks=mks).cpu()
+        comp = m.forward_composed(lrs, fvs, mks).cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 2e-4
+    assert float((got - comp).abs().max()) < 2e-4
+    assert not m.engine().overflowed()
+
+
+@pytest.mark.parametrize("cls", ["CRFP_DSV", "CRFP_simple", "CRFP"])
+def test_narrow_models_embedded_in_the_32_channel_schedule(cls, mid=16):
+    """Every wiring at mid_channels 16: engine (embedded weights) within 2e-4 of the per-operator composition of the narrow model over a
+    2-clip batch of 4 frames; the streaming interface of the narrow CRFP_DSV as well; bf16 storage within bf16 noise."""
+    from crfp_amd.model import CRFP
+    dev = torch.device("cuda:0")
+    torch.manual_seed(mid)
+    m = getattr(CRFP, cls)(dev, mid_channels=mid).to(dev).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.5)
+    lrs, fvs, mks = _clip(90 + mid, 2, 4, 24, 40, 96)
+    with torch.no_grad():
+        out = m(lrs, fvs, mks)
+        comp = m.forward_composed(lrs, fvs, mks)
+        assert m.engine().mid_channels == mid
+        tol = 2e-4 * max(1.0, float(comp.abs().max()))
+        assert float((out - comp).abs().max()) < tol
+        assert float((out[:, 1:] - comp[:, :1]).abs().max()) > 1e-3
+        if cls == "CRFP_DSV":
+            stream = m.forward_stream(lrs[:1], fvs[:1], mks[:1])
+            assert float((stream - comp[:1]).abs().max()) < tol
+        m.storage = "bf16"
+        b16 = m(lrs, fvs, mks)
+    assert float((b16 - out).abs().max()) < 0.06 and float((b16 - out).abs().mean()) < 4e-3
+
+
+def test_embed_mid32_rejects_what_it_cannot_place():
+    from crfp_amd import engine
+    from crfp_amd.model import CRFP
+    dev = torch.device("cuda:0")
+    sd16 = CRFP.CRFP_DSV(dev, mid_channels=16).state_dict()
+    with pytest.raises(ValueError):
+        engine.embed_mid32(CRFP.CRFP_simple(dev, mid_channels=16).state_dict(), 16)   # another wiring's shapes
+    with pytest.raises(ValueError):
+        engine.embed_mid32(sd16, 48)
+    with pytest.raises(ValueError):
+        engine.DSVEngine(sd16, dev)                       # a 16-channel table handed over as a 32-channel one
+    with pytest.raises(NotImplementedError):
+        engine.CRAEngine(CRFP.CRFP_DSV_CRA(dev, mid_channels=32).state_dict(), dev, mid_channels=16)
