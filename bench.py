@@ -234,6 +234,9 @@ def main():
     if extras and mode == "clip" and args.config == 2:
         benchlegs.leg_cra_engine(c)
 
+    if extras and mode == "clip" and args.config == 2:
+        benchlegs.leg_ablation_engines(c)
+
     if extras and storage == "f32":
         benchlegs.leg_per_op(c)
 

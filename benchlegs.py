@@ -436,6 +436,42 @@ def leg_cra_engine(c):
     torch.cuda.empty_cache()
 
 
+def leg_ablation_engines(c):
+    """CRFP_simple / CRFP (mid_channels 32) and the constructor-default mid_channels = 16 on their one-call schedules"""
+    from crfp_amd import synth
+    from crfp_amd.model import CRFP
+    args, dev, storage, t, data1, result = c.args, c.dev, c.storage, c.t, c.data1, c.result
+    # round 6: the reference's ablation wirings (model/CRFP.py:816-1385) and its constructor default width (:1388) no longer run as per-operator
+    # compositions: frames/s on this config's clip through crfp_simple_forward_batch / crfp_dense_forward_batch / the embedded 16-channel table,
+    # each checked against the per-operator composition of the same model
+    out = {}
+    with torch.no_grad():
+        for name, cls, mid, entry in (("CRFP_simple", "CRFP_simple", 32, "crfp_simple_forward_batch"), ("CRFP", "CRFP", 32, "crfp_dense_forward_batch"),
+                                      ("CRFP_DSV_mid16", "CRFP_DSV", 16, "crfp_dsv_forward_batch (embed_mid32)")):
+            m = getattr(CRFP, cls)(device=dev, mid_channels=mid)
+            sd = synth.make_state_dict_like({k: tuple(v.shape) for k, v in m.state_dict().items()}, 1)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            m = m.to(dev).eval()
+            m.storage = storage
+            d0 = data1[0]
+            got = m(*d0)
+            ref = m.forward_composed(*d0)
+            torch.cuda.synchronize()
+            n_s = max(2, min(args.steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(n_s):
+                m(*d0)
+            torch.cuda.synchronize()
+            out[name] = {"frames_per_sec": t * n_s / (time.perf_counter() - t0), "entry_point": entry, "mid_channels": mid,
+                         "max_abs_diff_vs_per_operator_composition": float((got - ref).abs().max())}
+            assert out[name]["max_abs_diff_vs_per_operator_composition"] < 2e-4, out
+            del m, got, ref
+            torch.cuda.empty_cache()
+    out["tolerance"] = 2e-4
+    out["note"] = "one clip per call on this config's clip; before round 6 these models ran as per-operator compositions (136-165 frames/s)"
+    result["ablation_engines"] = out
+
+
 def leg_per_op(c):
     """per-operator C-ABI entry points"""
     from crfp_amd.model import CRFP

@@ -90,9 +90,12 @@ def test_module_mirror_keys_and_shapes():
         assert list(m.state_dict().keys()) == list(sd.keys())
         m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
         assert any("spynet" in k for k, _ in m.named_parameters())        # trainer.py:131-141 relies on it
-    # round 4: every flag combination constructs (tests/test_flags.py pins the tables); only the shipped one has the one-call engine
-    assert not CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=16).has_engine()
+    # round 4: every flag combination constructs (tests/test_flags.py pins the tables); round 6: the shipped width and the constructor default
+    # (16, embedded in the 32-channel schedule) have the one-call engine, wider models and the flags-off combinations do not
+    assert CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=16).has_engine()
     assert CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=32).has_engine()
+    assert not CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=64).has_engine()
+    assert not CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=16, offset_prop=False).has_engine()
     with pytest.raises(ValueError):
         CRFP.CRFP_DSV(device=torch.device("cpu"), mid_channels=20)
 

@@ -40,6 +40,8 @@ int main() {
                     EXPECT(sn >= s1 / 2 && crfp_dsv_batch_status_offset(n, t, h, w) + 4ull * n <= sn);
                     EXPECT(crfp_dsv_batch_workspace_bytes_bf16(n, t, h, w) > 0 && crfp_cra_batch_workspace_bytes(n, t, h, w) >= sn / 2);
                     EXPECT(crfp_cra_batch_status_offset(n, t, h, w) < crfp_cra_batch_workspace_bytes(n, t, h, w));
+                    EXPECT(crfp_simple_batch_workspace_bytes(n, t, h, w) > sn && crfp_dense_batch_workspace_bytes_bf16(n, t, h, w) > 0);   // 8 feature quads per level instead of 6
+                    EXPECT(crfp_simple_batch_status_offset(n, t, h, w) + 4ull * n <= crfp_simple_batch_workspace_bytes(n, t, h, w));
                 }
             }
     EXPECT(crfp_dsv_batch_workspace_bytes(0, 7, 180, 320) == 0 && crfp_dsv_batch_workspace_bytes(-3, 7, 180, 320) == 0);
@@ -58,6 +60,16 @@ int main() {
     int nc = 0;
     while (crfp_cra_param_name(nc)) { EXPECT(crfp_cra_param_numel(nc, 0) > 0); ++nc; }
     EXPECT(nc > np);
+    // CRFP_simple / CRFP: CRFP_DSV's names, four other shapes (upsample: 128 rows; upsample_post: 32 columns; dense: 96 / 12 columns in main.0)
+    {
+        int other_s = 0, other_d = 0;
+        for (int i = 0; i < np; ++i) {
+            EXPECT(crfp_simple_param_numel(i, 0) > 0 && crfp_dense_param_numel(i, 1) > 0);
+            other_s += crfp_simple_param_numel(i, 0) != crfp_dsv_param_numel(i, 0);
+            other_d += crfp_dense_param_numel(i, 0) != crfp_dsv_param_numel(i, 0);
+        }
+        EXPECT(other_s == 3 && other_d == 7 && crfp_simple_param_numel(np, 0) <= 0 && crfp_dense_param_numel(-1, 0) <= 0);
+    }
     int nr = 0;
     while (crfp_rt_param_name(nr)) { EXPECT(crfp_rt_param_numel(nr, 0) > 0); ++nr; }
     EXPECT(nr > 0);
@@ -77,6 +89,8 @@ int main() {
     EXPECT(crfp_dsv_forward_batch(p16, 0, p16, p16, m16, p16, 0, 7, 180, 320, p16, (size_t)1 << 40, nullptr) != 0);
     EXPECT(crfp_dsv_forward_batch_bf16(p16, 0, p16, p16, m16, p16, 2, 7, 180, 320, p16, 64, nullptr) != 0);
     EXPECT(crfp_cra_forward_batch(p16, 0, p16, p16, m16, p16, 2, 7, 180, 320, p16, 64, nullptr) != 0);
+    EXPECT(crfp_simple_forward_batch(p16, 0, p16, p16, m16, p16, 2, 7, 180, 320, p16, 64, nullptr) != 0);
+    EXPECT(crfp_dense_forward_batch_bf16(p16, 0, p16, nullptr, m16, p16, 1, 7, 180, 320, p16, (size_t)1 << 40, nullptr) != 0);
     EXPECT(crfp_dsv_forward_clip_bf16(p16, CRFP_DSV_STRICT_F32, p16, p16, m16, p16, 7, 180, 320, p16, (size_t)1 << 40, nullptr) != 0);
     EXPECT(std::strlen(crfp_last_error_string()) > 0);
     // ---- whole engine calls on the stub runtime (tools/asan_host/hip_stub.cpp: every HIP call succeeds, no kernel runs): the host side of a
@@ -96,6 +110,9 @@ int main() {
         EXPECT(crfp_dsv_pack_weights(params, 0, pk, crfp_dsv_packed_weight_bytes(0), stream) == 0);
         EXPECT(crfp_dsv_pack_weights_bf16(params, 0, pk, crfp_dsv_packed_weight_bytes_bf16(0), stream) == 0);
         EXPECT(crfp_cra_pack_weights(params, 0, pk, crfp_cra_packed_weight_bytes(0), stream) == 0);
+        EXPECT(crfp_simple_pack_weights(params, 1, pk, crfp_simple_packed_weight_bytes(1), stream) == 0);
+        EXPECT(crfp_dense_pack_weights_bf16(params, 0, pk, crfp_dense_packed_weight_bytes_bf16(0), stream) == 0);
+        EXPECT(crfp_dense_pack_weights(params, 0, pk, crfp_dsv_packed_weight_bytes(0), stream) != 0);   // the wider main.0 images need more
         EXPECT(crfp_rt_pack_weights(params, 0, pk, crfp_rt_packed_weight_bytes(0), stream) == 0);
         EXPECT(crfp_dsv_pack_weights(params, 0, pk, 1024, stream) != 0);   // packed buffer too small
         const int geo[][2] = {{20, 36}, {33, 47}, {101, 170}, {180, 320}};
@@ -110,6 +127,10 @@ int main() {
                     EXPECT(crfp_dsv_forward_batch(pk, 0, lrs, fvs, mks, out, n, t, h, w, wsp, crfp_dsv_batch_workspace_bytes(n, t, h, w), stream) == 0);
                     EXPECT(crfp_dsv_forward_batch_bf16(pk, 0, lrs, fvs, mks, out, n, t, h, w, wsp, crfp_dsv_batch_workspace_bytes_bf16(n, t, h, w), stream) == 0);
                     EXPECT(crfp_cra_forward_batch(pk, 0, lrs, fvs, mks, out, n, t, h, w, wsp, crfp_cra_batch_workspace_bytes(n, t, h, w), stream) == 0);
+                    EXPECT(crfp_simple_forward_batch(pk, n == 2 ? CRFP_DSV_STRICT_F32 : 0, lrs, fvs, mks, out, n, t, h, w, wsp, crfp_simple_batch_workspace_bytes(n, t, h, w), stream) == 0);
+                    EXPECT(crfp_dense_forward_batch(pk, CRFP_DSV_SINGLE_STREAM, lrs, fvs, mks, out, n, t, h, w, wsp, crfp_dense_batch_workspace_bytes(n, t, h, w), stream) == 0);
+                    EXPECT(crfp_dense_forward_batch_bf16(pk, 0, lrs, fvs, mks, out, n, t, h, w, wsp, crfp_dense_batch_workspace_bytes_bf16(n, t, h, w), stream) == 0);
+                    EXPECT(crfp_simple_forward_batch(pk, 0, lrs, fvs, mks, out, n, t, h, w, wsp, crfp_dsv_batch_workspace_bytes(n, t, h, w), stream) != 0);   // CRFP_DSV's smaller workspace
                     EXPECT(crfp_dsv_forward_batch(pk, 0, lrs, fvs, mks, out, n, t, h, w, wsp, crfp_dsv_batch_workspace_bytes(n, t, h, w) - 1, stream) != 0);
                 }
             }
