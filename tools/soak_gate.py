@@ -13,8 +13,8 @@ dev = torch.device("cuda:0")
 T = torch.from_numpy
 
 
-def model(cls, storage):
-    m = cls(device=dev, mid_channels=32)
+def model(cls, storage, mid=32):
+    m = cls(device=dev, mid_channels=mid)
     sd = synth.make_state_dict_like({k: tuple(v.shape) for k, v in m.state_dict().items()}, 3)
     m.load_state_dict({k: T(v) for k, v in sd.items()})
     m = m.to(dev).eval()
@@ -25,9 +25,9 @@ def model(cls, storage):
 bad = 0
 with torch.no_grad():
     for storage in ("f32", "bf16"):
-        for cls in (CRFP.CRFP_DSV, CRFP.CRFP_DSV_CRA):
+        for cls, mid in ((CRFP.CRFP_DSV, 32), (CRFP.CRFP_DSV_CRA, 32), (CRFP.CRFP_simple, 32), (CRFP.CRFP, 32), (CRFP.CRFP_DSV, 16)):
             for n in (1, 4):
-                m = model(cls, storage)
+                m = model(cls, storage, mid)
                 lrs, fvs, mks = (T(x).to(dev) for x in synth.make_clip(77 + n, n, 7, 180, 320, fv_size=96, sigma_t=50.0))
                 ref = m(lrs, fvs, mks).clone()
                 t0 = time.perf_counter()
@@ -36,7 +36,7 @@ with torch.no_grad():
                     diff += int(not torch.equal(m(lrs, fvs, mks), ref))
                 torch.cuda.synchronize()
                 bad += diff
-                print(f"{cls.__name__:14s} {storage:4s} clips/call {n}: {a.iters // (2 if n == 4 else 1)} calls, {diff} differ, finite {bool(torch.isfinite(ref).all())}, {time.perf_counter() - t0:.1f} s", flush=True)
+                print(f"{cls.__name__ + ('' if mid == 32 else '/' + str(mid)):14s} {storage:4s} clips/call {n}: {a.iters // (2 if n == 4 else 1)} calls, {diff} differ, finite {bool(torch.isfinite(ref).all())}, {time.perf_counter() - t0:.1f} s", flush=True)
         # one frame per call, resident inputs (the side stream runs ahead of the caller's): 3 passes over a 60-frame sequence
         m = model(CRFP.CRFP_DSV, storage)
         m.inputs_resident = True
