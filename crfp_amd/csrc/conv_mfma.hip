@@ -673,7 +673,10 @@ __device__ __forceinline__ void load_quad_batch_v(f32x4 (&r)[NIN], const ConvSrc
 
 // The kernel's body: workgroup wg_x of wg_nx (the launch's work items: (tile, cout-tile group)) of batch item n of plan a.  A function so that
 // conv3x3_split_dual_kernel (below) can run TWO plans in one launch.
-template <int CT, int RPW, int NP>
+// KS (round 6, FNet's small maps): blockIdx.z enumerates (batch item, K slice) -- slice z % a.ksplit walks chunks [slice * nchunks / ksplit, ...) of
+// source item z / ksplit and stores its raw partial sums as "item" z of a float Q4 destination (the bias rides in slice 0; the launcher passes
+// act NONE / no residual / no guard); launch_ksplit_reduce or the pool / resize pass behind the layer adds the slices in order.
+template <int CT, int RPW, int NP, bool KS = false>
 __device__ __forceinline__ void conv3x3_split_body(const ConvArgs& a, const int wg_x, const int wg_nx, const int n) {
 #ifdef CRFP_LAB
     const long long t_entry = __builtin_amdgcn_s_memtime();
@@ -695,7 +698,8 @@ __device__ __forceinline__ void conv3x3_split_body(const ConvArgs& a, const int 
     const int btile = bwork / ngrp;
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = (bwork - btile * ngrp) * CT;
-    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
+    const int kslices = KS ? a.ksplit : 1, kslice = KS ? n % kslices : 0, item = KS ? n / kslices : n;
+    const int ns = a.src_bgroup > 0 ? item + item / a.src_bgroup : item;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 
     // halo pixels of this thread: clamped coordinates (every load is unconditional and in range; pixels
@@ -719,7 +723,7 @@ __device__ __forceinline__ void conv3x3_split_body(const ConvArgs& a, const int 
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[ct][pt][e] = 0.0f; acl[ct][pt][e] = 0.0f; }
-    {   // accumulators start at the bias: its loads are the first of the kernel and long landed when the MFMAs begin
+    if (!KS || kslice == 0) {   // accumulators start at the bias: its loads are the first of the kernel and long landed when the MFMAs begin
         const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -771,8 +775,9 @@ __device__ __forceinline__ void conv3x3_split_body(const ConvArgs& a, const int 
 #ifdef CRFP_LAB
     long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
 #endif
-    CRFP_SPLIT_ISSUE(0)
-    for (int ch = 0; ch < nchunks; ++ch) {
+    const int ch_begin = KS ? kslice * (nchunks / kslices) : 0, ch_end = KS ? ch_begin + nchunks / kslices : nchunks;
+    CRFP_SPLIT_ISSUE(ch_begin)
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;  // component masks of the chunk now in registers
         __syncthreads();  // every wave finished reading the previous chunk
 #ifdef CRFP_LAB
@@ -832,7 +837,7 @@ __device__ __forceinline__ void conv3x3_split_body(const ConvArgs& a, const int 
 #ifdef CRFP_LAB
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tB += t - t0; t0 = t; }
 #endif
-        if (ch + 1 < nchunks) CRFP_SPLIT_ISSUE(ch + 1)
+        if (ch + 1 < ch_end) CRFP_SPLIT_ISSUE(ch + 1)
 #ifdef CRFP_LAB
         if (a.stamps) { const long long t = __builtin_amdgcn_s_memtime(); tD += t - t0; t0 = t; }  // diagnostic: issue booked under D
 #endif
@@ -904,6 +909,11 @@ template <int CT, int RPW, int NP>
 __global__ __launch_bounds__(256, NP == 2 && CT == 1 && RPW == 1 ? 3 : 2) void conv3x3_split_kernel(const ConvArgs a) {
     conv3x3_split_body<CT, RPW, NP>(a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
 }
+#ifndef CRFP_ACT_BF16
+__global__ __launch_bounds__(256, 3) void conv3x3_split_ks_kernel(const ConvArgs a) {
+    conv3x3_split_body<1, 1, 2, true>(a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+}
+#endif
 
 #ifndef CRFP_ACT_BF16
 // Round 6: TWO independent convs of the same shape in ONE launch (workgroups [0, w0) run plan a0, the rest plan a1; w0 is a multiple of 8, so a
@@ -1314,7 +1324,7 @@ __device__ __forceinline__ cu32x2 quad_words(cu32x2 r, int m, bool valid) {
 #define CRFP_BF16_LB 5   // workgroups per CU the register allocation aims at.  Round 4, same box, 4-clip lock-step batch: 4 -> 5 takes the kernel
                          // sum per clip 5.67 -> 5.60 ms (32 -> 32 convs 9.4 -> 8.9 us), one-clip calls unchanged; 6 spills (40 B) and loses 6 %
 #endif
-template <int RPW>
+template <int RPW, bool KS = false>   // KS: K slices over blockIdx.z, see conv3x3_split_body
 __global__ __launch_bounds__(256, RPW == 1 ? CRFP_BF16_LB : 3) void conv3x3_bf16_kernel(const ConvArgs a) {
     constexpr int CT = 1, TH = 4 * RPW, LH = TH + 2, PT = 2 * RPW;
     constexpr int NEL = LH * LW;                 // halo pixels
@@ -1333,7 +1343,8 @@ __global__ __launch_bounds__(256, RPW == 1 ? CRFP_BF16_LB : 3) void conv3x3_bf16
     const int tx0 = (btile % tiles_x) * TW, ty0 = (btile / tiles_x) * TH;
     const int T0 = bwork - btile * ngrp;
     const int n = blockIdx.z;
-    const int ns = a.src_bgroup > 0 ? n + n / a.src_bgroup : n;   // source batch item (ConvArgs::src_bgroup)
+    const int kslices = KS ? a.ksplit : 1, kslice = KS ? n % kslices : 0, item = KS ? n / kslices : n;
+    const int ns = a.src_bgroup > 0 ? item + item / a.src_bgroup : item;   // source batch item (ConvArgs::src_bgroup)
     const int H = a.H, W = a.W;
 
     int cgy[NIN], cgx[NIN];
@@ -1349,7 +1360,12 @@ __global__ __launch_bounds__(256, RPW == 1 ? CRFP_BF16_LB : 3) void conv3x3_bf16
     }
 
     f32x16 acc[CT][PT];
-    {   // accumulators start at the bias
+    if (KS && kslice != 0) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][pt][e] = 0.0f;
+    } else {   // accumulators start at the bias
         const float4* __restrict__ bp = reinterpret_cast<const float4*>(a.bpk);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1389,8 +1405,9 @@ __global__ __launch_bounds__(256, RPW == 1 ? CRFP_BF16_LB : 3) void conv3x3_bf16
         }                                                                                                 \
     }
 
-    CRFP_BF16_ISSUE(0)
-    for (int ch = 0; ch < nchunks; ++ch) {
+    const int ch_begin = KS ? kslice * (nchunks / kslices) : 0, ch_end = KS ? ch_begin + nchunks / kslices : nchunks;
+    CRFP_BF16_ISSUE(ch_begin)
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int m0 = qm0, m1 = qm1, m2 = qm2, m3 = qm3;
         __syncthreads();  // every wave finished reading the previous chunk
         if ((m0 & m1 & m2 & m3) == 15 && !((m0 | m1 | m2 | m3) & 32)) {   // wave-uniform: 16 real bf16 channels -> plain copy
@@ -1421,7 +1438,7 @@ __global__ __launch_bounds__(256, RPW == 1 ? CRFP_BF16_LB : 3) void conv3x3_bf16
             if (idx < WPC) wlds[idx] = rws[k];
         }
         __syncthreads();
-        if (ch + 1 < nchunks) CRFP_BF16_ISSUE(ch + 1)
+        if (ch + 1 < ch_end) CRFP_BF16_ISSUE(ch + 1)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
@@ -2807,6 +2824,88 @@ int launch_conv_mfma_dual(const ConvArgs& a0, const char* name0, const ConvArgs&
 #endif
     const int rc = launch_conv_mfma(a0, name0, s);
     return rc ? rc : launch_conv_mfma(a1, name1, s);
+}
+
+// ---------------------------------------------------------------- K slices for small maps (round 6: FNet's deep layers) -- measured, NOT shipped
+// A conv over a small map is a handful of workgroups each walking ALL its 16-channel chunks in turn: FNet's 256 -> 256 layer on a 22 x 40 map is 48
+// workgroups x 16 chunks = 53 us on a chip of 256 CUs.  conv_auto_ksplit cuts K into `ks` slices that run as workgroups of their own (the rule
+// reads the layer's geometry only, never the batch size: one pair per call and a whole clip's pairs must take the same slices, or the
+// one-frame-per-call results would stop being bit-identical to the clip call's); launch_conv_ksplit runs them -- slice k of item n stores its raw
+// partial sums (bias in slice 0) as float Q4 item n * ks + k of `part` -- and launch_ksplit_reduce, or the pool / resize pass that reads the layer
+// anyway, adds the slices in order, applies the activation, rounds to the storage type and guards the fp16 operand range, as the conv's
+// epilogue would have.  Same box, product builds (profiles/r06_fnet_ksplit_ab.txt): fp32 FNet of ONE pair 318 -> 270 us and the one-frame-per-call
+// rate without the resident promise 600 -> 619 frames/s -- but the six pairs of a clip 598 -> 690 us (their layers already fill the chip; the
+// partial tensors are 50 MB per pair of extra traffic) and the fp32 HEADLINE clip 9.177 -> 9.266 ms; bf16 build: one pair 219 -> 215 us (its
+// chunks are three times cheaper: nothing to shorten), six pairs 350 -> 495 us.  A rule that may not look at the batch size cannot have the one
+// without the other, so the product keeps every layer in one piece; the lab library takes the slices with CRFP_CONV_KSPLIT=1 (fp32 build) / 2 (both).
+int conv_auto_ksplit(int H, int W, int ctiles, int kq) {
+#ifdef CRFP_LAB
+    static const int on = getenv("CRFP_CONV_KSPLIT") ? atoi(getenv("CRFP_CONV_KSPLIT")) : 0;
+#else
+    constexpr int on = 0;
+#endif
+    if (on < (kActBf16 ? 2 : 1) || (kq & 3)) return 1;
+    const int nch = kq >> 2;
+    const long long wgs = (long long)((W + TW - 1) / TW) * ((H + 3) / 4) * ctiles;   // 4-row tiles of the four-wave kernels
+    int ks = 1;
+    while (ks < 8 && nch % (2 * ks) == 0 && nch / (2 * ks) >= 2 && wgs * 2 * ks <= 384) ks *= 2;
+    return ks;
+}
+
+// a: the layer's plan as launch_conv_mfma takes it, with a.ksplit = ks, a.N = items (not items * ks), one ST_Q4 destination = `part`
+// (bstride = floats of one (item, slice) = cout-quads * H * W * 4); activation, residual and guard belong to the reduce pass
+int launch_conv_ksplit(const ConvArgs& a, const char* name, hipStream_t s) {
+    bool q4 = true;
+    for (int i = 0; i < a.nsrc; ++i) q4 = q4 && (a.src[i].kind == SRC_Q4 || a.src[i].kind == SRC_ZERO);
+    const int nch = a.kq >> 2;
+    if (a.ksplit < 2 || (a.kq & 3) || a.kq > CRFP_MAX_KQ || nch % a.ksplit || !q4 || !a.wsplit || a.strict || precision_env_strict(0) || a.store != ST_Q4 ||
+        a.ndst != 1 || a.resid || a.s3_dst || a.post_scale != 1.0f || (a.cout & 3)) {
+        set_error("conv_ksplit %s: unsupported plan (ksplit=%d kq=%d store=%d ndst=%d strict=%d)", name, a.ksplit, a.kq, a.store, a.ndst, a.strict);
+        return CRFP_E_UNSUPPORTED;
+    }
+    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + 3) / 4);
+    double in_ch = 0;
+    for (int i = 0; i < a.nsrc; ++i) in_ch += a.src[i].kind == SRC_ZERO ? 0 : a.src[i].nch;
+    const double px = (double)a.N * a.H * a.W;
+    ProfScope prof(name, s, px * (in_ch * (double)sizeof(act_t) + a.cout * 4.0 * a.ksplit) + (double)a.cout * in_ch * 9 * 4.0, 2.0 * px * a.cout * in_ch * 9.0);
+    ConvArgs& am = const_cast<ConvArgs&>(a);   // callers pass a private, mutable plan copy
+    am.stamps = nullptr;
+    am.act = CRFP_ACT_NONE;
+    am.dst_f32 = 1;
+    am.ovf = nullptr;
+    am.wsplit16 = (const char*)a.wsplit + conv_split16_offset_bytes(a);
+#ifndef CRFP_ACT_BF16
+    am.wsplit_sa = (const char*)a.wsplit + conv_split_sa_offset_bytes(a);
+#endif
+    const int rc = build_quad_descs(am, name);
+    if (rc) return rc;
+    const dim3 grid(tiles * a.ctiles, 1, a.N * a.ksplit);
+#ifdef CRFP_ACT_BF16
+    conv3x3_bf16_kernel<1, true><<<grid, 256, 0, s>>>(am);
+#else
+    conv3x3_split_ks_kernel<<<grid, 256, 0, s>>>(am);
+#endif
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[n] (Q4, storage type) = act(sum over k of part[n * ks + k]) in slice order; values an fp16 operand cannot hold raise item n's status word
+__global__ void ksplit_reduce_kernel(const float* __restrict__ part, long long pb, int ks, act_t* __restrict__ out, long long ob, long long quads, int act,
+                                     unsigned* ovf, int ovf_div, int ovf_add) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= quads) return;
+    const int n = blockIdx.y;
+    const cf32x4 v = ksplit_load(part, pb, ks, n, i * 4, act, ovf_word(ovf, ovf_div, ovf_add, n));
+    stq(out + (long long)n * ob + i * 4, v);
+}
+
+int launch_ksplit_reduce(const float* part, long long pb, int ks, float* out, long long ob, int N, int nq, int H, int W, int act, unsigned* ovf, int ovf_div,
+                         int ovf_add, hipStream_t s) {
+    const long long quads = (long long)nq * H * W;
+    ProfScope prof("ksplit_reduce_q4", s, (double)N * quads * (16.0 * ks + 4.0 * sizeof(act_t)), 0);
+    ksplit_reduce_kernel<<<dim3((unsigned)((quads + 255) / 256), N), 256, 0, s>>>(part, pb, ks, as_act(out), ob, quads, act, ovf, ovf_div, ovf_add);
+    CRFP_CHECK_LAUNCH();
+    return 0;
 }
 
 #ifdef CRFP_ACT_BF16

@@ -309,6 +309,31 @@ __device__ __forceinline__ unsigned* ovf_word(unsigned* base, int div, int add, 
     return (skip0 && g == q * div) ? nullptr : base + q;
 }
 
+// What a K-sliced conv (launch_conv_ksplit, conv_mfma.hip) would have stored at float offset `off` of batch item n: the sum of its ks partial
+// tensors in slice order (the bias rides in slice 0), the activation (NONE / RELU / LRELU(0.1) as the conv epilogue's max(v, slope v)), rounded to
+// the storage type; a value an fp16 operand cannot hold raises `ovfw` as the epilogue's guard would.  part: float Q4, pb floats per (item, slice).
+__device__ __forceinline__ cf32x4 ksplit_load(const float* __restrict__ part, long long pb, int ks, int n, long long off, int act, unsigned* ovfw) {
+    const float* p = part + (long long)n * ks * pb + off;
+    cf32x4 v = *reinterpret_cast<const cf32x4*>(p);
+    for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const cf32x4*>(p + (long long)k * pb);
+    const float slope = act == CRFP_ACT_RELU ? 0.0f : (act == CRFP_ACT_LRELU01 ? 0.1f : 1.0f);
+    v = cf32x4{fmaxf(v.x, slope * v.x), fmaxf(v.y, slope * v.y), fmaxf(v.z, slope * v.z), fmaxf(v.w, slope * v.w)};
+    const float vmax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (ovfw && !(vmax < 65504.0f)) atomicOr(ovfw, 1u);
+#ifdef CRFP_ACT_BF16
+    v = quad_from_bits(quad_to_bits(v));
+#endif
+    return v;
+}
+// the K slices a source tensor arrives in (null part: an ordinary Q4 tensor)
+struct KsIn {
+    const float* part = nullptr;   // float Q4 partial tensors, item n slice k at (n * ks + k) * pb
+    long long pb = 0;
+    int ks = 0, act = 0;
+    unsigned* ovf = nullptr;
+    int ovf_div = 0, ovf_add = 0;
+};
+
 // ------------------------------------------------------------------ XCD-aware tile order
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  With the natural order two
 // neighbouring tiles (which share halo rows / gathered lines) always sit on different XCDs and both fetch the shared lines
@@ -412,6 +437,14 @@ int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long
 int launch_avgpool2_nchw(const float* x, float* out, int N, int C, int H, int W, hipStream_t s);
 int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, int N, int nq, int H, int W,
                        hipStream_t s);
+// K slices for small maps (round 6, conv_mfma.hip / resample.hip): the geometry-only rule, the sliced conv, and the three passes that add the slices
+int conv_auto_ksplit(int H, int W, int ctiles, int kq);
+int launch_conv_ksplit(const ConvArgs& a, const char* name, hipStream_t s);
+int launch_ksplit_reduce(const float* part, long long pb, int ks, float* out, long long ob, int N, int nq, int H, int W, int act, unsigned* ovf, int ovf_div,
+                         int ovf_add, hipStream_t s);
+int launch_avgpool2_q4_ks(const KsIn& in, float* out, long long ob, int N, int nq, int H, int W, hipStream_t s);
+int launch_upsample_q4_ks(const KsIn& in, float* out, long long ob, int N, int nq, int H, int W, int OH, int OW, float sh, float sw, float mul,
+                          hipStream_t s);
 // N > 1: lr_b / fv_b / mk_b = elements between the batch items of the three API tensors (frames of different clips), out_b likewise
 // gate (optional, launch_mask_gate): only tiles with a mask pixel within 3 tiles are produced (what encoder_hr's two convs then read)
 int launch_hr_prep(const float* lr, const float* fv, const uint8_t* mk, float* out_q4, int h, int w, hipStream_t s, int N = 1,

@@ -17,6 +17,7 @@
 #include "crfp_common.h"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -403,6 +404,9 @@ struct Layout {
     long long gate_b;
     int h1, w1, h2, w2, h3, w3;
     int fnet_cap;   // pairs one FNet pass can hold
+    // FNet's small maps run their convs in K slices (conv_auto_ksplit): the float partial tensors of the layer in flight (the largest layer's ks * cout * H * W
+    // floats per pair)
+    Ten fpart;
 
     Layout(int B_, int t_, int h_, int w_, int wiring = W_DSV) : B(B_), t(t_), h(h_), w(w_), cra(wiring == W_CRA), pq(wiring >= W_SIMPLE ? 8 : 6) {
         flat = (long long)B * t <= kFlatFrames;
@@ -443,6 +447,17 @@ struct Layout {
         fu3 = A.take("fnet.u3", nb, 16, 8 * h3, 8 * w3);
         fg0 = A.take("fnet.g0", nb, 8, 8 * h3, 8 * w3);
         fg1 = A.take("fnet.g1", nb, 1, 8 * h3, 8 * w3, 0, 0, true);
+        {
+            const int lh[7] = {h, h1, h2, h3, 2 * h3, 4 * h3, 8 * h3}, lw[7] = {w, w1, w2, w3, 2 * w3, 4 * w3, 8 * w3};
+            long long most = 0;
+            for (int i = 0; i < 14; ++i) {
+                const int kq = (kConvs[i].cin / 4 + 3) / 4 * 4, H = lh[i / 2], W = lw[i / 2];
+                const int ks = H > 0 && W > 0 ? conv_auto_ksplit(H, W, (kConvs[i].cout + 31) / 32, kq) : 1;
+                if (ks > 1) most = std::max(most, (long long)ks * kConvs[i].cout * H * W);
+            }
+            const long long per = (long long)h * w * 4;
+            fpart = A.take("fnet.part", nb, (int)((most + per - 1) / per), h, w, 0, 0, true);
+        }
         // state-independent per-frame work (fovea blend, encoder_hr, upsample conv, flow upsampling) is
         // produced one or two frames ahead on a side stream -> two buffer sets, indexed by frame parity
         for (int p = 0; p < 2; ++p) {
@@ -849,24 +864,46 @@ struct Runner {
         Q4 g0 = q(L.fg0, 8, 8 * L.h3, 8 * L.w3), g1 = q(L.fg1, 1, 8 * L.h3, 8 * L.w3), fl = q(L.flow_lr, 1, h, w);
         fl.p = flow_out;
         mfma(IT_F0, nb, h, w, {{cur, cur_bs}, {prev, prev_bs}}, {{a0.p, a0.bs(), 0, 8}}, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, group);
-        mfma_q(IT_F0 + 1, nb, a0, a1);
-        RUN(launch_avgpool2_q4(a1.p, a1.bs(), p1.p, p1.bs(), nb, 8, h, w, s));
-        mfma_q(IT_F0 + 2, nb, p1, b0);
-        mfma_q(IT_F0 + 3, nb, b0, b1);
-        RUN(launch_avgpool2_q4(b1.p, b1.bs(), p2.p, p2.bs(), nb, 16, L.h1, L.w1, s));
-        mfma_q(IT_F0 + 4, nb, p2, c0);
-        mfma_q(IT_F0 + 5, nb, c0, c1);
-        RUN(launch_avgpool2_q4(c1.p, c1.bs(), p3.p, p3.bs(), nb, 32, L.h2, L.w2, s));
-        mfma_q(IT_F0 + 6, nb, p3, d0);
-        mfma_q(IT_F0 + 7, nb, d0, d1);
-        RUN(launch_upsample_q4(d1.p, d1.bs(), u1.p, u1.bs(), nb, 64, d1.H, d1.W, u1.H, u1.W, 0.5f, 0.5f, 1.0f, s, 0));
-        mfma_q(IT_F0 + 8, nb, u1, e0);
-        mfma_q(IT_F0 + 9, nb, e0, e1);
-        RUN(launch_upsample_q4(e1.p, e1.bs(), u2.p, u2.bs(), nb, 32, e1.H, e1.W, u2.H, u2.W, 0.5f, 0.5f, 1.0f, s, 0));
-        mfma_q(IT_F0 + 10, nb, u2, f0);
-        mfma_q(IT_F0 + 11, nb, f0, f1);
-        RUN(launch_upsample_q4(f1.p, f1.bs(), u3.p, u3.bs(), nb, 16, f1.H, f1.W, u3.H, u3.W, 0.5f, 0.5f, 1.0f, s, 0));
-        mfma_q(IT_F0 + 12, nb, u3, g0);
+        // Round 6: a layer over a small map runs in K slices (conv_auto_ksplit: the layer's geometry decides, never the number of pairs, so one pair per
+        // call and a clip's pairs compute the same bits); its partial tensors are added by the pool / resize pass behind it -- which reads the layer
+        // anyway -- or by launch_ksplit_reduce.  conv(i, in, out) returns the slices (1: `out` holds the layer as before).
+        KsIn ki;
+        auto conv = [&](int i, const Q4& in, const Q4& out) {
+            const Item& it = M.items[IT_F0 + i];
+            static const bool env_strict = precision_env_strict(0);
+            const int ks = (strict || env_strict || rc) ? 1 : conv_auto_ksplit(in.H, in.W, it.c.ctiles, it.c.kq);
+            if (ks < 2) { mfma_q(IT_F0 + i, nb, in, out); return 1; }
+            const long long pb = out.bs();   // floats of one (pair, slice): the layer's quads
+            ConvArgs a = plan(IT_F0 + i, nb, in.H, in.W, {{in.p, in.bs()}}, {{F(L.fpart), pb, 0, out.nq}}, 0, 0);
+            a.ksplit = ks;
+            ki.part = F(L.fpart); ki.pb = pb; ki.ks = ks; ki.act = it.c.act;
+            ki.ovf = ovf(); ki.ovf_div = ovf_div; ki.ovf_add = ovf_add;
+            rc = launch_conv_ksplit(a, it.name, s);
+            return ks;
+        };
+        auto reduce = [&](int ks, const Q4& out) {   // the layer as an ordinary tensor (its reader is another conv)
+            if (ks > 1) RUN(launch_ksplit_reduce(ki.part, ki.pb, ks, out.p, out.bs(), nb, out.nq, out.H, out.W, ki.act, ki.ovf, ki.ovf_div, ki.ovf_add, s));
+        };
+        auto pool = [&](int ks, const Q4& in, const Q4& out) {
+            if (ks > 1) RUN(launch_avgpool2_q4_ks(ki, out.p, out.bs(), nb, in.nq, in.H, in.W, s));
+            else RUN(launch_avgpool2_q4(in.p, in.bs(), out.p, out.bs(), nb, in.nq, in.H, in.W, s));
+        };
+        auto resize2 = [&](int ks, const Q4& in, const Q4& out) {
+            if (ks > 1) RUN(launch_upsample_q4_ks(ki, out.p, out.bs(), nb, in.nq, in.H, in.W, out.H, out.W, 0.5f, 0.5f, 1.0f, s));
+            else RUN(launch_upsample_q4(in.p, in.bs(), out.p, out.bs(), nb, in.nq, in.H, in.W, out.H, out.W, 0.5f, 0.5f, 1.0f, s, 0));
+        };
+        pool(conv(1, a0, a1), a1, p1);
+        reduce(conv(2, p1, b0), b0);
+        pool(conv(3, b0, b1), b1, p2);
+        reduce(conv(4, p2, c0), c0);
+        pool(conv(5, c0, c1), c1, p3);
+        reduce(conv(6, p3, d0), d0);
+        resize2(conv(7, d0, d1), d1, u1);
+        reduce(conv(8, u1, e0), e0);
+        resize2(conv(9, e0, e1), e1, u2);
+        reduce(conv(10, u2, f0), f0);
+        resize2(conv(11, f0, f1), f1, u3);
+        reduce(conv(12, u3, g0), g0);
         // tanh * 256 flow and its resize to (h, w) stay float in both builds (coordinates)
         mfma(IT_F0 + 13, nb, g0.H, g0.W, {{g0.p, g0.bs()}}, {{g1.p, g1.bs(), 0, g1.nq}}, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 1);
         RUN(crfp::launch_upsample_q4(g1.p, g1.bs(), fl.p, fl.bs(), nb, 1, g1.H, g1.W, h, w, (float)g1.H / (float)h,

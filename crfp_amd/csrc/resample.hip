@@ -114,8 +114,10 @@ int launch_offmask_nchw_to_q4(const float* offset, const float* mask, float* out
 
 // bilinear resize of a Q4 tensor; out = mul * (l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11))
 // out_bgroup > 0: batch item n WRITES destination item n + n / out_bgroup (see ConvArgs::src_bgroup: FNet's per-clip pair mapping)
+// KS: the source arrives as the K slices of the conv that produced it (launch_conv_ksplit): every tap is ksplit_load's reduced, activated value
+template <bool KS>
 __global__ void upsample_q4_kernel(const act_t* __restrict__ x, long long xb, act_t* __restrict__ out, long long ob,
-                                   int nq, int H, int W, int OH, int OW, float sh, float sw, float mul, int out_bgroup) {
+                                   int nq, int H, int W, int OH, int OW, float sh, float sw, float mul, int out_bgroup, const KsIn ki) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= OW || oy >= OH) return;
@@ -125,10 +127,12 @@ __global__ void upsample_q4_kernel(const act_t* __restrict__ x, long long xb, ac
     src_index(oy, sh, H, y0, y1, ly0, ly1);
     src_index(ox, sw, W, x0, x1, lx0, lx1);
     const act_t* p = x + (long long)n * xb + (long long)q * H * W * 4;
-    const cf32x4 a = ldq(p + ((long long)y0 * W + x0) * 4);
-    const cf32x4 b = ldq(p + ((long long)y0 * W + x1) * 4);
-    const cf32x4 c = ldq(p + ((long long)y1 * W + x0) * 4);
-    const cf32x4 d = ldq(p + ((long long)y1 * W + x1) * 4);
+    unsigned* const ow = KS ? ovf_word(ki.ovf, ki.ovf_div, ki.ovf_add, n) : nullptr;
+    const long long qo = (long long)q * H * W * 4;
+    const cf32x4 a = KS ? ksplit_load(ki.part, ki.pb, ki.ks, n, qo + ((long long)y0 * W + x0) * 4, ki.act, ow) : ldq(p + ((long long)y0 * W + x0) * 4);
+    const cf32x4 b = KS ? ksplit_load(ki.part, ki.pb, ki.ks, n, qo + ((long long)y0 * W + x1) * 4, ki.act, ow) : ldq(p + ((long long)y0 * W + x1) * 4);
+    const cf32x4 c = KS ? ksplit_load(ki.part, ki.pb, ki.ks, n, qo + ((long long)y1 * W + x0) * 4, ki.act, ow) : ldq(p + ((long long)y1 * W + x0) * 4);
+    const cf32x4 d = KS ? ksplit_load(ki.part, ki.pb, ki.ks, n, qo + ((long long)y1 * W + x1) * 4, ki.act, ow) : ldq(p + ((long long)y1 * W + x1) * 4);
     cf32x4 r;
     r.x = mul * (ly0 * (lx0 * a.x + lx1 * b.x) + ly1 * (lx0 * c.x + lx1 * d.x));
     r.y = mul * (ly0 * (lx0 * a.y + lx1 * b.y) + ly1 * (lx0 * c.y + lx1 * d.y));
@@ -142,7 +146,17 @@ int launch_upsample_q4(const float* x, long long xb, float* out, long long ob, i
                        int OW, float sh, float sw, float mul, hipStream_t s, int out_bgroup) {
     ProfScope prof("upsample_bilinear_q4", s, (double)N * nq * 16.0 * ((double)H * W + (double)OH * OW), 0);
     dim3 grid((OW + 63) / 64, (OH + 3) / 4, N * nq);
-    upsample_q4_kernel<<<grid, 256, 0, s>>>(as_act(x), xb, as_act(out), ob, nq, H, W, OH, OW, sh, sw, mul, out_bgroup);
+    upsample_q4_kernel<false><<<grid, 256, 0, s>>>(as_act(x), xb, as_act(out), ob, nq, H, W, OH, OW, sh, sw, mul, out_bgroup, KsIn());
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same resize of a tensor that arrives as K slices (launch_conv_ksplit): the reduce pass rides in the taps
+int launch_upsample_q4_ks(const KsIn& in, float* out, long long ob, int N, int nq, int H, int W, int OH, int OW, float sh, float sw, float mul,
+                          hipStream_t s) {
+    ProfScope prof("upsample_bilinear_q4", s, (double)N * nq * ((double)H * W * 16.0 * in.ks + (double)OH * OW * 4.0 * sizeof(act_t)), 0);
+    dim3 grid((OW + 63) / 64, (OH + 3) / 4, N * nq);
+    upsample_q4_kernel<true><<<grid, 256, 0, s>>>(nullptr, 0, as_act(out), ob, nq, H, W, OH, OW, sh, sw, mul, 0, in);
     CRFP_CHECK_LAUNCH();
     return 0;
 }
@@ -208,18 +222,21 @@ int launch_upflow(const float* flow_q4, long long fb, float* out_nhw2, long long
 #endif
 
 // AvgPool2d(2,2), floor mode: out = (v00 + v01 + v10 + v11) / 4 in that order
+template <bool KS>   // KS: see upsample_q4_kernel
 __global__ void avgpool2_q4_kernel(const act_t* __restrict__ x, long long xb, act_t* __restrict__ out, long long ob,
-                                   int nq, int H, int W) {
+                                   int nq, int H, int W, const KsIn ki) {
     const int OH = H / 2, OW = W / 2;
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= OW || oy >= OH) return;
     const int q = blockIdx.z % nq, n = blockIdx.z / nq;
     const act_t* p = x + (long long)n * xb + (long long)q * H * W * 4;
-    const cf32x4 a = ldq(p + ((long long)(2 * oy) * W + 2 * ox) * 4);
-    const cf32x4 b = ldq(p + ((long long)(2 * oy) * W + 2 * ox + 1) * 4);
-    const cf32x4 c = ldq(p + ((long long)(2 * oy + 1) * W + 2 * ox) * 4);
-    const cf32x4 d = ldq(p + ((long long)(2 * oy + 1) * W + 2 * ox + 1) * 4);
+    unsigned* const ow = KS ? ovf_word(ki.ovf, ki.ovf_div, ki.ovf_add, n) : nullptr;
+    const long long qo = (long long)q * H * W * 4;
+    const cf32x4 a = KS ? ksplit_load(ki.part, ki.pb, ki.ks, n, qo + ((long long)(2 * oy) * W + 2 * ox) * 4, ki.act, ow) : ldq(p + ((long long)(2 * oy) * W + 2 * ox) * 4);
+    const cf32x4 b = KS ? ksplit_load(ki.part, ki.pb, ki.ks, n, qo + ((long long)(2 * oy) * W + 2 * ox + 1) * 4, ki.act, ow) : ldq(p + ((long long)(2 * oy) * W + 2 * ox + 1) * 4);
+    const cf32x4 c = KS ? ksplit_load(ki.part, ki.pb, ki.ks, n, qo + ((long long)(2 * oy + 1) * W + 2 * ox) * 4, ki.act, ow) : ldq(p + ((long long)(2 * oy + 1) * W + 2 * ox) * 4);
+    const cf32x4 d = KS ? ksplit_load(ki.part, ki.pb, ki.ks, n, qo + ((long long)(2 * oy + 1) * W + 2 * ox + 1) * 4, ki.act, ow) : ldq(p + ((long long)(2 * oy + 1) * W + 2 * ox + 1) * 4);
     cf32x4 r;
     r.x = (((a.x + b.x) + c.x) + d.x) / 4.0f;
     r.y = (((a.y + b.y) + c.y) + d.y) / 4.0f;
@@ -232,7 +249,15 @@ int launch_avgpool2_q4(const float* x, long long xb, float* out, long long ob, i
                        hipStream_t s) {
     ProfScope prof("avgpool2_q4", s, (double)N * nq * 16.0 * ((double)H * W * 1.25), 0);
     dim3 grid((W / 2 + 63) / 64, (H / 2 + 3) / 4, N * nq);
-    avgpool2_q4_kernel<<<grid, 256, 0, s>>>(as_act(x), xb, as_act(out), ob, nq, H, W);
+    avgpool2_q4_kernel<false><<<grid, 256, 0, s>>>(as_act(x), xb, as_act(out), ob, nq, H, W, KsIn());
+    CRFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_avgpool2_q4_ks(const KsIn& in, float* out, long long ob, int N, int nq, int H, int W, hipStream_t s) {
+    ProfScope prof("avgpool2_q4", s, (double)N * nq * (double)H * W * (16.0 * in.ks + 1.0 * sizeof(act_t)), 0);
+    dim3 grid((W / 2 + 63) / 64, (H / 2 + 3) / 4, N * nq);
+    avgpool2_q4_kernel<true><<<grid, 256, 0, s>>>(nullptr, 0, as_act(out), ob, nq, H, W, in);
     CRFP_CHECK_LAUNCH();
     return 0;
 }

@@ -38,3 +38,17 @@ def test_round6_stencil_forms_are_bit_identical_to_the_launches_they_replace(env
         base["CRFP_CHECK_STORAGE"] = "bf16"
     assert _golden_check(base, lab=True, want="DIGEST") == _golden_check(dict(base, **env), lab=True, want="DIGEST")
     assert _golden_check(base, want="DIGEST") == _golden_check(base, lab=True, want="DIGEST")   # and the product computes the same clip
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_k_sliced_fnet_layers(storage):
+    """Lab library, CRFP_CONV_KSPLIT=2: FNet's small maps run their convs in K slices (conv_auto_ksplit / launch_conv_ksplit; the slices are added by
+    the pool / resize pass behind the layer or by launch_ksplit_reduce) -- measured and not shipped (conv_mfma.hip).  The sliced layers move the golden
+    clip by summation order only: inside the golden's tolerance of the reference, but not the bits of the layers in one piece (so the slices did run);
+    the product library never slices: its clip is the lab default's, bit for bit."""
+    env = {"CRFP_CHECK_STORAGE": "bf16"} if storage == "bf16" else {}
+    tol = 6e-2 if storage == "bf16" else 2e-4
+    assert float(_golden_check(dict(env, CRFP_CONV_KSPLIT="2"), lab=True).split()[1]) < tol
+    whole = _golden_check(env, lab=True, want="DIGEST")
+    assert _golden_check(dict(env, CRFP_CONV_KSPLIT="2"), lab=True, want="DIGEST") != whole
+    assert _golden_check(dict(env, CRFP_CONV_KSPLIT="2"), want="DIGEST") == whole
