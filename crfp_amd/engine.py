@@ -19,7 +19,7 @@ def param_names(wiring: str = "dsv"):
 
 
 def embed_mid32(state_dict, mid: int, wiring: str = "dsv", y_only: bool = False):
-    """A CRFP_DSV / CRFP_simple / CRFP state_dict of ``mid_channels = mid`` (16: the reference's constructor default, model/CRFP.py:1388,
+    """A CRFP_DSV / CRFP_DSV_CRA / CRFP_simple / CRFP state_dict of ``mid_channels = mid`` (16: the reference's constructor default, model/CRFP.py:1388,
     and the only width below 32 its `downsample` assertion admits, :206-222) -> the state_dict of the SAME function at mid_channels = 32, which the one-call engine schedules run: every
     tensor of the narrow model sits at fixed channel positions of its 32- (8x maps: 4-) channel twin, the other channels are exact
     zeros (zero weight rows and biases; lrelu / relu / the residual adds keep them zero), and zero weight columns ignore them.  The
@@ -29,10 +29,10 @@ def embed_mid32(state_dict, mid: int, wiring: str = "dsv", y_only: bool = False)
     layout.  Pixel-(un)shuffle channel indices c * r^2 + s survive as they are.  Products with the padding are exact zeros, so the
     results equal the narrow model's up to fp32 summation order (tests: the reference's own mid16 goldens)."""
     import torch as _t
-    if mid != 16 or wiring not in ("dsv", "simple", "dense"):
+    if mid != 16 or wiring not in ("dsv", "cra", "simple", "dense"):
         raise ValueError(f"embed_mid32: mid_channels {mid} / wiring {wiring!r}")
     m, l = mid, mid // 8
-    abl = wiring != "dsv"
+    abl = wiring in ("simple", "dense")
     p = m if abl else 3 * m // 4                     # features a level passes on
     ident = lambda n, base=0: [base + j for j in range(n)]   # noqa: E731
     feat = ident(m)
@@ -76,6 +76,14 @@ def embed_mid32(state_dict, mid: int, wiring: str = "dsv", y_only: bool = False)
     table["downsample.downsample_conv"] = (grp, ident(16 * l), 32, 64)
     table["upsample.upsample_conv"] = (ups_rows, feat, 128 if abl else 96, 32)
     table["upsample_post.upsample_conv"] = (ident(16 * l), ident(p), 64, 32 if abl else 24)
+    if wiring == "cra":   # CRFP_DSV_CRA's four-level fovea encoder LTE_simple_hr_ps(l) (4 l channels at 2x) and the per-level fusion convs (m + 4 l -> m)
+        q4 = ident(4 * l)
+        table["encoder_hr.slice2.1"] = (q4, ident(16 * l), 16, 64)
+        for stem in ("slice2.3", "slice3.0", "slice3.2", "slice4.0", "slice4.2", "conv_lv0", "conv_lv1", "conv_lv2"):
+            table["encoder_hr." + stem] = (q4, q4, 16, 16)
+        table["encoder_hr.conv_lv3"] = (lq, lq, 4, 4)
+        for k in range(3):
+            table[f"conv_tttf_{k}"] = (cur, cur + off(q4, 32), 32, 48)
     co_last = 1 if y_only else 3
     table["conv_last"] = (ident(co_last), lq, co_last, 4)
     out = {}
@@ -142,8 +150,6 @@ class DSVEngine:
         self._stream_hw = None
         self.mid_channels = int(mid_channels)
         if self.mid_channels != 32:
-            if self.WIRING == "cra":
-                raise NotImplementedError("crfp_amd: the CRFP_DSV_CRA engine schedule exists for mid_channels = 32")
             state_dict = embed_mid32(state_dict, self.mid_channels, self.WIRING, bool(y_only))
         self.pack(state_dict)
 

@@ -497,7 +497,6 @@ class CRFP_DSV_CRA(CRFP_DSV):
     types); every other constructor combination runs ``forward_composed`` (per-operator HIP calls), as in CRFP_DSV."""
 
     _engine_class = CRAEngine
-    _engine_mids = (32,)
 
     def __init__(self, device, mid_channels=16, y_only=False, hr_dcn=True, offset_prop=True, spynet_pretrained=None):
         super().__init__(device, mid_channels, y_only, hr_dcn, offset_prop, spynet_pretrained)

@@ -59,7 +59,7 @@ def test_state_dict_tables_match_the_reference_for_every_flag_combination(flags)
         assert list(mine) == list(ref), name
         assert mine == ref, name
         if hasattr(m, "has_engine"):
-            mids = (32,) if name.startswith("cra") else (16, 32)   # mid_channels = 16 runs embedded in the 32-channel schedule
+            mids = (16, 32)   # mid_channels = 16 runs embedded in the 32-channel schedule
             assert m.has_engine() == (kw.get("mid_channels", 16) in mids and kw.get("hr_dcn", True) and kw.get("offset_prop", True))
 
 
@@ -76,7 +76,7 @@ def test_flag_combinations_behave_like_the_reference(flags):
             continue
         m = _model(flags, name, dev)
         # the cases with a one-call engine schedule run it here (their composed twins: test_gpu_cra.py, test_gpu_ablation_engines.py)
-        assert getattr(m, "has_engine", lambda: False)() == (name in ("cra_mid32", "simple_mid32", "dense_mid32", "mid16_default", "mid16_yonly"))
+        assert getattr(m, "has_engine", lambda: False)() == (name in ("cra_mid32", "cra_mid16_yonly", "simple_mid32", "dense_mid32", "mid16_default", "mid16_yonly"))
         lrs, fvs, mks = (T(a).to(dev) for a in synth.make_clip(int(flags[f"{name}.clip_seed"]), 1, int(flags[f"{name}.t"]), h, w, fv_size=fv))
         if f"{name}.forward_error" in flags:
             cls = {"RuntimeError": RuntimeError, "AttributeError": AttributeError}[str(flags[f"{name}.forward_error"])]
@@ -143,7 +143,7 @@ def test_runtime_mirror_routes_what_the_engine_does_not_take(rt_flags):
     assert float((clamped - T(g["oversize.out"])).abs().max()) < 2e-4
 
 
-@pytest.mark.parametrize("cls,wiring", [("CRFP_DSV", "dsv"), ("CRFP_simple", "simple"), ("CRFP", "dense")])
+@pytest.mark.parametrize("cls,wiring", [("CRFP_DSV", "dsv"), ("CRFP_DSV_CRA", "cra"), ("CRFP_simple", "simple"), ("CRFP", "dense")])
 @pytest.mark.parametrize("y_only", [False, True])
 def test_embedded_narrow_tables_have_the_32_channel_shapes_and_keep_every_weight(cls, wiring, y_only, mid=16):
     """No GPU: crfp_amd.engine.embed_mid32 places a narrow model's parameters inside the 32-channel table the engine packs -- same keys,

@@ -143,7 +143,7 @@ def test_ablation_engines_at_the_benchmark_geometry_and_what_they_refuse():
         engine.SimpleEngine(CRFP.CRFP_simple(dev, mid_channels=32).state_dict(), dev).stream_frame(None, None, None)
 
 
-@pytest.mark.parametrize("case", ["mid16_default", "mid16_yonly"])
+@pytest.mark.parametrize("case", ["mid16_default", "mid16_yonly", "cra_mid16_yonly"])
 def test_mid16_runs_the_engine_and_matches_the_reference_golden(flags, case):
     """mid_channels = 16 (the reference's constructor default, model/CRFP.py:1388) through the one-call schedule -- the same function embedded in
     the 32-channel engine (crfp_amd.engine.embed_mid32) -- against the reference's own output and the per-operator composition."""
@@ -163,7 +163,7 @@ def test_mid16_runs_the_engine_and_matches_the_reference_golden(flags, case):
     assert not m.engine().overflowed()
 
 
-@pytest.mark.parametrize("cls", ["CRFP_DSV", "CRFP_simple", "CRFP"])
+@pytest.mark.parametrize("cls", ["CRFP_DSV", "CRFP_DSV_CRA", "CRFP_simple", "CRFP"])
 def test_narrow_models_embedded_in_the_32_channel_schedule(cls, mid=16):
     """Every wiring at mid_channels 16: engine (embedded weights) within 2e-4 of the per-operator composition of the narrow model over a
     2-clip batch of 4 frames; the streaming interface of the narrow CRFP_DSV as well; bf16 storage within bf16 noise."""
@@ -201,5 +201,5 @@ def test_embed_mid32_rejects_what_it_cannot_place():
         engine.embed_mid32(sd16, 48)
     with pytest.raises(ValueError):
         engine.DSVEngine(sd16, dev)                       # a 16-channel table handed over as a 32-channel one
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):      # a 32-channel table announced as a 16-channel one
         engine.CRAEngine(CRFP.CRFP_DSV_CRA(dev, mid_channels=32).state_dict(), dev, mid_channels=16)
